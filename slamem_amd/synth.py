@@ -1,0 +1,97 @@
+"""Synthetic reference / read generator (SURVEY.md Appendix C.2 spec).
+
+Counter-based splitmix64: the k-th draw of a stream seeded with ``seed`` is
+``mix(seed + (k+1) * GAMMA)``, so every draw can be computed independently
+(numpy here, one thread per draw in ``csrc/synth.hip`` on the GPU).
+
+Draw layout (0-based draw index ``k``):
+
+* reference base ``i``            -> draw ``i``                  (``"ACGT"[x & 3]``)
+* read ``r`` start position       -> draw ``n + r*(L+2)``        (``x % (n-L+1)``)
+* read ``r`` base ``i``           -> draw ``n + r*(L+2) + 1 + i`` (substitute when
+  ``(u32)x < (u32)(sub * 2**32)``; replacement ``alt(c)[(x >> 32) % 3]``)
+* read ``r`` strand flip          -> draw ``n + r*(L+2) + 1 + L`` (``x % 100 < rc_percent``)
+
+This is test / bench infrastructure, not part of the MEM engine.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+_ALT = np.frombuffer(b"CGTAGTACTACG", dtype=np.uint8).reshape(4, 3)  # alt(A),alt(C),alt(G),alt(T)
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+_COMP[:] = np.arange(256, dtype=np.uint8)
+for a, b in zip(b"ACGT", b"TGCA"):
+    _COMP[a] = b
+
+
+def splitmix64_at(seed: int, k: np.ndarray) -> np.ndarray:
+    """Value of the k-th (0-based) ``next()`` call of a splitmix64 seeded with ``seed``."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (k.astype(np.uint64) + np.uint64(1)) * GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def make_reference(n: int, seed: int = 42, chunk: int = 1 << 24) -> np.ndarray:
+    """n i.i.d. uniform A/C/G/T bytes (uint8 ASCII)."""
+    out = np.empty(n, dtype=np.uint8)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        x = splitmix64_at(seed, np.arange(s, e, dtype=np.uint64))
+        out[s:e] = _ACGT[(x & np.uint64(3)).astype(np.int64)]
+    return out
+
+
+def make_reads(ref: np.ndarray, first: int, count: int, length: int = 150, sub: float = 0.02,
+               seed: int = 42, rc_percent: int = 0) -> np.ndarray:
+    """Reads ``first .. first+count-1`` as a (count, length) uint8 array."""
+    n = ref.shape[0]
+    L = length
+    thr = np.uint64(int(sub * 4294967296.0) & 0xFFFFFFFF)
+    r = np.arange(first, first + count, dtype=np.uint64)
+    base = np.uint64(n) + r * np.uint64(L + 2)
+    p = splitmix64_at(seed, base) % np.uint64(n - L + 1)
+    idx = p[:, None].astype(np.int64) + np.arange(L, dtype=np.int64)[None, :]
+    c = ref[idx]
+    x = splitmix64_at(seed, base[:, None] + np.uint64(1) + np.arange(L, dtype=np.uint64)[None, :])
+    do_sub = (x & np.uint64(0xFFFFFFFF)) < thr
+    code = np.zeros_like(c)
+    code[c == ord("C")] = 1
+    code[c == ord("G")] = 2
+    code[c == ord("T")] = 3
+    alt = _ALT[code.astype(np.int64), ((x >> np.uint64(32)) % np.uint64(3)).astype(np.int64)]
+    c = np.where(do_sub, alt, c)
+    flip = (splitmix64_at(seed, base + np.uint64(1 + L)) % np.uint64(100)) < np.uint64(rc_percent)
+    if flip.any():
+        c[flip] = _COMP[c[flip][:, ::-1]]
+    return np.ascontiguousarray(c)
+
+
+def write_fasta_reference(path: str, ref: np.ndarray, name: str | None = None, width: int = 80) -> None:
+    n = ref.shape[0]
+    name = name or f"synthetic_ref_{n}"
+    with open(path, "wb") as f:
+        f.write(b">" + name.encode() + b"\n")
+        full = (n // width) * width
+        if full:
+            body = np.empty((n // width, width + 1), dtype=np.uint8)
+            body[:, :width] = ref[:full].reshape(-1, width)
+            body[:, width] = 10
+            f.write(body.tobytes())
+        if n > full:
+            f.write(ref[full:].tobytes() + b"\n")
+
+
+def write_fasta_reads(path: str, reads: np.ndarray, first: int = 0) -> None:
+    with open(path, "wb") as f:
+        for k in range(reads.shape[0]):
+            f.write(b">q%d\n" % (first + k))
+            f.write(reads[k].tobytes())
+            f.write(b"\n")
