@@ -1,0 +1,177 @@
+/* slamem_hip.h -- C ABI of the MI355X-native MEM engine (libslamem_hip.so).
+ *
+ * Drop-in boundary for slaMEM's MEM path.  The reference has no FFI layer: its
+ * boundary is the pair of C headers bwtindex.h + lcparray.h as used by
+ * GetMatches (slamem.c:37-218).  Those are per-base calls on file-static
+ * globals, unusable across a PCIe/GPU boundary, so the ABI below is the coarse
+ * (batched, handle-based, error-code) form of the same operations; every entry
+ * point cites the reference interface it replaces.  Plain C types only: no
+ * torch / HIP types in any signature (streams are passed as void*).
+ *
+ * Conventions
+ *   - every function returns SLAMEM_OK (0) or a SLAMEM_ERR_* code; nothing
+ *     calls exit() (the reference prints to stdout and exit(-1)s:
+ *     slamem.c:58-61, bwtindex.c:1441-1444).  slamem_last_error_message()
+ *     gives the text for the calling thread.
+ *   - "_dev" pointers are device (HBM) pointers on the index's device.
+ *   - rows are BWT rows 0..n (n = text length; row 0 is the '$' suffix);
+ *     intervals are inclusive [top, bottom], as in the reference.
+ *   - coordinates in slamem_mem are 0-based; the CLI prints them 1-based
+ *     like slamem.c:148.
+ */
+#ifndef SLAMEM_HIP_H
+#define SLAMEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMEM_ABI_VERSION 1
+
+enum {
+    SLAMEM_OK = 0,
+    SLAMEM_ERR_ARG = 1,      /* bad argument                                     */
+    SLAMEM_ERR_HIP = 2,      /* a HIP runtime call failed (message has the text) */
+    SLAMEM_ERR_NOMEM = 3,    /* host or device allocation failed                 */
+    SLAMEM_ERR_CAPACITY = 4, /* output buffer too small; *total_out has the need */
+    SLAMEM_ERR_FORMAT = 5,   /* arena / file is not a slamem index               */
+    SLAMEM_ERR_IO = 6,
+    SLAMEM_ERR_NO_DEVICE = 7 /* no usable MI355X: there is NO CPU fallback       */
+};
+
+typedef struct slamem_index slamem_index; /* opaque; one per device, immutable after build */
+
+/* One MEM: T[ref_pos .. ref_pos+length) == Q[query_pos .. query_pos+length),
+ * not extendable on either side.  Replaces the fprintf at slamem.c:148,173. */
+typedef struct {
+    uint32_t ref_pos;
+    uint32_t query_pos; /* in the strand that was scanned (reverse blocks: in the reverse complement, slamem.c:100-102) */
+    uint32_t length;
+} slamem_mem;
+
+typedef struct {
+    uint32_t text_length;  /* n                                           */
+    uint32_t bwt_size;     /* n + 1            == FMI_GetBWTSize(), bwtindex.c:263 */
+    uint32_t num_n_rows;   /* BWT rows holding 'N'                        */
+    uint32_t dollar_row;   /* BWT row holding '$'                         */
+    uint32_t max_lcp;      /* largest LCP value                           */
+    uint32_t sort_rounds;  /* prefix-doubling rounds the build needed     */
+    uint64_t arena_bytes;  /* bytes of HBM the index occupies             */
+    int32_t device;
+    int32_t owns_arena;
+} slamem_index_info;
+
+/* Per-phase device times of the last build / search on this thread's most recent
+ * call, in milliseconds, measured with HIP events on the stream the kernels ran on. */
+typedef struct {
+    float build_total_ms;
+    float build_pack_ms;      /* K1 text pack + histogram                         */
+    float build_sort_ms;      /* K2 suffix sort (all radix passes, all rounds)    */
+    float build_bwt_ms;       /* K3 BWT planes + rank samples                     */
+    float build_lcp_ms;       /* K5 exact LCP                                     */
+    float build_links_ms;     /* K7 PSV / NSV                                     */
+    float search_kernel_ms;   /* K8 the MEM search kernel alone                   */
+    float search_total_ms;    /* K8 + scan + K9 scatter                           */
+    uint64_t search_launches; /* number of K8 launches accumulated since reset    */
+    double search_kernel_ms_sum;
+} slamem_timings;
+
+/* ---- library ---------------------------------------------------------- */
+int slamem_abi_version(void);
+const char *slamem_strerror(int code);
+const char *slamem_last_error_message(void);
+int slamem_device_count(int *count_out);
+int slamem_get_timings(slamem_timings *out);
+int slamem_reset_timings(void);
+
+/* ---- (a) index construction ------------------------------------------- */
+/* Replaces FMI_BuildIndex(texts,sizes,1,&lcp,verbose) (bwtindex.h:7, call at
+ * slamem.c:73) followed by BuildSampledLCPArray(text,n,lcp,minlcp,verbose)
+ * (lcparray.h:1, call at slamem.c:74).  text: n bytes of A,C,G,T,N (any case;
+ * every other byte counts as N, as letterIds does at bwtindex.c:183-196).
+ * The text is borrowed for the call only (the reference frees it right after
+ * the build too, slamem.c:75-77).  Everything runs on the device: suffix sort,
+ * BWT bit-planes + rank samples, exact LCP, PSV/NSV links. */
+int slamem_index_build(const char *text_host, uint32_t n, int device, slamem_index **out);
+int slamem_index_build_device(const void *text_dev, uint32_t n, int device, void *stream, slamem_index **out);
+/* Replaces FMI_FreeIndex() + FreeSampledSuffixArray() (slamem.c:208-209). */
+int slamem_index_free(slamem_index *idx);
+int slamem_index_get_info(const slamem_index *idx, slamem_index_info *out);
+
+/* The index is ONE contiguous HBM arena (4 KiB header + arrays), so that it can
+ * be broadcast to peer GPUs with a single RCCL call and saved / loaded as one
+ * blob (the reference only has a commented-out IDX0 sketch, bwtindex.c:480-579). */
+int slamem_index_arena(const slamem_index *idx, void **arena_dev_out, uint64_t *bytes_out);
+int slamem_index_export(const slamem_index *idx, void *dst_dev, uint64_t dst_bytes, void *stream);
+/* Borrow an arena that a peer built (after ncclBroadcast / torch.distributed.broadcast).
+ * The caller keeps the memory alive until slamem_index_free(). */
+int slamem_index_attach(void *arena_dev, uint64_t bytes, int device, slamem_index **out);
+int slamem_index_save(const slamem_index *idx, const char *path);
+int slamem_index_load(const char *path, int device, slamem_index **out);
+
+/* Structure-level parity (all uniquely defined by the text).
+ * which: one of SLAMEM_ARRAY_*; host_dst must hold count elements of the stated type. */
+enum {
+    SLAMEM_ARRAY_SA = 0,  /* uint32[n+1]  suffix array                                  */
+    SLAMEM_ARRAY_BWT = 1, /* uint8[n+1]   letter ids $=0 N=1 A=2 C=3 G=4 T=5            */
+    SLAMEM_ARRAY_LCP = 2, /* int32[n+2]   exact LCP, [0] = [n+1] = -1                   */
+    SLAMEM_ARRAY_PSV = 3, /* uint32[n+2]  nearest smaller value above (valid for 1..n)  */
+    SLAMEM_ARRAY_NSV = 4  /* uint32[n+2]  nearest smaller value below (valid for 1..n)  */
+};
+int slamem_index_download(const slamem_index *idx, int which, void *host_dst, uint64_t count);
+
+/* ---- fine-grained operations, batched (one lane per element) ------------ */
+/* FMI_FollowLetter (bwtindex.h:8 / bwtindex.c:359): in-place on top/bottom; size_out[i] = new
+ * interval size or 0 (then top/bottom are left unchanged). */
+int slamem_follow_letter_batch(const slamem_index *idx, const char *letters_dev, uint32_t *top_dev,
+                               uint32_t *bottom_dev, uint32_t *size_out_dev, uint64_t count, void *stream);
+/* GetEnclosingLCPInterval (lcparray.h:2 / lcparray.c:330): in-place; depth_out[i] = parent depth, -1 at the root. */
+int slamem_enclosing_interval_batch(const slamem_index *idx, uint32_t *top_dev, uint32_t *bottom_dev,
+                                    int32_t *depth_out_dev, uint64_t count, void *stream);
+/* FMI_PositionInText (bwtindex.h:9 / bwtindex.c:402). */
+int slamem_position_in_text_batch(const slamem_index *idx, const uint32_t *rows_dev, uint32_t *pos_out_dev,
+                                  uint64_t count, void *stream);
+/* FMI_GetCharAtBWTPos (bwtindex.h:10 / bwtindex.c:304): one of "$NACGT". */
+int slamem_char_at_bwt_pos_batch(const slamem_index *idx, const uint32_t *rows_dev, char *chars_out_dev,
+                                 uint64_t count, void *stream);
+
+/* ---- (b) MEM retrieval ---------------------------------------------------- */
+/* Replaces the query loop of GetMatches (slamem.c:90-207) for a BATCH of query
+ * records: per record the forward strand and, if both_strands, its reverse
+ * complement (ReverseComplementSequence, sequence.c:413) are scanned right to
+ * left with backward search + parent-interval widening, and every MEM of
+ * length >= min_len is reported.
+ *
+ *   queries_dev       concatenated query characters (A,C,G,T,N; other bytes = N);
+ *                     8-byte aligned and readable up to the next multiple of 8 bytes
+ *   offsets_dev       uint64[num_queries+1]; record i is [offsets[i], offsets[i+1])
+ *   strand blocks     block b = 2*i + strand when both_strands, else b = i
+ *   mems_dev          out: slamem_mem[mems_capacity], grouped by block, inside a
+ *                     block in the reference's emission order (slamem.c:139-193)
+ *   block_offsets_dev out: uint64[num_blocks+1]; block b owns [off[b], off[b+1])
+ *   workspace_dev     scratch of slamem_find_mems_workspace_bytes() bytes
+ *   total_out         number of MEMs found (also when SLAMEM_ERR_CAPACITY is returned)
+ *
+ * Synchronous with respect to the stream on return (it has to read the total). */
+int slamem_find_mems_workspace_bytes(uint32_t num_queries, int both_strands, uint64_t mems_capacity,
+                                     uint64_t *bytes_out);
+int slamem_find_mems_device(const slamem_index *idx, const void *queries_dev, const uint64_t *offsets_dev,
+                            uint32_t num_queries, uint32_t min_len, int both_strands,
+                            slamem_mem *mems_dev, uint64_t mems_capacity, uint64_t *block_offsets_dev,
+                            void *workspace_dev, uint64_t workspace_bytes, void *stream, uint64_t *total_out);
+
+/* Host-buffer convenience used by the C front end: uploads the batch, runs
+ * slamem_find_mems_device (growing the output buffer if needed) and returns
+ * malloc()ed arrays the caller frees with slamem_host_free(). */
+int slamem_find_mems_host(const slamem_index *idx, const char *queries, const uint64_t *offsets,
+                          uint32_t num_queries, uint32_t min_len, int both_strands,
+                          slamem_mem **mems_out, uint64_t **block_offsets_out, uint64_t *total_out);
+void slamem_host_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMEM_HIP_H */

@@ -1,0 +1,111 @@
+// common.h -- internal definitions shared by the HIP translation units of libslamem_hip.so.
+// gfx950 (MI355X) only.  Nothing here is part of the public ABI (include/slamem_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/slamem_hip.h"
+
+namespace slamem {
+
+// ---------------------------------------------------------------------------------
+// Alphabet (reference: bwtindex.c:39-41,183-196):  $=0 N=1 A=2 C=3 G=4 T=5
+// ---------------------------------------------------------------------------------
+constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
+constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
+constexpr uint32_t kArenaVersion = 1;
+constexpr uint64_t kHeaderBytes = 4096;
+constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
+constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
+
+// FM block: 128 BWT rows in ONE 64-byte line (one HBM/L2 sector pair per rank query).
+//   cnt[c-2] = C[c] + occ(c, rows < 128k) for c in A,C,G,T          (reference a1: letterJumpsSample, bwtindex.c:1454,1481)
+//   p0/p1    = two bit-planes of (letter id - 2) for A,C,G,T rows    (reference a1: bwtBits[3], bwtindex.c:33-37)
+//   ex       = rows whose letter is N or '$' (their plane bits are 0)
+// N is searched through the sorted list of N rows (rare letter), '$' is one known row.
+struct __attribute__((aligned(64))) FMBlock {
+    uint32_t cnt[4];
+    uint64_t p0[2];
+    uint64_t p1[2];
+    uint64_t ex[2];
+};
+static_assert(sizeof(FMBlock) == 64, "FM block must be one 64-byte line");
+
+// Arena header (first 4 KiB of the index arena; also the on-disk header).
+struct ArenaHeader {
+    uint32_t magic_lo, magic_hi;
+    uint32_t version;
+    uint32_t n;           // text length; rows = n + 1
+    uint64_t total_bytes;
+    uint64_t off_fm;      // FMBlock[nblocks]
+    uint64_t off_l8;      // uint8 [n+2]   min(LCP+1, 255)
+    uint64_t off_l32;     // uint32[n+2]   LCP+1  (0 at rows 0 and n+1)
+    uint64_t off_psv;     // uint32[n+2]
+    uint64_t off_nsv;     // uint32[n+2]
+    uint64_t off_sa;      // uint32[n+1]
+    uint64_t off_nrows;   // uint32[num_n]  sorted BWT rows holding N
+    uint32_t nblocks;
+    uint32_t dollar_row;
+    uint32_t num_n;
+    uint32_t max_lcp;
+    uint32_t sort_rounds;
+    uint32_t C[6];        // C[c] = number of characters of text+'$' smaller than c
+    uint32_t reserved[16];
+};
+static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
+
+// What the kernels see (passed by value).
+struct IndexView {
+    const FMBlock* fm;
+    const uint8_t* l8;
+    const uint32_t* l32;
+    const uint32_t* psv;
+    const uint32_t* nsv;
+    const uint32_t* sa;
+    const uint32_t* nrows;
+    uint32_t n;
+    uint32_t nblocks;
+    uint32_t dollar_row;
+    uint32_t num_n;
+};
+
+// Raw record written by the search kernel before the per-block compaction (K9).
+struct RawKey { uint32_t block; uint32_t k; };
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define SLAMEM_HIP(call)                                                         \
+    do {                                                                         \
+        hipError_t e__ = (call);                                                 \
+        if (e__ != hipSuccess) return ::slamem::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+struct Timings {
+    slamem_timings t;
+};
+Timings& thread_timings();
+
+}  // namespace slamem
+
+// The opaque handle of the C ABI.
+struct slamem_index {
+    slamem::ArenaHeader hdr;   // host copy
+    void* arena;               // device
+    uint64_t arena_bytes;
+    int device;
+    int owns_arena;
+    slamem::IndexView view;
+};
+
+namespace slamem {
+void make_view(slamem_index* idx);
+int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t stream, slamem_index** out);
+int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
+                     uint32_t num_queries, uint32_t min_len, int both_strands, slamem_mem* mems_dev,
+                     uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
+                     uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out);
+uint64_t find_mems_workspace_bytes(uint64_t num_blocks, uint64_t mems_capacity);
+}  // namespace slamem

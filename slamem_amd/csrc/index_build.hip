@@ -1,0 +1,708 @@
+// index_build.hip -- north_star (a): build the FM-index and the parent-interval structure on the GPU.
+//
+// Replaces, as one device pipeline (no host fallback):
+//   FMI_BuildIndex          bwtindex.c:1318-1696  (GetLMSs 706, SortLMSs 787, InducedSort 1024, LF/SA samples 1451-1522)
+//   BuildSampledLCPArray    lcparray.c:545-1106   (LCP samples 627-706, PSV/NSV links 782-989)
+//   PackedNumberArray       packednumbers.c:18-71 (temporary BWT; not needed: the BWT goes straight into bit-planes)
+//
+// The reference is a sequential induced sort (pointer chasing); the arrays it produces are uniquely
+// defined by the text, so this build uses what maps to the hardware instead:
+//   K1  pack text to 4-bit codes + letter histogram            streaming, coalesced 16-B loads
+//   K2  suffix sort by prefix doubling: LSD radix sort of 48-bit 16-mer keys, then rounds that only
+//       re-sort the still-ambiguous groups by (group, rank[i+h])
+//   K3  BWT -> 128-row FM blocks (ballot -> bit-planes, rank samples by block scan)
+//   K4  SA kept in full (288 GB HBM: locate is one read instead of a ~31-step LF walk, bwtindex.c:402-420)
+//   K5  exact LCP, Kasai order over text chunks, 16 characters per 64-bit compare
+//   K7  PSV/NSV for every row through a 32-ary min hierarchy (replaces the sampled links of lcparray.c:782-989)
+#include "common.h"
+#include "prims.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace slamem {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ascii_code(uint32_t ch) {
+    uint32_t x = ch & 0xDFu;  // upper case
+    return x == 'A' ? 2u : x == 'C' ? 3u : x == 'G' ? 4u : x == 'T' ? 5u : 1u;  // everything else is N (bwtindex.c:184)
+}
+
+// 16 consecutive 4-bit codes starting at text position p (big-endian nibbles: first character on top).
+__device__ __forceinline__ uint64_t window16(const uint64_t* __restrict__ pk, uint64_t p) {
+    uint64_t w0 = pk[p >> 4];
+    uint32_t sh = (uint32_t)(p & 15u) * 4u;
+    if (sh == 0) return w0;
+    uint64_t w1 = pk[(p >> 4) + 1];
+    return (w0 << sh) | (w1 >> (64u - sh));
+}
+
+__device__ __forceinline__ uint32_t nibble_at(const uint64_t* __restrict__ pk, uint64_t p) {
+    return (uint32_t)(pk[p >> 4] >> (60u - 4u * (uint32_t)(p & 15u))) & 15u;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: pack + histogram.  One thread per 16 characters (one 16-byte load, one 8-byte store).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_text(const uint8_t* __restrict__ text, uint32_t n,
+                                                   uint64_t* __restrict__ pk, uint64_t nwords,
+                                                   uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[6];
+    if (threadIdx.x < 6) sh[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    if (w < nwords) {
+        uint64_t base = w * 16;
+        uint64_t word = 0;
+        if (base + 16 <= n && ((uintptr_t)(text + base) & 15u) == 0) {
+            uint4 v = *reinterpret_cast<const uint4*>(text + base);
+            uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint32_t code = ascii_code((q[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                word |= (uint64_t)code << (60 - 4 * k);
+                c1 += code == 1; c2 += code == 2; c3 += code == 3; c4 += code == 4; c5 += code == 5;
+            }
+        } else {
+            for (int k = 0; k < 16; k++) {
+                uint64_t p = base + k;
+                if (p < n) {
+                    uint32_t code = ascii_code(text[p]);
+                    word |= (uint64_t)code << (60 - 4 * k);
+                    c1 += code == 1; c2 += code == 2; c3 += code == 3; c4 += code == 4; c5 += code == 5;
+                }
+            }
+        }
+        pk[w] = word;
+    }
+    if (c1) atomicAdd(&sh[1], c1);
+    if (c2) atomicAdd(&sh[2], c2);
+    if (c3) atomicAdd(&sh[3], c3);
+    if (c4) atomicAdd(&sh[4], c4);
+    if (c5) atomicAdd(&sh[5], c5);
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x < 6 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: suffix sort
+// ------------------------------------------------------------------------------------------
+// 48-bit key of the first 16 characters of suffix i (3 bits per character, '$'/past-the-end = 0).
+__global__ void __launch_bounds__(256) k_make_keys(const uint64_t* __restrict__ pk, uint32_t rows,
+                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    uint64_t x = window16(pk, i) & 0x7777777777777777ull;
+    x = (x & 0x0F0F0F0F0F0F0F0Full) | ((x & 0xF0F0F0F0F0F0F0F0ull) >> 1);  // 2 chars -> 6 bits per byte
+    x = (x & 0x00FF00FF00FF00FFull) | ((x & 0xFF00FF00FF00FF00ull) >> 2);  // 4 chars -> 12 bits per 16
+    x = (x & 0x0000FFFF0000FFFFull) | ((x & 0xFFFF0000FFFF0000ull) >> 4);  // 8 chars -> 24 bits per 32
+    x = (x & 0x00000000FFFFFFFFull) | ((x >> 32) << 24);                    // 16 chars -> 48 bits
+    keys[i] = x;
+    vals[i] = (uint32_t)i;
+}
+
+// group heads after a sort: head = key differs from the previous one; tmp = head ? position : 0
+__global__ void __launch_bounds__(256) k_heads(const uint64_t* __restrict__ keys, uint64_t m,
+                                               const uint32_t* __restrict__ pos /* nullptr: identity */,
+                                               uint8_t* __restrict__ head, uint32_t* __restrict__ tmp) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    uint8_t h = (k == 0) || (keys[k] != keys[k - 1]);
+    head[k] = h;
+    uint32_t p = pos ? pos[k] : (uint32_t)k;
+    tmp[k] = h ? p : 0u;
+}
+
+// rank[suffix] = position of its group head;  active = group has more than one member;
+// optionally write the suffixes back to their SA positions.
+__global__ void __launch_bounds__(256) k_assign_ranks(const uint32_t* __restrict__ sfx, const uint32_t* __restrict__ gh,
+                                                      const uint8_t* __restrict__ head, uint64_t m,
+                                                      const uint32_t* __restrict__ pos /* nullptr: identity */,
+                                                      uint32_t* __restrict__ sa_writeback /* nullable */,
+                                                      uint32_t* __restrict__ rank, uint8_t* __restrict__ active) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    uint32_t s = sfx[k];
+    rank[s] = gh[k];
+    if (sa_writeback) sa_writeback[pos ? pos[k] : (uint32_t)k] = s;
+    active[k] = !(head[k] && (k + 1 == m || head[k + 1]));
+}
+
+// keys for one doubling round: (group head position, rank of the suffix h characters further on)
+__global__ void __launch_bounds__(256) k_round_keys(const uint32_t* __restrict__ pos, uint64_t m,
+                                                    const uint32_t* __restrict__ sa, const uint32_t* __restrict__ rank,
+                                                    uint32_t n, uint64_t h, uint64_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    uint32_t s = sa[pos[k]];
+    uint64_t t = (uint64_t)s + h;
+    if (t > n) t = n;  // cannot happen for a suffix that still shares its first h characters; keeps reads in bounds
+    keys[k] = ((uint64_t)rank[s] << 32) | (uint64_t)rank[t];
+    vals[k] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: BWT -> FM blocks.  One lane per BWT row, one wave per 64-row half block.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bwt_planes(const uint32_t* __restrict__ sa, const uint64_t* __restrict__ pk,
+                                                    uint32_t rows, uint32_t nblocks, FMBlock* __restrict__ fm,
+                                                    uint4* __restrict__ halfcnt, uint8_t* __restrict__ is_n,
+                                                    uint32_t* __restrict__ dollar_row) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t code = 0;
+    bool valid = r < rows;
+    if (valid) {
+        uint32_t s = sa[r];
+        if (s == 0) { *dollar_row = (uint32_t)r; code = 0; }
+        else code = nibble_at(pk, (uint64_t)s - 1);  // BWT[r] = T[SA[r]-1]   (bwtindex.c:1092,1204)
+        is_n[r] = (code == 1);
+    }
+    bool ex = !valid || code < 2;
+    uint32_t c2 = code - 2u;
+    unsigned long long b0 = __ballot(!ex && (c2 & 1u));
+    unsigned long long b1 = __ballot(!ex && (c2 & 2u));
+    unsigned long long be = __ballot(ex);
+    uint64_t half = r >> 6;  // 64-row half block index
+    if ((threadIdx.x & 63u) == 0 && (half >> 1) < nblocks) {
+        FMBlock* b = &fm[half >> 1];
+        uint32_t hsel = (uint32_t)(half & 1u);
+        b->p0[hsel] = b0;
+        b->p1[hsel] = b1;
+        b->ex[hsel] = be;
+        unsigned long long ne = ~be;
+        uint4 c;
+        c.x = __popcll(~b0 & ~b1 & ne);  // A
+        c.y = __popcll(b0 & ~b1 & ne);   // C
+        c.z = __popcll(~b0 & b1 & ne);   // G
+        c.w = __popcll(b0 & b1 & ne);    // T
+        halfcnt[half] = c;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_block_counts(const uint4* __restrict__ halfcnt, uint32_t nblocks,
+                                                      uint4* __restrict__ blkcnt) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    uint4 a = halfcnt[2 * (uint64_t)b], c = halfcnt[2 * (uint64_t)b + 1];
+    blkcnt[b] = make_uint4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+}
+
+// cnt[c-2] = C[c] + occ(c, rows before the block)      (reference: letterJumpsSample, bwtindex.c:1454,1481)
+__global__ void __launch_bounds__(256) k_rank_samples(const uint4* __restrict__ pre, uint32_t nblocks, uint4 C,
+                                                      FMBlock* __restrict__ fm) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    uint4 p = pre[b];
+    fm[b].cnt[0] = C.x + p.x;
+    fm[b].cnt[1] = C.y + p.y;
+    fm[b].cnt[2] = C.z + p.z;
+    fm[b].cnt[3] = C.w + p.w;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: exact LCP in text order (Kasai): one thread per chunk of text positions, the match length
+// carried from position i to i+1 never drops by more than one.  Stores LCP+1 (0 = "-1" sentinel).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kLcpChunk = 32;
+
+__global__ void __launch_bounds__(256) k_lcp_kasai(const uint64_t* __restrict__ pk, const uint32_t* __restrict__ sa,
+                                                   const uint32_t* __restrict__ rank, uint32_t rows,
+                                                   uint32_t* __restrict__ l32, uint8_t* __restrict__ l8,
+                                                   uint32_t* __restrict__ max_lcp) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i0 = t * kLcpChunk;
+    if (i0 >= rows) return;
+    uint64_t i1 = i0 + kLcpChunk;
+    if (i1 > rows) i1 = rows;
+    uint32_t h = 0, mx = 0;
+    for (uint64_t i = i0; i < i1; i++) {
+        uint32_t r = rank[i];
+        if (r == 0) { h = 0; continue; }  // the '$' suffix: row 0 keeps the sentinel
+        uint64_t j = sa[r - 1];
+        // extend: compare 16 characters per step; the unique '$' guarantees a mismatch before either suffix ends
+        for (;;) {
+            uint64_t x = window16(pk, i + h) ^ window16(pk, j + h);
+            if (x) { h += (uint32_t)__clzll((long long)x) >> 2; break; }
+            h += 16;
+        }
+        l32[r] = h + 1;
+        l8[r] = (uint8_t)(h + 1 < 255u ? h + 1 : 255u);
+        mx = h > mx ? h : mx;
+        if (h) h--;
+    }
+    if (mx) atomicMax(max_lcp, mx);
+}
+
+__global__ void k_lcp_sentinels(uint32_t rows, uint32_t* l32, uint8_t* l8, uint32_t* psv, uint32_t* nsv) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        l32[0] = 0; l8[0] = 0; l32[rows] = 0; l8[rows] = 0;  // LCP[0] = LCP[n+1] = -1   (lcparray.c:624,667)
+        psv[0] = 0; nsv[0] = rows; psv[rows] = 0; nsv[rows] = rows;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: PSV / NSV of every row through a 32-ary hierarchy of minima.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxLevels = 8;
+struct MinLevels {
+    const uint32_t* lv[kMaxLevels];  // lv[0] = the values themselves
+    uint64_t size[kMaxLevels];
+    int count;
+};
+
+__global__ void __launch_bounds__(256) k_min_level(const uint32_t* __restrict__ in, uint64_t in_size,
+                                                   uint32_t* __restrict__ out, uint64_t out_size) {
+    uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= out_size) return;
+    uint64_t lo = b * 32, hi = lo + 32;
+    if (hi > in_size) hi = in_size;
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint64_t j = lo; j < hi; j++) { uint32_t v = in[j]; m = v < m ? v : m; }
+    out[b] = m;
+}
+
+__device__ __forceinline__ uint32_t psv_search(const MinLevels& L, uint64_t i, uint32_t v) {
+    const uint32_t* a = L.lv[0];
+    uint64_t lo = i & ~31ull;
+    for (uint64_t j = i; j-- > lo;)
+        if (a[j] < v) return (uint32_t)j;
+    uint64_t b = i >> 5;
+    int k = 1;
+    uint64_t c = 0;
+    for (;;) {  // climb: blocks to the left of b inside b's group of 32
+        const uint32_t* m = L.lv[k];
+        uint64_t glo = b & ~31ull;
+        bool found = false;
+        for (uint64_t x = b; x-- > glo;)
+            if (m[x] < v) { c = x; found = true; break; }
+        if (found) break;
+        b >>= 5;
+        k++;
+        if (k >= L.count) return 0u;  // unreachable (a[0] = 0 is smaller than every real value); bounds the loop
+    }
+    while (k > 1) {  // descend to the right-most child whose minimum is smaller
+        const uint32_t* m = L.lv[k - 1];
+        uint64_t base = c * 32, x = base + 32;
+        if (x > L.size[k - 1]) x = L.size[k - 1];
+        while (x-- > base)
+            if (m[x] < v) break;
+        c = x;
+        k--;
+    }
+    uint64_t base = c * 32, j = base + 32;
+    if (j > L.size[0]) j = L.size[0];
+    while (j-- > base)
+        if (a[j] < v) break;
+    return (uint32_t)j;
+}
+
+__device__ __forceinline__ uint32_t nsv_search(const MinLevels& L, uint64_t i, uint32_t v) {
+    const uint32_t* a = L.lv[0];
+    uint64_t hi = (i | 31ull) + 1;
+    if (hi > L.size[0]) hi = L.size[0];
+    for (uint64_t j = i + 1; j < hi; j++)
+        if (a[j] < v) return (uint32_t)j;
+    uint64_t b = i >> 5;
+    int k = 1;
+    uint64_t c = 0;
+    for (;;) {
+        const uint32_t* m = L.lv[k];
+        uint64_t ghi = (b | 31ull) + 1;
+        if (ghi > L.size[k]) ghi = L.size[k];
+        bool found = false;
+        for (uint64_t x = b + 1; x < ghi; x++)
+            if (m[x] < v) { c = x; found = true; break; }
+        if (found) break;
+        b >>= 5;
+        k++;
+        if (k >= L.count) return (uint32_t)(L.size[0] - 1);  // unreachable (the last value is 0); bounds the loop
+    }
+    while (k > 1) {
+        const uint32_t* m = L.lv[k - 1];
+        uint64_t x = c * 32, end = x + 32;
+        if (end > L.size[k - 1]) end = L.size[k - 1];
+        for (; x < end; x++)
+            if (m[x] < v) break;
+        c = x;
+        k--;
+    }
+    uint64_t j = c * 32, end = j + 32;
+    if (end > L.size[0]) end = L.size[0];
+    for (; j < end; j++)
+        if (a[j] < v) break;
+    return (uint32_t)j;
+}
+
+__global__ void __launch_bounds__(256) k_links(MinLevels L, uint32_t rows, uint32_t* __restrict__ psv,
+                                               uint32_t* __restrict__ nsv) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;  // rows 1..n
+    if (i >= rows) return;
+    uint32_t v = L.lv[0][i];  // >= 1 for every real row
+    psv[i] = psv_search(L, i, v);
+    nsv[i] = nsv_search(L, i, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// download helpers (structure-level parity)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bwt_codes(IndexView ix, uint8_t* __restrict__ out) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > ix.n) return;
+    const FMBlock* b = &ix.fm[r >> kFmRowsLog2];
+    uint32_t o = (uint32_t)r & (kFmRows - 1), hsel = o >> 6, bit = o & 63u;
+    uint32_t code;
+    if ((b->ex[hsel] >> bit) & 1ull) code = (r == ix.dollar_row) ? 0u : 1u;
+    else code = 2u + (uint32_t)((b->p0[hsel] >> bit) & 1ull) + 2u * (uint32_t)((b->p1[hsel] >> bit) & 1ull);
+    out[r] = (uint8_t)code;
+}
+
+__global__ void __launch_bounds__(256) k_lcp_minus1(const uint32_t* __restrict__ l32, uint64_t count, int32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (int32_t)l32[i] - 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    hipError_t init() { hipError_t e = hipEventCreate(&a); return e != hipSuccess ? e : hipEventCreate(&b); }
+};
+
+inline unsigned grid_for(uint64_t items, unsigned block = 256) { return (unsigned)((items + block - 1) / block); }
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+inline int bits_for(uint64_t v) { int b = 0; while ((1ull << b) <= v && b < 63) b++; return b ? b : 1; }
+
+}  // namespace
+
+void make_view(slamem_index* idx) {
+    char* base = static_cast<char*>(idx->arena);
+    const ArenaHeader& h = idx->hdr;
+    idx->view.fm = reinterpret_cast<const FMBlock*>(base + h.off_fm);
+    idx->view.l8 = reinterpret_cast<const uint8_t*>(base + h.off_l8);
+    idx->view.l32 = reinterpret_cast<const uint32_t*>(base + h.off_l32);
+    idx->view.psv = reinterpret_cast<const uint32_t*>(base + h.off_psv);
+    idx->view.nsv = reinterpret_cast<const uint32_t*>(base + h.off_nsv);
+    idx->view.sa = reinterpret_cast<const uint32_t*>(base + h.off_sa);
+    idx->view.nrows = reinterpret_cast<const uint32_t*>(base + h.off_nrows);
+    idx->view.n = h.n;
+    idx->view.nblocks = h.nblocks;
+    idx->view.dollar_row = h.dollar_row;
+    idx->view.num_n = h.num_n;
+}
+
+int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t stream, slamem_index** out) {
+    if (!text_dev || !out || n == 0 || n > 0xFFFFFFF0u) {
+        set_error("slamem_index_build: text must hold 1 .. 2^32-17 characters");
+        return SLAMEM_ERR_ARG;
+    }
+    SLAMEM_HIP(hipSetDevice(device));
+    const uint32_t rows = n + 1;
+    const uint64_t R = rows;
+    const uint64_t nwords = (R + 15) / 16 + 2;  // two zero words of slack for window16()
+    const uint32_t nblocks = (uint32_t)((R + 1 + kFmRows - 1) >> kFmRowsLog2);  // occ(c, <= n) reads offset n+1
+
+    Timings& tm = thread_timings();
+    EventPair ev_all, ev;
+    SLAMEM_HIP(ev_all.init());
+    SLAMEM_HIP(ev.init());
+    SLAMEM_HIP(hipEventRecord(ev_all.a, stream));
+
+    // ---- K1 ---------------------------------------------------------------------------------
+    DevBuf pk, scal;
+    SLAMEM_HIP(pk.alloc(nwords * 8));
+    SLAMEM_HIP(scal.alloc(64 * 4));  // [0..5] histogram, [8] dollar_row, [9] max_lcp, [10] select count
+    uint32_t* d_scal = scal.as<uint32_t>();
+    SLAMEM_HIP(hipMemsetAsync(pk.p, 0, nwords * 8, stream));
+    SLAMEM_HIP(hipMemsetAsync(d_scal, 0, 64 * 4, stream));
+    SLAMEM_HIP(hipEventRecord(ev.a, stream));
+    hipLaunchKernelGGL(k_pack_text, dim3(grid_for(nwords - 2)), dim3(256), 0, stream,
+                       static_cast<const uint8_t*>(text_dev), n, pk.as<uint64_t>(), nwords - 2, d_scal);
+    SLAMEM_HIP(hipGetLastError());
+    SLAMEM_HIP(hipEventRecord(ev.b, stream));
+    uint32_t h_scal[64];
+    SLAMEM_HIP(hipMemcpyAsync(h_scal, d_scal, sizeof(h_scal), hipMemcpyDeviceToHost, stream));
+    SLAMEM_HIP(hipStreamSynchronize(stream));
+    SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_pack_ms, ev.a, ev.b));
+    const uint32_t num_n = h_scal[1];
+
+    // ---- arena ------------------------------------------------------------------------------
+    ArenaHeader hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    hdr.magic_lo = kArenaMagicLo;
+    hdr.magic_hi = kArenaMagicHi;
+    hdr.version = kArenaVersion;
+    hdr.n = n;
+    hdr.nblocks = nblocks;
+    hdr.num_n = num_n;
+    hdr.C[0] = 0;
+    hdr.C[1] = 1;
+    for (int c = 2; c < 6; c++) hdr.C[c] = hdr.C[c - 1] + h_scal[c - 1];
+    uint64_t off = kHeaderBytes;
+    hdr.off_fm = off;    off = align_up(off + (uint64_t)nblocks * sizeof(FMBlock), 256);
+    hdr.off_l8 = off;    off = align_up(off + (R + 1), 256);
+    hdr.off_l32 = off;   off = align_up(off + (R + 1) * 4, 256);
+    hdr.off_psv = off;   off = align_up(off + (R + 1) * 4, 256);
+    hdr.off_nsv = off;   off = align_up(off + (R + 1) * 4, 256);
+    hdr.off_sa = off;    off = align_up(off + R * 4, 256);
+    hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
+    hdr.total_bytes = off;
+
+    DevBuf arena;
+    if (arena.alloc(hdr.total_bytes) != hipSuccess) {
+        set_error("slamem_index_build: cannot allocate %llu bytes of HBM for the index", (unsigned long long)hdr.total_bytes);
+        return SLAMEM_ERR_NOMEM;
+    }
+    char* base = arena.as<char>();
+    FMBlock* d_fm = reinterpret_cast<FMBlock*>(base + hdr.off_fm);
+    uint8_t* d_l8 = reinterpret_cast<uint8_t*>(base + hdr.off_l8);
+    uint32_t* d_l32 = reinterpret_cast<uint32_t*>(base + hdr.off_l32);
+    uint32_t* d_psv = reinterpret_cast<uint32_t*>(base + hdr.off_psv);
+    uint32_t* d_nsv = reinterpret_cast<uint32_t*>(base + hdr.off_nsv);
+    uint32_t* d_sa = reinterpret_cast<uint32_t*>(base + hdr.off_sa);
+    uint32_t* d_nrows = reinterpret_cast<uint32_t*>(base + hdr.off_nrows);
+    SLAMEM_HIP(hipMemsetAsync(base, 0, kHeaderBytes, stream));
+
+    // ---- K2: suffix sort ----------------------------------------------------------------------
+    DevBuf keysA, keysB, valsA, valsB, rank, flagA, flagB, tmp32, gh, posA, posB, sorttmp;
+    if (keysA.alloc(R * 8) != hipSuccess || keysB.alloc(R * 8) != hipSuccess || valsA.alloc(R * 4) != hipSuccess ||
+        valsB.alloc(R * 4) != hipSuccess || rank.alloc(R * 4) != hipSuccess || flagA.alloc(R) != hipSuccess ||
+        flagB.alloc(R) != hipSuccess || tmp32.alloc(R * 4) != hipSuccess || gh.alloc(R * 4) != hipSuccess ||
+        posA.alloc(R * 4) != hipSuccess || posB.alloc(R * 4) != hipSuccess) {
+        set_error("slamem_index_build: cannot allocate suffix-sort scratch (%llu rows)", (unsigned long long)R);
+        return SLAMEM_ERR_NOMEM;
+    }
+    size_t tmp_bytes = 0, need = 0;
+    SLAMEM_HIP(sort_pairs_u64_u32(nullptr, need, keysA.as<uint64_t>(), keysB.as<uint64_t>(), valsA.as<uint32_t>(),
+                                  valsB.as<uint32_t>(), R, 0, 64, stream));
+    tmp_bytes = need;
+    SLAMEM_HIP(scan_max_inclusive_u32(nullptr, need, tmp32.as<uint32_t>(), gh.as<uint32_t>(), R, stream));
+    tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
+    SLAMEM_HIP(select_indices_u32(nullptr, need, flagA.as<uint8_t>(), posA.as<uint32_t>(), d_scal + 10, R, stream));
+    tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
+    SLAMEM_HIP(select_flagged_u32(nullptr, need, posA.as<uint32_t>(), flagA.as<uint8_t>(), posB.as<uint32_t>(), d_scal + 10, R, stream));
+    tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
+    SLAMEM_HIP(scan_sum_exclusive_uint4(nullptr, need, (const uint4*)nullptr, (uint4*)nullptr, nblocks, stream));
+    tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
+    SLAMEM_HIP(sorttmp.alloc(tmp_bytes));
+
+    SLAMEM_HIP(hipEventRecord(ev.a, stream));
+    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(R)), dim3(256), 0, stream, pk.as<uint64_t>(), rows,
+                       keysA.as<uint64_t>(), valsA.as<uint32_t>());
+    SLAMEM_HIP(hipGetLastError());
+    need = tmp_bytes;
+    SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysA.as<uint64_t>(), keysB.as<uint64_t>(), valsA.as<uint32_t>(),
+                                  d_sa, R, 0, 48, stream));
+    hipLaunchKernelGGL(k_heads, dim3(grid_for(R)), dim3(256), 0, stream, keysB.as<uint64_t>(), R,
+                       (const uint32_t*)nullptr, flagA.as<uint8_t>(), tmp32.as<uint32_t>());
+    need = tmp_bytes;
+    SLAMEM_HIP(scan_max_inclusive_u32(sorttmp.p, need, tmp32.as<uint32_t>(), gh.as<uint32_t>(), R, stream));
+    hipLaunchKernelGGL(k_assign_ranks, dim3(grid_for(R)), dim3(256), 0, stream, d_sa, gh.as<uint32_t>(),
+                       flagA.as<uint8_t>(), R, (const uint32_t*)nullptr, (uint32_t*)nullptr, rank.as<uint32_t>(),
+                       flagB.as<uint8_t>());
+    SLAMEM_HIP(hipGetLastError());
+    need = tmp_bytes;
+    SLAMEM_HIP(select_indices_u32(sorttmp.p, need, flagB.as<uint8_t>(), posA.as<uint32_t>(), d_scal + 10, R, stream));
+    uint32_t m = 0;
+    SLAMEM_HIP(hipMemcpyAsync(&m, d_scal + 10, 4, hipMemcpyDeviceToHost, stream));
+    SLAMEM_HIP(hipStreamSynchronize(stream));
+
+    uint32_t rounds = 0;
+    uint64_t h = 16;
+    uint32_t* pos_cur = posA.as<uint32_t>();
+    uint32_t* pos_nxt = posB.as<uint32_t>();
+    const int key_bits = 32 + bits_for(R);
+    while (m > 0) {
+        rounds++;
+        if (rounds > 40) { set_error("slamem_index_build: suffix sort did not converge"); return SLAMEM_ERR_HIP; }
+        hipLaunchKernelGGL(k_round_keys, dim3(grid_for(m)), dim3(256), 0, stream, pos_cur, (uint64_t)m, d_sa,
+                           rank.as<uint32_t>(), n, h, keysA.as<uint64_t>(), valsA.as<uint32_t>());
+        SLAMEM_HIP(hipGetLastError());
+        need = tmp_bytes;
+        SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysA.as<uint64_t>(), keysB.as<uint64_t>(), valsA.as<uint32_t>(),
+                                      valsB.as<uint32_t>(), m, 0, key_bits > 64 ? 64 : key_bits, stream));
+        hipLaunchKernelGGL(k_heads, dim3(grid_for(m)), dim3(256), 0, stream, keysB.as<uint64_t>(), (uint64_t)m,
+                           (const uint32_t*)pos_cur, flagA.as<uint8_t>(), tmp32.as<uint32_t>());
+        need = tmp_bytes;
+        SLAMEM_HIP(scan_max_inclusive_u32(sorttmp.p, need, tmp32.as<uint32_t>(), gh.as<uint32_t>(), m, stream));
+        hipLaunchKernelGGL(k_assign_ranks, dim3(grid_for(m)), dim3(256), 0, stream, valsB.as<uint32_t>(),
+                           gh.as<uint32_t>(), flagA.as<uint8_t>(), (uint64_t)m, (const uint32_t*)pos_cur, d_sa,
+                           rank.as<uint32_t>(), flagB.as<uint8_t>());
+        SLAMEM_HIP(hipGetLastError());
+        need = tmp_bytes;
+        SLAMEM_HIP(select_flagged_u32(sorttmp.p, need, pos_cur, flagB.as<uint8_t>(), pos_nxt, d_scal + 10, m, stream));
+        SLAMEM_HIP(hipMemcpyAsync(&m, d_scal + 10, 4, hipMemcpyDeviceToHost, stream));
+        SLAMEM_HIP(hipStreamSynchronize(stream));
+        uint32_t* t = pos_cur; pos_cur = pos_nxt; pos_nxt = t;
+        h *= 2;
+    }
+    SLAMEM_HIP(hipEventRecord(ev.b, stream));
+    SLAMEM_HIP(hipEventSynchronize(ev.b));
+    SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_sort_ms, ev.a, ev.b));
+    hdr.sort_rounds = rounds;
+    // rank[] is now the inverse suffix array.
+
+    // ---- K3: BWT planes + rank samples ------------------------------------------------------------
+    SLAMEM_HIP(hipEventRecord(ev.a, stream));
+    SLAMEM_HIP(hipMemsetAsync(d_fm, 0, (uint64_t)nblocks * sizeof(FMBlock), stream));
+    uint4* d_half = keysA.as<uint4>();            // 2*nblocks uint4  (scratch reuse: R*8 bytes >= nblocks*32)
+    uint4* d_blk = keysB.as<uint4>();             // nblocks uint4
+    uint4* d_pre = d_blk + nblocks;               // nblocks uint4   (nblocks*32 <= R*8 holds for R >= 4*nblocks)
+    DevBuf small;                                 // tiny texts: the aliasing bound above fails, use a private buffer
+    if ((uint64_t)nblocks * 32 > R * 8) {
+        SLAMEM_HIP(small.alloc((uint64_t)nblocks * 64));
+        d_half = small.as<uint4>();
+        d_blk = d_half + 2 * (uint64_t)nblocks;
+        d_pre = d_blk + nblocks;
+    }
+    SLAMEM_HIP(hipMemsetAsync(d_half, 0, (uint64_t)nblocks * 32, stream));
+    hipLaunchKernelGGL(k_bwt_planes, dim3(grid_for((uint64_t)nblocks * kFmRows)), dim3(256), 0, stream, d_sa,
+                       pk.as<uint64_t>(), rows, nblocks, d_fm, d_half, flagA.as<uint8_t>(), d_scal + 8);
+    SLAMEM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_block_counts, dim3(grid_for(nblocks)), dim3(256), 0, stream, d_half, nblocks, d_blk);
+    need = tmp_bytes;
+    SLAMEM_HIP(scan_sum_exclusive_uint4(sorttmp.p, need, d_blk, d_pre, nblocks, stream));
+    hipLaunchKernelGGL(k_rank_samples, dim3(grid_for(nblocks)), dim3(256), 0, stream, d_pre, nblocks,
+                       make_uint4(hdr.C[2], hdr.C[3], hdr.C[4], hdr.C[5]), d_fm);
+    SLAMEM_HIP(hipGetLastError());
+    if (num_n) {
+        need = tmp_bytes;
+        SLAMEM_HIP(select_indices_u32(sorttmp.p, need, flagA.as<uint8_t>(), d_nrows, d_scal + 10, R, stream));
+    }
+    SLAMEM_HIP(hipEventRecord(ev.b, stream));
+    SLAMEM_HIP(hipEventSynchronize(ev.b));
+    SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_bwt_ms, ev.a, ev.b));
+
+    // ---- K5: LCP --------------------------------------------------------------------------------------
+    SLAMEM_HIP(hipEventRecord(ev.a, stream));
+    hipLaunchKernelGGL(k_lcp_sentinels, dim3(1), dim3(64), 0, stream, rows, d_l32, d_l8, d_psv, d_nsv);
+    hipLaunchKernelGGL(k_lcp_kasai, dim3(grid_for((R + kLcpChunk - 1) / kLcpChunk)), dim3(256), 0, stream,
+                       pk.as<uint64_t>(), d_sa, rank.as<uint32_t>(), rows, d_l32, d_l8, d_scal + 9);
+    SLAMEM_HIP(hipGetLastError());
+    SLAMEM_HIP(hipEventRecord(ev.b, stream));
+    SLAMEM_HIP(hipEventSynchronize(ev.b));
+    SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_lcp_ms, ev.a, ev.b));
+
+    // ---- K7: PSV / NSV ------------------------------------------------------------------------------------
+    SLAMEM_HIP(hipEventRecord(ev.a, stream));
+    MinLevels L;
+    memset(&L, 0, sizeof(L));
+    L.lv[0] = d_l32;
+    L.size[0] = R + 1;
+    L.count = 1;
+    {
+        uint32_t* lvbuf = keysA.as<uint32_t>();  // about (R+1)/31 words in total; keysA holds 2R words
+        uint64_t used = 0, cap = R * 2 - 1;       // in uint32 units (one word kept for the guard level)
+        uint64_t sz = R + 1;
+        std::vector<uint64_t> sizes;
+        uint64_t total = 0;
+        for (uint64_t s = sz; s > 1;) { s = (s + 31) / 32; sizes.push_back(s); total += s; }
+        if (total > cap) { set_error("slamem_index_build: internal: min-hierarchy scratch"); return SLAMEM_ERR_HIP; }
+        for (size_t k = 0; k < sizes.size(); k++) {
+            if (L.count >= kMaxLevels) { set_error("slamem_index_build: internal: too many min levels"); return SLAMEM_ERR_HIP; }
+            uint32_t* outp = lvbuf + used;
+            hipLaunchKernelGGL(k_min_level, dim3(grid_for(sizes[k])), dim3(256), 0, stream, L.lv[L.count - 1],
+                               L.size[L.count - 1], outp, sizes[k]);
+            L.lv[L.count] = outp;
+            L.size[L.count] = sizes[k];
+            L.count++;
+            used += sizes[k];
+        }
+        // one extra all-zero top level so that a climb never indexes past the last real level
+        if (L.count < kMaxLevels) {
+            uint32_t* outp = lvbuf + used;
+            SLAMEM_HIP(hipMemsetAsync(outp, 0, 4, stream));
+            L.lv[L.count] = outp;
+            L.size[L.count] = 1;
+            L.count++;
+        }
+    }
+    SLAMEM_HIP(hipGetLastError());
+    if (n >= 1) {
+        hipLaunchKernelGGL(k_links, dim3(grid_for(n)), dim3(256), 0, stream, L, rows, d_psv, d_nsv);
+        SLAMEM_HIP(hipGetLastError());
+    }
+    SLAMEM_HIP(hipEventRecord(ev.b, stream));
+    SLAMEM_HIP(hipMemcpyAsync(h_scal, d_scal, sizeof(h_scal), hipMemcpyDeviceToHost, stream));
+    SLAMEM_HIP(hipStreamSynchronize(stream));
+    SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_links_ms, ev.a, ev.b));
+    hdr.dollar_row = h_scal[8];
+    hdr.max_lcp = h_scal[9];
+
+    SLAMEM_HIP(hipMemcpyAsync(base, &hdr, sizeof(hdr), hipMemcpyHostToDevice, stream));
+    SLAMEM_HIP(hipEventRecord(ev_all.b, stream));
+    SLAMEM_HIP(hipStreamSynchronize(stream));
+    SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_total_ms, ev_all.a, ev_all.b));
+
+    slamem_index* idx = static_cast<slamem_index*>(calloc(1, sizeof(slamem_index)));
+    if (!idx) { set_error("out of host memory"); return SLAMEM_ERR_NOMEM; }
+    idx->hdr = hdr;
+    idx->arena = arena.p;
+    arena.p = nullptr;  // ownership moves to the handle
+    idx->arena_bytes = hdr.total_bytes;
+    idx->device = device;
+    idx->owns_arena = 1;
+    make_view(idx);
+    *out = idx;
+    return SLAMEM_OK;
+}
+
+int download_array(const slamem_index* idx, int which, void* host_dst, uint64_t count) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    const uint64_t R = (uint64_t)idx->hdr.n + 1;
+    const IndexView& v = idx->view;
+    switch (which) {
+    case SLAMEM_ARRAY_SA:
+        if (count != R) break;
+        SLAMEM_HIP(hipMemcpy(host_dst, v.sa, R * 4, hipMemcpyDeviceToHost));
+        return SLAMEM_OK;
+    case SLAMEM_ARRAY_PSV:
+        if (count != R + 1) break;
+        SLAMEM_HIP(hipMemcpy(host_dst, v.psv, (R + 1) * 4, hipMemcpyDeviceToHost));
+        return SLAMEM_OK;
+    case SLAMEM_ARRAY_NSV:
+        if (count != R + 1) break;
+        SLAMEM_HIP(hipMemcpy(host_dst, v.nsv, (R + 1) * 4, hipMemcpyDeviceToHost));
+        return SLAMEM_OK;
+    case SLAMEM_ARRAY_BWT: {
+        if (count != R) break;
+        DevBuf d;
+        SLAMEM_HIP(d.alloc(R));
+        hipLaunchKernelGGL(k_bwt_codes, dim3(grid_for(R)), dim3(256), 0, 0, v, d.as<uint8_t>());
+        SLAMEM_HIP(hipGetLastError());
+        SLAMEM_HIP(hipMemcpy(host_dst, d.p, R, hipMemcpyDeviceToHost));
+        return SLAMEM_OK;
+    }
+    case SLAMEM_ARRAY_LCP: {
+        if (count != R + 1) break;
+        DevBuf d;
+        SLAMEM_HIP(d.alloc((R + 1) * 4));
+        hipLaunchKernelGGL(k_lcp_minus1, dim3(grid_for(R + 1)), dim3(256), 0, 0, v.l32, R + 1, d.as<int32_t>());
+        SLAMEM_HIP(hipGetLastError());
+        SLAMEM_HIP(hipMemcpy(host_dst, d.p, (R + 1) * 4, hipMemcpyDeviceToHost));
+        return SLAMEM_OK;
+    }
+    default:
+        set_error("slamem_index_download: unknown array id %d", which);
+        return SLAMEM_ERR_ARG;
+    }
+    set_error("slamem_index_download: wrong element count for array %d", which);
+    return SLAMEM_ERR_ARG;
+}
+
+}  // namespace slamem

@@ -1,0 +1,422 @@
+// mem_search.hip -- north_star (b): per-query backward search + parent-interval MEM extension.
+//
+// Replaces the hot body of GetMatches (slamem.c:105-199) and every index query it calls:
+//   FMI_FollowLetter          bwtindex.c:359-400   -> follow()
+//   FMI_LetterJump/BitsSetCount bwtindex.c:315-356 -> occ_lt()  (hardware popcount on a 128-row block)
+//   FMI_GetCharAtBWTPos       bwtindex.c:304-313   -> bwt_code()
+//   FMI_PositionInText        bwtindex.c:402-420   -> one read of the full suffix array
+//   GetEnclosingLCPInterval   lcparray.c:330-423   -> parent()  (semantics of lcparray.c:514-523)
+//   GetLcpPosFromBwtPos / GetLcpValueFromLcpPos / GetBwtPosFromLcpPos / GetPrefixLinkFromLcpPos / IsTopCorner
+//                             lcparray.c:119-328   -> subsumed: LCP and both links are stored for EVERY row
+//                                                     (1 + 4 + 4 + 4 bytes per row in HBM instead of a sampled
+//                                                     structure that costs 4-6 dependent probes per parent call)
+//   ReverseComplementSequence sequence.c:413-430   -> folded into the query fetch of the reverse-strand lane
+//
+// Work mapping: one lane per (query record, strand) -- the scan of one strand is a chain of ~2 dependent
+// random reads per base, so throughput comes from occupancy (thousands of independent chains per CU), not
+// from splitting a chain.  MEMs are appended to a raw list through one wave-aggregated atomic per emitting
+// wave-instruction and put into (block, emission order) by K9.
+#include "common.h"
+#include "prims.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace slamem {
+
+// ------------------------------------------------------------------------------------------
+// device-side index queries
+// ------------------------------------------------------------------------------------------
+struct Blk {
+    uint4 a;  // cnt[0..3]
+    uint4 b;  // p0[0], p0[1]
+    uint4 c;  // p1[0], p1[1]
+    uint4 d;  // ex[0], ex[1]
+};
+
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+__device__ __forceinline__ Blk load_blk(const FMBlock* __restrict__ fm, uint32_t bi) {
+    const uint4* p = reinterpret_cast<const uint4*>(fm + bi);
+    Blk k;
+    k.a = p[0]; k.b = p[1]; k.c = p[2]; k.d = p[3];
+    return k;
+}
+
+// C[c] + occ(c, rows < off of this block), c2 = letter id - 2 in 0..3, off in 0..127
+__device__ __forceinline__ uint32_t occ_lt(const Blk& k, uint32_t c2, uint32_t off) {
+    uint64_t p00 = u64_of(k.b.x, k.b.y), p01 = u64_of(k.b.z, k.b.w);
+    uint64_t p10 = u64_of(k.c.x, k.c.y), p11 = u64_of(k.c.z, k.c.w);
+    uint64_t e0 = u64_of(k.d.x, k.d.y), e1 = u64_of(k.d.z, k.d.w);
+    uint64_t f0 = (c2 & 1u) ? ~0ull : 0ull, f1 = (c2 & 2u) ? ~0ull : 0ull;
+    uint64_t m0 = ~(p00 ^ f0) & ~(p10 ^ f1) & ~e0;
+    uint64_t m1 = ~(p01 ^ f0) & ~(p11 ^ f1) & ~e1;
+    uint32_t cnt = c2 == 0 ? k.a.x : c2 == 1 ? k.a.y : c2 == 2 ? k.a.z : k.a.w;
+    uint32_t lo = off < 64u ? off : 64u, hi = off < 64u ? 0u : off - 64u;
+    uint64_t mlo = lo == 64u ? ~0ull : ((1ull << lo) - 1ull);
+    uint64_t mhi = (1ull << hi) - 1ull;  // hi <= 63
+    return cnt + (uint32_t)__popcll(m0 & mlo) + (uint32_t)__popcll(m1 & mhi);
+}
+
+// number of N rows strictly below `row`
+__device__ __forceinline__ uint32_t n_rows_lt(const IndexView& ix, uint32_t row) {
+    uint32_t lo = 0, hi = ix.num_n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ix.nrows[mid] < row) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// FMI_GetCharAtBWTPos as a letter id
+__device__ __forceinline__ uint32_t bwt_code(const IndexView& ix, uint32_t row) {
+    const FMBlock* b = ix.fm + (row >> kFmRowsLog2);
+    uint32_t o = row & (kFmRows - 1u), hs = o >> 6, bit = o & 63u;
+    uint64_t e = b->ex[hs];
+    if ((e >> bit) & 1ull) return row == ix.dollar_row ? 0u : 1u;
+    return 2u + (uint32_t)((b->p0[hs] >> bit) & 1ull) + 2u * (uint32_t)((b->p1[hs] >> bit) & 1ull);
+}
+
+// FMI_FollowLetter: returns true and updates [top,bot] when the extended string occurs
+__device__ __forceinline__ bool follow(const IndexView& ix, uint32_t c, uint32_t& top, uint32_t& bot) {
+    uint32_t nt, nb;
+    if (c >= 2u) {
+        uint32_t bi_t = top >> kFmRowsLog2, bi_b = (bot + 1u) >> kFmRowsLog2;
+        Blk kt = load_blk(ix.fm, bi_t);
+        nt = occ_lt(kt, c - 2u, top & (kFmRows - 1u));
+        if (bi_b == bi_t) nb = occ_lt(kt, c - 2u, (bot + 1u) & (kFmRows - 1u));
+        else { Blk kb = load_blk(ix.fm, bi_b); nb = occ_lt(kb, c - 2u, (bot + 1u) & (kFmRows - 1u)); }
+    } else {  // N: C[N] = 1 (only '$' is smaller)
+        if (ix.num_n == 0) return false;
+        nt = 1u + n_rows_lt(ix, top);
+        nb = 1u + n_rows_lt(ix, bot + 1u);
+    }
+    if (nt >= nb) return false;  // nb is one past the new bottom
+    top = nt;
+    bot = nb - 1u;
+    return true;
+}
+
+// GetEnclosingLCPInterval: parent LCP-interval of [top,bot]; returns its depth, -1 at the root.
+__device__ __forceinline__ int parent(const IndexView& ix, uint32_t& top, uint32_t& bot) {
+    uint32_t a = ix.l8[top], b = ix.l8[bot + 1u];
+    if (a == 255u) a = ix.l32[top];
+    if (b == 255u) b = ix.l32[bot + 1u];
+    uint32_t d = a > b ? a : b;  // values are LCP+1
+    if (d == 0u) return -1;
+    if (a == d) top = ix.psv[top];
+    if (b == d) bot = ix.nsv[bot + 1u] - 1u;
+    return (int)(d - 1u);
+}
+
+__device__ __forceinline__ uint32_t ascii_code_q(uint32_t ch) {
+    uint32_t x = ch & 0xDFu;
+    return x == 'A' ? 2u : x == 'C' ? 3u : x == 'G' ? 4u : x == 'T' ? 5u : 1u;
+}
+
+// ------------------------------------------------------------------------------------------
+// K8: the MEM search kernel
+// ------------------------------------------------------------------------------------------
+struct SearchArgs {
+    IndexView ix;
+    const uint64_t* qwords;    // query characters viewed as 8-byte words
+    const uint64_t* offsets;   // [num_queries+1]
+    uint32_t num_queries;
+    uint32_t strands;          // 1 or 2
+    uint32_t min_len;
+    uint32_t pad;
+    uint64_t capacity;         // raw records that fit
+    unsigned long long* total; // running number of MEMs
+    RawKey* raw_key;
+    slamem_mem* raw_mem;
+    uint32_t* block_counts;    // [num_blocks + 1]
+};
+
+struct QueryCursor {
+    const uint64_t* words;
+    uint64_t base;    // byte offset of the record
+    uint32_t len;
+    uint32_t rev;     // reverse-complement view
+    uint64_t widx;
+    uint64_t w;
+    __device__ __forceinline__ void init(const uint64_t* q, uint64_t b, uint32_t l, uint32_t r) {
+        words = q; base = b; len = l; rev = r; widx = ~0ull; w = 0;
+    }
+    // letter id of position j of the scanned strand
+    __device__ __forceinline__ uint32_t at(uint32_t j) {
+        uint64_t p = base + (rev ? (uint64_t)(len - 1u - j) : (uint64_t)j);
+        uint64_t wi = p >> 3;
+        if (wi != widx) { w = words[wi]; widx = wi; }
+        uint32_t c = ascii_code_q((uint32_t)(w >> ((p & 7u) * 8u)) & 0xFFu);
+        return (rev && c >= 2u) ? 7u - c : c;  // A<->T, C<->G; N stays N  (sequence.c:419-426)
+    }
+};
+
+__device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t row, uint32_t j,
+                                     uint32_t len) {
+    uint32_t r = A.ix.sa[row];  // FMI_PositionInText
+    unsigned long long slot = atomicAdd(A.total, 1ull);  // the compiler aggregates this per wave
+    if (slot < A.capacity) {
+        A.raw_key[slot] = RawKey{blockid, k};
+        A.raw_mem[slot] = slamem_mem{r, j, len};
+    }
+    k++;
+}
+
+__global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t nblocks = (uint64_t)A.num_queries * A.strands;
+    if (g >= nblocks) return;
+    uint32_t qi = (uint32_t)(A.strands == 2 ? g >> 1 : g);
+    uint32_t rev = A.strands == 2 ? (uint32_t)(g & 1u) : 0u;
+    uint64_t o0 = A.offsets[qi], o1 = A.offsets[qi + 1];
+    uint32_t len = (uint32_t)(o1 - o0);
+    const IndexView& ix = A.ix;
+    const uint32_t L = A.min_len;
+
+    QueryCursor qc;
+    qc.init(A.qwords, o0, len, rev);
+
+    uint32_t top = 0, bot = ix.n;  // root: all rows  (slamem.c:110-111)
+    int depth = 0;
+    uint32_t k = 0;
+    uint32_t cur = len ? qc.at(len - 1u) : 0u;
+    for (uint32_t j = len; j-- > 0u;) {  // slamem.c:114
+        uint32_t c = cur;
+        uint32_t left = j ? qc.at(j - 1u) : 0xFFu;  // next character to the left; nothing at j == 0 (slamem.c:137-138)
+        cur = left;
+        // extend to the left, widening to parent intervals while the extension fails (slamem.c:121-128)
+        for (;;) {
+            if (follow(ix, c, top, bot)) break;
+            int d = parent(ix, top, bot);
+            depth = d;
+            if (d < 0) break;  // root and the letter does not occur at all
+        }
+        depth++;  // slamem.c:129
+        if ((uint32_t)depth >= L && depth > 0) {  // slamem.c:130
+            uint32_t t = top, b = bot, pt = bot + 1u, pb = bot;
+            int msz = depth;
+            while (msz >= (int)L) {  // this interval and every ancestor that is still deep enough (slamem.c:139)
+                for (uint32_t row = t; row != pt; row++)  // new rows above (slamem.c:140)
+                    if (bwt_code(ix, row) != left) emit(A, (uint32_t)g, k, row, j, (uint32_t)msz);
+                for (uint32_t row = b; row != pb; row--)  // new rows below, bottom-up (slamem.c:165)
+                    if (bwt_code(ix, row) != left) emit(A, (uint32_t)g, k, row, j, (uint32_t)msz);
+                pt = t;
+                pb = b;
+                msz = parent(ix, t, b);  // slamem.c:192
+            }
+        }
+    }
+    A.block_counts[g] = k;
+}
+
+// K9: raw list -> grouped output
+__global__ void __launch_bounds__(256) k_scatter_mems(const RawKey* __restrict__ key, const slamem_mem* __restrict__ raw,
+                                                      uint64_t count, const uint64_t* __restrict__ block_offsets,
+                                                      slamem_mem* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    RawKey kk = key[i];
+    out[block_offsets[kk.block] + kk.k] = raw[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// fine-grained batch kernels (one lane per element) -- same device functions as K8
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_follow_batch(IndexView ix, const char* __restrict__ letters, uint32_t* top,
+                                                      uint32_t* bot, uint32_t* size_out, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t t = top[i], b = bot[i];
+    if (t > b || b > ix.n) { size_out[i] = 0; return; }
+    bool ok = follow(ix, ascii_code_q((uint8_t)letters[i]), t, b);
+    if (ok) { top[i] = t; bot[i] = b; size_out[i] = b - t + 1u; }
+    else size_out[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_parent_batch(IndexView ix, uint32_t* top, uint32_t* bot, int32_t* depth_out,
+                                                      uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t t = top[i], b = bot[i];
+    if (t > b || b > ix.n) { depth_out[i] = -2; return; }
+    depth_out[i] = parent(ix, t, b);
+    top[i] = t;
+    bot[i] = b;
+}
+
+__global__ void __launch_bounds__(256) k_locate_batch(IndexView ix, const uint32_t* __restrict__ rows, uint32_t* out,
+                                                      uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t r = rows[i];
+    out[i] = r <= ix.n ? ix.sa[r] : 0xFFFFFFFFu;
+}
+
+__global__ void __launch_bounds__(256) k_bwtchar_batch(IndexView ix, const uint32_t* __restrict__ rows, char* out,
+                                                       uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t r = rows[i];
+    const char L[] = {'$', 'N', 'A', 'C', 'G', 'T'};
+    out[i] = r <= ix.n ? L[bwt_code(ix, r)] : '?';
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+namespace {
+inline unsigned grid_for(uint64_t items, unsigned block = 256) { return (unsigned)((items + block - 1) / block); }
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+struct WorkspaceLayout {
+    uint64_t off_total, off_counts, off_rawkey, off_rawmem, off_scan, scan_bytes, bytes;
+};
+
+WorkspaceLayout layout_workspace(uint64_t num_blocks, uint64_t capacity) {
+    WorkspaceLayout w;
+    uint64_t off = 0;
+    w.off_total = off;   off = align_up(off + 64, 256);
+    w.off_counts = off;  off = align_up(off + (num_blocks + 1) * 4, 256);
+    w.off_rawkey = off;  off = align_up(off + capacity * sizeof(RawKey), 256);
+    w.off_rawmem = off;  off = align_up(off + capacity * sizeof(slamem_mem), 256);
+    size_t need = 0;
+    (void)scan_sum_exclusive_u32_u64(nullptr, need, nullptr, nullptr, num_blocks, 0);
+    w.scan_bytes = need;
+    w.off_scan = off;    off = align_up(off + need, 256);
+    w.bytes = off;
+    return w;
+}
+}  // namespace
+
+uint64_t find_mems_workspace_bytes(uint64_t num_blocks, uint64_t mems_capacity) {
+    return layout_workspace(num_blocks, mems_capacity).bytes;
+}
+
+int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
+                     uint32_t num_queries, uint32_t min_len, int both_strands, slamem_mem* mems_dev,
+                     uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
+                     uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out) {
+    if (!idx || !offsets_dev || !block_offsets_dev || !workspace_dev || !total_out || (!mems_dev && mems_capacity) ||
+        (!queries_dev && num_queries)) {
+        set_error("slamem_find_mems_device: null argument");
+        return SLAMEM_ERR_ARG;
+    }
+    if (min_len < 1) {
+        set_error("slamem_find_mems_device: minimum MEM length must be >= 1");
+        return SLAMEM_ERR_ARG;
+    }
+    if (((uintptr_t)queries_dev & 7u) != 0) {
+        set_error("slamem_find_mems_device: queries_dev must be 8-byte aligned");
+        return SLAMEM_ERR_ARG;
+    }
+    const uint32_t strands = both_strands ? 2u : 1u;
+    const uint64_t num_blocks = (uint64_t)num_queries * strands;
+    if (num_blocks >= 0xFFFFFFFFull) {
+        set_error("slamem_find_mems_device: at most 2^32-2 strand blocks per call");
+        return SLAMEM_ERR_ARG;
+    }
+    WorkspaceLayout w = layout_workspace(num_blocks, mems_capacity);
+    if (workspace_bytes < w.bytes) {
+        set_error("slamem_find_mems_device: workspace too small (%llu < %llu bytes)",
+                  (unsigned long long)workspace_bytes, (unsigned long long)w.bytes);
+        return SLAMEM_ERR_ARG;
+    }
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    char* ws = static_cast<char*>(workspace_dev);
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
+
+    Timings& tm = thread_timings();
+    hipEvent_t e0, e1, e2;
+    SLAMEM_HIP(hipEventCreate(&e0));
+    SLAMEM_HIP(hipEventCreate(&e1));
+    SLAMEM_HIP(hipEventCreate(&e2));
+    int rc = SLAMEM_OK;
+    do {
+        hipError_t e;
+        if ((e = hipMemsetAsync(d_total, 0, 64, stream)) != hipSuccess) { rc = hip_fail(e, "memset", __FILE__, __LINE__); break; }
+        if ((e = hipMemsetAsync(d_counts + num_blocks, 0, 4, stream)) != hipSuccess) { rc = hip_fail(e, "memset", __FILE__, __LINE__); break; }
+        SearchArgs A;
+        memset(&A, 0, sizeof(A));
+        A.ix = idx->view;
+        A.qwords = static_cast<const uint64_t*>(queries_dev);
+        A.offsets = offsets_dev;
+        A.num_queries = num_queries;
+        A.strands = strands;
+        A.min_len = min_len;
+        A.capacity = mems_capacity;
+        A.total = d_total;
+        A.raw_key = reinterpret_cast<RawKey*>(ws + w.off_rawkey);
+        A.raw_mem = reinterpret_cast<slamem_mem*>(ws + w.off_rawmem);
+        A.block_counts = d_counts;
+        (void)hipEventRecord(e0, stream);
+        if (num_blocks) {
+            hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
+            if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_find_mems", __FILE__, __LINE__); break; }
+        }
+        (void)hipEventRecord(e1, stream);
+        size_t need = w.scan_bytes;
+        if ((e = scan_sum_exclusive_u32_u64(ws + w.off_scan, need, d_counts, block_offsets_dev, num_blocks, stream)) != hipSuccess) {
+            rc = hip_fail(e, "scan", __FILE__, __LINE__); break;
+        }
+        unsigned long long total = 0;
+        if ((e = hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) { rc = hip_fail(e, "memcpy", __FILE__, __LINE__); break; }
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) { rc = hip_fail(e, "k_find_mems (sync)", __FILE__, __LINE__); break; }
+        *total_out = total;
+        if (total > mems_capacity) {
+            set_error("slamem_find_mems_device: %llu MEMs found, output capacity is %llu", total, (unsigned long long)mems_capacity);
+            rc = SLAMEM_ERR_CAPACITY;
+        } else if (total) {
+            hipLaunchKernelGGL(k_scatter_mems, dim3(grid_for(total)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
+                               (uint64_t)total, block_offsets_dev, mems_dev);
+            if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_scatter_mems", __FILE__, __LINE__); break; }
+        }
+        (void)hipEventRecord(e2, stream);
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) { rc = hip_fail(e, "k_scatter_mems (sync)", __FILE__, __LINE__); break; }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+            tm.t.search_kernel_ms = ms;
+            tm.t.search_kernel_ms_sum += ms;
+            tm.t.search_launches++;
+        }
+        if (hipEventElapsedTime(&ms, e0, e2) == hipSuccess) tm.t.search_total_ms = ms;
+    } while (0);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    return rc;
+}
+
+int follow_letter_batch(const slamem_index* idx, const char* letters, uint32_t* top, uint32_t* bot, uint32_t* size_out,
+                        uint64_t count, hipStream_t stream) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    if (!count) return SLAMEM_OK;
+    hipLaunchKernelGGL(k_follow_batch, dim3(grid_for(count)), dim3(256), 0, stream, idx->view, letters, top, bot, size_out, count);
+    SLAMEM_HIP(hipGetLastError());
+    return SLAMEM_OK;
+}
+int enclosing_interval_batch(const slamem_index* idx, uint32_t* top, uint32_t* bot, int32_t* depth_out, uint64_t count,
+                             hipStream_t stream) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    if (!count) return SLAMEM_OK;
+    hipLaunchKernelGGL(k_parent_batch, dim3(grid_for(count)), dim3(256), 0, stream, idx->view, top, bot, depth_out, count);
+    SLAMEM_HIP(hipGetLastError());
+    return SLAMEM_OK;
+}
+int position_in_text_batch(const slamem_index* idx, const uint32_t* rows, uint32_t* out, uint64_t count, hipStream_t stream) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    if (!count) return SLAMEM_OK;
+    hipLaunchKernelGGL(k_locate_batch, dim3(grid_for(count)), dim3(256), 0, stream, idx->view, rows, out, count);
+    SLAMEM_HIP(hipGetLastError());
+    return SLAMEM_OK;
+}
+int char_at_bwt_pos_batch(const slamem_index* idx, const uint32_t* rows, char* out, uint64_t count, hipStream_t stream) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    if (!count) return SLAMEM_OK;
+    hipLaunchKernelGGL(k_bwtchar_batch, dim3(grid_for(count)), dim3(256), 0, stream, idx->view, rows, out, count);
+    SLAMEM_HIP(hipGetLastError());
+    return SLAMEM_OK;
+}
+
+}  // namespace slamem

@@ -1,0 +1,55 @@
+// synth.hip -- bench / test support (NOT part of the product ABI): the SURVEY.md Appendix C.2 generator
+// on the GPU, so that bench.py's inputs are resident in HBM when the timed region starts.
+// Counter-based splitmix64: draw k of a stream = mix(seed + (k+1)*GAMMA); same values as slamem_amd/synth.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__device__ __forceinline__ uint64_t draw(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void k_ref(uint8_t* out, uint64_t n, uint64_t seed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = "ACGT"[draw(seed, i) & 3];
+}
+
+// one thread per read base; reads stored back to back, `length` bytes each
+__global__ void k_reads(const uint8_t* ref, uint64_t n, uint8_t* out, uint64_t first, uint64_t count, uint32_t length,
+                        uint32_t sub_thr, uint64_t seed, uint32_t rc_percent) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * length) return;
+    uint64_t r = t / length;
+    uint32_t i = (uint32_t)(t - r * length);
+    uint64_t base = n + (first + r) * (uint64_t)(length + 2);
+    uint64_t p = draw(seed, base) % (n - length + 1);
+    bool flip = (draw(seed, base + 1 + length) % 100) < rc_percent;
+    uint8_t c = ref[p + i];
+    uint64_t x = draw(seed, base + 1 + i);
+    if ((uint32_t)x < sub_thr) {
+        uint32_t code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+        c = "CGTAGTACTACG"[code * 3 + (uint32_t)((x >> 32) % 3)];
+    }
+    if (flip) {
+        c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+        out[r * length + (length - 1 - i)] = c;
+    } else {
+        out[r * length + i] = c;
+    }
+}
+
+extern "C" int slamem_synth_reference(void* out_dev, uint64_t n, uint64_t seed, void* stream) {
+    hipLaunchKernelGGL(k_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint8_t*)out_dev, n, seed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int slamem_synth_reads(const void* ref_dev, uint64_t n, void* out_dev, uint64_t first, uint64_t count,
+                                  uint32_t length, double sub, uint64_t seed, uint32_t rc_percent, void* stream) {
+    uint32_t thr = (uint32_t)(uint64_t)(sub * 4294967296.0);
+    uint64_t total = count * length;
+    hipLaunchKernelGGL(k_reads, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)ref_dev, n, (uint8_t*)out_dev, first, count, length, thr, seed, rc_percent);
+    return (int)hipGetLastError();
+}

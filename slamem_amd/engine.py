@@ -1,0 +1,257 @@
+"""Python view of the MEM engine: thin wrappers over the C ABI (include/slamem_hip.h).
+
+torch is used for what the task calls plumbing only: device memory (tensors own the HBM buffers handed
+to the C ABI as raw pointers), streams and torch.distributed.  All compute happens in libslamem_hip.so.
+
+Method names mirror the reference's own interface for this path (bwtindex.h / lcparray.h as used by
+GetMatches, slamem.c:37-218), in batched form.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+MEM_DTYPE = np.dtype([("ref_pos", "<u4"), ("query_pos", "<u4"), ("length", "<u4")])
+
+
+def _ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+def _stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("slamem_amd runs on an MI355X only (device must be cuda:N); there is no CPU path")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: slamem_amd has no CPU fallback")
+    return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+class Index:
+    """FM-index + parent-interval structure resident in HBM.
+
+    ``Index.build`` replaces ``FMI_BuildIndex`` + ``BuildSampledLCPArray`` (slamem.c:73-74);
+    ``close`` replaces ``FMI_FreeIndex`` + ``FreeSampledSuffixArray`` (slamem.c:208-209).
+    """
+
+    def __init__(self, handle: int, device: torch.device, keepalive=None):
+        self._h = C.c_void_p(handle)
+        self.device = device
+        self._keepalive = keepalive  # arena tensor when attached
+        info = capi.IndexInfo()
+        capi.check(capi.lib().slamem_index_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.n = int(info.text_length)
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def build(cls, text, device="cuda:0") -> "Index":
+        """text: bytes / numpy uint8 / torch uint8 tensor (host or device) of A,C,G,T,N."""
+        dev = _require_gpu(device)
+        L = capi.lib()
+        if isinstance(text, (bytes, bytearray)):
+            text = np.frombuffer(bytes(text), dtype=np.uint8)
+        if isinstance(text, np.ndarray):
+            text = torch.from_numpy(np.ascontiguousarray(text, dtype=np.uint8))
+        if text.device != dev:
+            text = text.to(dev)
+        text = text.contiguous()
+        n = text.numel()
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            stream = _stream_handle(dev)
+            capi.check(L.slamem_index_build_device(_ptr(text), n, dev.index, stream, C.byref(h)))
+        return cls(h.value, dev)
+
+    @classmethod
+    def attach(cls, arena: torch.Tensor) -> "Index":
+        """Borrow an arena that was broadcast from a peer GPU (uint8 tensor on this device)."""
+        dev = _require_gpu(arena.device)
+        h = C.c_void_p()
+        capi.check(capi.lib().slamem_index_attach(_ptr(arena), arena.numel(), dev.index, C.byref(h)))
+        return cls(h.value, dev, keepalive=arena)
+
+    @classmethod
+    def load(cls, path: str, device="cuda:0") -> "Index":
+        dev = _require_gpu(device)
+        h = C.c_void_p()
+        capi.check(capi.lib().slamem_index_load(path.encode(), dev.index, C.byref(h)))
+        return cls(h.value, dev)
+
+    def save(self, path: str) -> None:
+        capi.check(capi.lib().slamem_index_save(self._h, path.encode()))
+
+    def export_arena(self) -> torch.Tensor:
+        """A torch-owned copy of the arena (what rank 0 hands to torch.distributed.broadcast)."""
+        out = torch.empty(int(self.info.arena_bytes), dtype=torch.uint8, device=self.device)
+        capi.check(capi.lib().slamem_index_export(self._h, _ptr(out), out.numel(), _stream_handle(self.device)))
+        return out
+
+    def close(self) -> None:
+        h, self._h = self._h, None
+        if h:
+            capi.lib().slamem_index_free(h)
+        self._keepalive = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- FMI_GetBWTSize (bwtindex.c:263) ---------------------------------------------------------
+    def bwt_size(self) -> int:
+        return self.n + 1
+
+    # ---- structure-level parity -----------------------------------------------------------------------
+    def download(self, which: int) -> np.ndarray:
+        n = self.n
+        shape, dt = {capi.ARRAY_SA: (n + 1, np.uint32), capi.ARRAY_BWT: (n + 1, np.uint8),
+                     capi.ARRAY_LCP: (n + 2, np.int32), capi.ARRAY_PSV: (n + 2, np.uint32),
+                     capi.ARRAY_NSV: (n + 2, np.uint32)}[which]
+        out = np.empty(shape, dtype=dt)
+        capi.check(capi.lib().slamem_index_download(self._h, which, out.ctypes.data, shape))
+        return out
+
+    # ---- fine-grained operations, batched ------------------------------------------------------------
+    def follow_letter(self, letters: bytes, top, bottom):
+        """FMI_FollowLetter (bwtindex.c:359) for arrays of (letter, top, bottom) -> (size, top, bottom)."""
+        dev = self.device
+        cnt = len(letters)
+        lt = torch.from_numpy(np.frombuffer(bytes(letters), dtype=np.uint8).copy()).to(dev)
+        t = torch.as_tensor(np.asarray(top, dtype=np.uint32).view(np.int32)).to(dev)
+        b = torch.as_tensor(np.asarray(bottom, dtype=np.uint32).view(np.int32)).to(dev)
+        s = torch.zeros(cnt, dtype=torch.int32, device=dev)
+        capi.check(capi.lib().slamem_follow_letter_batch(self._h, _ptr(lt), _ptr(t), _ptr(b), _ptr(s), cnt,
+                                                         _stream_handle(dev)))
+        torch.cuda.synchronize(dev)
+        f = lambda x: x.cpu().numpy().view(np.uint32)
+        return f(s), f(t), f(b)
+
+    def enclosing_interval(self, top, bottom):
+        """GetEnclosingLCPInterval (lcparray.c:330) -> (depth, top, bottom)."""
+        dev = self.device
+        t = torch.as_tensor(np.asarray(top, dtype=np.uint32).view(np.int32)).to(dev)
+        b = torch.as_tensor(np.asarray(bottom, dtype=np.uint32).view(np.int32)).to(dev)
+        d = torch.zeros(t.numel(), dtype=torch.int32, device=dev)
+        capi.check(capi.lib().slamem_enclosing_interval_batch(self._h, _ptr(t), _ptr(b), _ptr(d), t.numel(),
+                                                              _stream_handle(dev)))
+        torch.cuda.synchronize(dev)
+        return d.cpu().numpy(), t.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32)
+
+    def position_in_text(self, rows):
+        """FMI_PositionInText (bwtindex.c:402)."""
+        dev = self.device
+        r = torch.as_tensor(np.asarray(rows, dtype=np.uint32).view(np.int32)).to(dev)
+        o = torch.zeros(r.numel(), dtype=torch.int32, device=dev)
+        capi.check(capi.lib().slamem_position_in_text_batch(self._h, _ptr(r), _ptr(o), r.numel(), _stream_handle(dev)))
+        torch.cuda.synchronize(dev)
+        return o.cpu().numpy().view(np.uint32)
+
+    def char_at_bwt_pos(self, rows) -> bytes:
+        """FMI_GetCharAtBWTPos (bwtindex.c:304)."""
+        dev = self.device
+        r = torch.as_tensor(np.asarray(rows, dtype=np.uint32).view(np.int32)).to(dev)
+        o = torch.zeros(r.numel(), dtype=torch.uint8, device=dev)
+        capi.check(capi.lib().slamem_char_at_bwt_pos_batch(self._h, _ptr(r), _ptr(o), r.numel(), _stream_handle(dev)))
+        torch.cuda.synchronize(dev)
+        return o.cpu().numpy().tobytes()
+
+    # ---- GetMatches (slamem.c:90-207) for a batch ---------------------------------------------------------
+    def matcher(self, num_queries: int, both_strands: bool, mems_capacity: int) -> "Matcher":
+        return Matcher(self, num_queries, both_strands, mems_capacity)
+
+    def find_mems(self, queries, offsets, min_len: int = 20, both_strands: bool = False):
+        """Convenience: host arrays in, (mems structured array, block_offsets) out."""
+        dev = self.device
+        q = np.ascontiguousarray(np.frombuffer(queries, dtype=np.uint8) if isinstance(queries, (bytes, bytearray))
+                                 else queries, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        num = offsets.shape[0] - 1
+        qd = torch.zeros((q.shape[0] + 15) // 8 * 8, dtype=torch.uint8, device=dev)
+        if q.shape[0]:
+            qd[: q.shape[0]] = torch.from_numpy(q).to(dev)
+        od = torch.from_numpy(offsets.view(np.int64)).to(dev)
+        cap = max(1024, q.shape[0] // 8 + 4 * num)
+        while True:
+            m = self.matcher(num, both_strands, cap)
+            try:
+                total = m.run(qd, od, min_len)
+                break
+            except capi.SlamemError as e:
+                if e.code != capi.SLAMEM_ERR_CAPACITY:
+                    raise
+                cap = int(m.last_total)
+        mems = m.mems[:total].cpu().numpy().view(np.uint32).reshape(-1, 3)
+        out = np.empty(total, dtype=MEM_DTYPE)
+        out["ref_pos"], out["query_pos"], out["length"] = mems[:, 0], mems[:, 1], mems[:, 2]
+        return out, m.block_offsets.cpu().numpy().view(np.uint64)
+
+
+class Matcher:
+    """Pre-allocated output + workspace buffers for repeated slamem_find_mems_device calls (bench loop)."""
+
+    def __init__(self, index: Index, num_queries: int, both_strands: bool, mems_capacity: int):
+        self.index = index
+        self.num_queries = int(num_queries)
+        self.both = bool(both_strands)
+        self.capacity = int(mems_capacity)
+        dev = index.device
+        nb = self.num_queries * (2 if self.both else 1)
+        need = C.c_uint64()
+        capi.check(capi.lib().slamem_find_mems_workspace_bytes(self.num_queries, int(self.both), self.capacity,
+                                                               C.byref(need)))
+        self.workspace = torch.empty(int(need.value), dtype=torch.uint8, device=dev)
+        self.mems = torch.empty((max(self.capacity, 1), 3), dtype=torch.int32, device=dev)
+        self.block_offsets = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+        self.last_total = 0
+
+    def run(self, queries_dev: torch.Tensor, offsets_dev: torch.Tensor, min_len: int) -> int:
+        dev = self.index.device
+        total = C.c_uint64()
+        rc = capi.lib().slamem_find_mems_device(
+            self.index._h, _ptr(queries_dev), _ptr(offsets_dev), self.num_queries, int(min_len), int(self.both),
+            _ptr(self.mems), self.capacity, _ptr(self.block_offsets), _ptr(self.workspace), self.workspace.numel(),
+            _stream_handle(dev), C.byref(total))
+        self.last_total = int(total.value)
+        capi.check(rc)
+        return self.last_total
+
+
+def timings() -> dict:
+    t = capi.Timings()
+    capi.check(capi.lib().slamem_get_timings(C.byref(t)))
+    return t.as_dict()
+
+
+def reset_timings() -> None:
+    capi.lib().slamem_reset_timings()
+
+
+# ---- bench / test support: synthetic inputs generated on the GPU (csrc/synth.hip) ----------------------
+def synth_reference(n: int, seed: int = 42, device="cuda:0") -> torch.Tensor:
+    dev = _require_gpu(device)
+    out = torch.empty(n + 16, dtype=torch.uint8, device=dev)[:n]
+    rc = capi.synth_lib().slamem_synth_reference(_ptr(out), n, seed, _stream_handle(dev))
+    if rc:
+        raise RuntimeError(f"synth kernel launch failed: hip error {rc}")
+    return out
+
+
+def synth_reads(ref: torch.Tensor, first: int, count: int, length: int = 150, sub: float = 0.02, seed: int = 42,
+                rc_percent: int = 0) -> torch.Tensor:
+    dev = ref.device
+    out = torch.zeros(count * length + 16, dtype=torch.uint8, device=dev)
+    rc = capi.synth_lib().slamem_synth_reads(_ptr(ref), ref.numel(), _ptr(out), first, count, length, float(sub), seed,
+                                             rc_percent, _stream_handle(dev))
+    if rc:
+        raise RuntimeError(f"synth kernel launch failed: hip error {rc}")
+    return out

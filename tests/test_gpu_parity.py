@@ -1,0 +1,144 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the same inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from slamem_amd import engine
+    return engine
+
+
+def rand_text(rng, n, alpha, repeats=0, max_rep=300, nrun=0):
+    t = rng.choice(np.frombuffer(alpha.encode(), dtype=np.uint8), size=n)
+    for _ in range(repeats):
+        L = int(rng.integers(10, max_rep))
+        a, b = int(rng.integers(0, n - L)), int(rng.integers(0, n - L))
+        t[b:b + L] = t[a:a + L].copy()
+    if nrun:
+        a = int(rng.integers(0, n - nrun))
+        t[a:a + nrun] = ord("N")
+    return t.tobytes()
+
+
+CASES = [("ACGT", 1000, 0, 0), ("ACGT", 5000, 4, 0), ("AC", 2000, 3, 0), ("ACGTN", 3000, 2, 150), ("A", 300, 0, 0),
+         ("ACGT", 1, 0, 0), ("ACGT", 2, 0, 0), ("ACGT", 127, 0, 0), ("ACGT", 128, 0, 0), ("ACGT", 4095, 2, 0),
+         ("ACGT", 100000, 20, 0)]
+
+
+@pytest.mark.parametrize("alpha,n,repeats,nrun", CASES)
+def test_index_arrays_match_oracle(eng, alpha, n, repeats, nrun):
+    """SA / BWT / LCP / PSV / NSV are uniquely defined by the text: bit-exact equality."""
+    from oracle import pyoracle as po
+    from slamem_amd import capi
+    rng = np.random.default_rng(n * 7 + repeats)
+    text = rand_text(rng, n, alpha, repeats if n > 700 else 0, nrun=nrun if n > 700 else 0)
+    o = po.OracleIndex(text)
+    g = eng.Index.build(text)
+    assert g.bwt_size() == n + 1
+    assert np.array_equal(g.download(capi.ARRAY_SA).astype(np.int64), o.sa)
+    assert np.array_equal(g.download(capi.ARRAY_BWT), o.bwt)
+    lcp = g.download(capi.ARRAY_LCP).astype(np.int64)
+    assert np.array_equal(lcp, o.lcp)
+    psv, nsv = g.download(capi.ARRAY_PSV).astype(np.int64), g.download(capi.ARRAY_NSV).astype(np.int64)
+    assert np.array_equal(psv[1:n + 1], o.psv[1:n + 1])
+    assert np.array_equal(nsv[1:n + 1], o.nsv[1:n + 1])
+    g.close()
+
+
+def make_queries(rng, text, nq, alpha, maxlen=300):
+    t = np.frombuffer(text, dtype=np.uint8)
+    n = len(t)
+    qs = []
+    for k in range(nq):
+        L = int(rng.integers(1, min(maxlen, n) + 1))
+        if k % 5 != 4:
+            a = int(rng.integers(0, n - L + 1))
+            q = t[a:a + L].copy()
+            mut = rng.random(L) < 0.03
+            q[mut] = rng.choice(np.frombuffer(alpha.encode(), dtype=np.uint8), size=int(mut.sum()))
+        else:
+            q = rng.choice(np.frombuffer(alpha.encode(), dtype=np.uint8), size=L)
+        qs.append(q.tobytes())
+    return qs
+
+
+def pack(qs):
+    off = np.zeros(len(qs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(q) for q in qs])
+    return np.frombuffer(b"".join(qs), dtype=np.uint8), off
+
+
+@pytest.mark.parametrize("alpha,n,repeats,nrun,l,both", [
+    ("ACGT", 3000, 3, 0, 20, False), ("ACGT", 3000, 3, 0, 20, True), ("AC", 1500, 2, 0, 10, True),
+    ("ACGTN", 2500, 2, 120, 8, True), ("ACGT", 800, 1, 0, 1, False), ("ACGT", 900, 1, 0, 3, True),
+    ("ACGT", 20000, 10, 0, 15, True), ("A", 200, 0, 0, 5, True), ("ACGTN", 4000, 3, 400, 2, False)])
+def test_find_mems_matches_oracle_in_order(eng, alpha, n, repeats, nrun, l, both):
+    """Same MEMs, same blocks, same emission order as the restated GetMatches (slamem.c:114-199)."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(n + l)
+    text = rand_text(rng, n, alpha, repeats, nrun=nrun)
+    qs = make_queries(rng, text, 40, alpha) + [b"", b"N" * 25, text[:30], text[-30:]]
+    q, off = pack(qs)
+    o = po.OracleIndex(text)
+    om, obc = o.match_batch(q, off, l, both)
+    g = eng.Index.build(text)
+    gm, goff = g.find_mems(q, off, l, both)
+    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+    assert len(gm) == len(om)
+    for f in ("ref_pos", "query_pos", "length"):
+        assert np.array_equal(gm[f], om[f]), f
+    g.close()
+
+
+def test_fine_grained_ops_match_oracle(eng):
+    """FMI_FollowLetter / GetEnclosingLCPInterval / FMI_PositionInText / FMI_GetCharAtBWTPos, batched."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(5)
+    text = rand_text(rng, 5000, "ACGTN", 4, nrun=100)
+    n = len(text)
+    o = po.OracleIndex(text)
+    g = eng.Index.build(text)
+    tops = rng.integers(0, n + 1, size=4000)
+    bots = np.minimum(n, tops + (rng.integers(0, 50, size=4000) * (rng.random(4000) < 0.7)))
+    tops[:10], bots[:10] = 0, n
+    letters = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=4000))
+    s, t, b = g.follow_letter(letters, tops, bots)
+    d, pt, pb = g.enclosing_interval(tops, bots)
+    for i in range(4000):
+        es, et, eb = o.follow_letter(chr(letters[i]), int(tops[i]), int(bots[i]))
+        assert (int(s[i]), int(t[i]), int(b[i])) == (es, et, eb), i
+        ed, ept, epb = o.enclosing_interval(int(tops[i]), int(bots[i]))
+        assert (int(d[i]), int(pt[i]), int(pb[i])) == (ed, ept, epb), i
+    rows = np.arange(0, n + 1)
+    assert np.array_equal(g.position_in_text(rows).astype(np.int64), o.sa)
+    assert g.char_at_bwt_pos(rows) == bytes(b"$NACGT"[c] for c in o.bwt)
+    g.close()
+
+
+def test_arena_export_attach_save_load(eng, tmp_path):
+    import torch
+    rng = np.random.default_rng(9)
+    text = rand_text(rng, 3000, "ACGT", 2)
+    qs = make_queries(rng, text, 20, "ACGT")
+    q, off = pack(qs)
+    g = eng.Index.build(text)
+    ref, refoff = g.find_mems(q, off, 12, True)
+    arena = g.export_arena()
+    peer = torch.empty_like(arena)
+    peer.copy_(arena)  # stands in for torch.distributed.broadcast
+    g2 = eng.Index.attach(peer)
+    a, aoff = g2.find_mems(q, off, 12, True)
+    assert np.array_equal(a, ref) and np.array_equal(aoff, refoff)
+    p = str(tmp_path / "idx.slamem")
+    g.save(p)
+    g3 = eng.Index.load(p)
+    a, aoff = g3.find_mems(q, off, 12, True)
+    assert np.array_equal(a, ref) and np.array_equal(aoff, refoff)
+    with pytest.raises(Exception):
+        eng.Index.attach(torch.zeros(8192, dtype=torch.uint8, device="cuda:0"))
