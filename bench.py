@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- MEMs/sec of the MI355X MEM engine on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched through torch.distributed.run)
+
+Workload (config.workload): synthetic 100 Mbp reference (SURVEY.md Appendix C.2 generator, seed 42),
+10 M x 150 bp reads per GPU with 2 % substitutions, half of them reverse-complemented, `-b -l 20`
+(BASELINE.json configs[2], the configuration the metric is quoted on).  One "step" = one pass of the hot
+path (slamem_find_mems_device: K8 search + K9 output compaction) over the rank's read batch, inputs
+already resident in HBM.  Reads shard across ranks with no data-path collective (weak scaling: every rank
+matches its own 10 M reads); the index is built once on rank 0 and broadcast over RCCL/xGMI, and per-rank
+MEM counts are gathered every step.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_find_mems) by the fixed
+reference-layout byte formula of SURVEY.md 8(d); `cpu_baseline` times the oracle (our CPU restatement of
+the reference algorithm, single thread) on a bounded sample of the same reads on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FIXED_BYTES_PER_BASE = 155.0  # SURVEY.md 8(d) figure for these reads
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--ref-len", type=int, default=100_000_000)
+    p.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    p.add_argument("--read-len", type=int, default=150)
+    p.add_argument("--min-len", type=int, default=20)
+    p.add_argument("--sub", type=float, default=0.02)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--rc-percent", type=int, default=50)
+    p.add_argument("--forward-only", action="store_true")
+    p.add_argument("--cpu-sample-reads", type=int, default=40_000)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(ref_host: np.ndarray, reads_host: np.ndarray, read_len: int, min_len: int, both: bool):
+    """Oracle (port of the reference algorithm) on the host cores: bounded sample, one thread."""
+    from oracle import pyoracle as po  # cpu_baseline leg: the only place bench.py touches oracle/
+    t0 = time.time()
+    idx = po.OracleIndex(ref_host.tobytes())
+    build_s = time.time() - t0
+    n = reads_host.shape[0] // read_len
+    offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(read_len)
+    counts = po.Counts()
+    t0 = time.time()
+    mems, bc = idx.match_batch(reads_host, offsets, min_len, both, counts)
+    match_s = time.time() - t0
+    return {"mems": mems, "block_counts": bc, "counts": counts, "build_s": build_s, "match_s": match_s, "reads": n}
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from slamem_amd import engine
+
+    both = not a.forward_only
+    n, M, L = a.ref_len, a.reads, a.read_len
+
+    # ---- inputs, generated in HBM --------------------------------------------------------------------
+    ref = engine.synth_reference(n, a.seed, dev)
+    reads = engine.synth_reads(ref, rank * M, M, L, a.sub, a.seed, a.rc_percent)
+    offsets = torch.arange(M + 1, dtype=torch.int64, device=dev) * L
+    torch.cuda.synchronize(dev)
+
+    # ---- index: built once on rank 0, broadcast over RCCL/xGMI ---------------------------------------------
+    build_s = bcast_s = 0.0
+    build_t = {}
+    if rank == 0:
+        t0 = time.time()
+        index = engine.Index.build(ref, dev)
+        torch.cuda.synchronize(dev)
+        build_s = time.time() - t0
+        build_t = {k: v for k, v in engine.timings().items() if k.startswith("build_")}
+    if world > 1:
+        size = torch.zeros(1, dtype=torch.int64, device=dev)
+        if rank == 0:
+            size[0] = int(index.info.arena_bytes)
+        dist.broadcast(size, 0)
+        arena = index.export_arena() if rank == 0 else torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.time()
+        dist.broadcast(arena, 0)
+        torch.cuda.synchronize(dev)
+        bcast_s = time.time() - t0
+        if rank != 0:
+            index = engine.Index.attach(arena)
+    arena_bytes = int(index.info.arena_bytes)
+
+    # ---- the timed hot path ------------------------------------------------------------------------------------
+    matcher = index.matcher(M, both, mems_capacity=4 * M + 1024)
+    counts_all = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        total = matcher.run(reads, offsets, a.min_len)
+        if world > 1:
+            mine[0] = total
+            dist.all_gather_into_tensor(counts_all, mine)  # final gather of per-rank MEM counts
+        else:
+            counts_all[0] = total
+        return total
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    engine.reset_timings()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    tm = engine.timings()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    kms = torch.tensor([tm["search_kernel_ms_sum"] / max(1, tm["search_launches"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kernel_ms = float(kms.item())
+    total_mems = int(counts_all.sum().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        strands = 2 if both else 1
+        bases_per_launch = float(M) * L * strands
+        out = {
+            "metric": "MEMs/sec (and queries/sec) on 100 Mbp ref x 10 M 150 bp queries, l=20",
+            "value": total_mems / (elapsed / a.steps),
+            "unit": "MEMs/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {n} bp reference (splitmix64 seed {a.seed}) x {M} reads/GPU of {L} bp, "
+                                   f"{a.sub:.0%} substitutions, {a.rc_percent}% reverse-complemented, "
+                                   f"{'-b ' if both else ''}-l {a.min_len}",
+                       "ref_len": n, "reads_per_gpu": M, "read_len": L, "min_len": a.min_len, "both_strands": both,
+                       "parallelism": f"query shards x{world}, index replicated by RCCL broadcast"},
+            "queries_per_sec": world * M / (elapsed / a.steps),
+            "mems_per_step": total_mems,
+            "index_build_s": build_s,
+            "index_build_ms": build_t,
+            "index_bytes": arena_bytes,
+            "index_broadcast_s": bcast_s,
+            "kernel": "k_find_mems",
+            "kernel_ms": kernel_ms,
+        }
+        bytes_per_base = FIXED_BYTES_PER_BASE
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline and a.cpu_sample_reads > 0:
+            S = min(a.cpu_sample_reads, M)
+            ref_h = ref.cpu().numpy()
+            reads_h = reads[: S * L].cpu().numpy()
+            r = cpu_baseline(ref_h, reads_h, L, a.min_len, both)
+            cpu = {"value": len(r["mems"]) / r["match_s"], "unit": "MEMs/s", "cores": 1, "kind": "port",
+                   "sample": f"first {S} reads of the same batch ({'both strands' if both else 'forward'}), "
+                             f"oracle/liboracle.so single thread, matching only",
+                   "queries_per_sec": S / r["match_s"], "match_s": r["match_s"], "index_build_s": r["build_s"],
+                   "host_cpus": os.cpu_count()}
+            bytes_per_base = r["counts"].algorithmic_bytes() / max(1, r["counts"].n_querybase)
+            # parity of the GPU result on the sample (the checker, not the thing measured)
+            nb = S * strands
+            boff = matcher.block_offsets[: nb + 1].cpu().numpy()
+            gm = matcher.mems[: int(boff[-1])].cpu().numpy().view(np.uint32)
+            om = r["mems"]
+            ok = (np.array_equal(np.diff(boff), r["block_counts"].astype(np.int64)) and len(om) == gm.shape[0]
+                  and np.array_equal(gm[:, 0], om["ref_pos"]) and np.array_equal(gm[:, 1], om["query_pos"])
+                  and np.array_equal(gm[:, 2], om["length"]))
+            out["sample_parity_vs_oracle"] = bool(ok)
+            out["op_counts_per_base"] = {k: v / max(1, r["counts"].n_querybase) for k, v in r["counts"].as_dict().items()}
+        algo_bytes = bytes_per_base * bases_per_launch
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath))
+                if t.get("reads_per_gpu") == M and t.get("ref_len") == n and t.get("both_strands") == both:
+                    traffic = t.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_query_base": bytes_per_base,
+                           "query_bases_per_launch": bases_per_launch}
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

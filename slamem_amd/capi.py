@@ -96,6 +96,16 @@ def _declare(L):
             f.restype = i32
 
 
+def _load_torch_runtime_first():
+    # torch bundles its own libamdhip64; if libslamem_hip.so pulls in /opt/rocm's copy BEFORE torch loads its
+    # own, the process ends up with two HIP runtimes and the second one sees no device.  Loading torch first
+    # makes both share one runtime (the C front end never loads torch and simply uses /opt/rocm's).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib():
     """The loaded HIP library; raises (loudly) if it has not been built."""
     global _LIB
@@ -104,6 +114,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C slamem_amd/csrc`).  slamem_amd has no CPU fallback.")
+        _load_torch_runtime_first()
         L = C.CDLL(LIB_PATH)
         _declare(L)
         if L.slamem_abi_version() != 1:
@@ -117,6 +128,7 @@ def synth_lib():
     if _SYNTH is None:
         if not os.path.exists(SYNTH_PATH):
             raise ImportError(f"{SYNTH_PATH} is missing: run __graft_entry__.build()")
+        _load_torch_runtime_first()
         S = C.CDLL(SYNTH_PATH)
         S.slamem_synth_reference.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         S.slamem_synth_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,

@@ -60,7 +60,7 @@ class Index:
         if isinstance(text, (bytes, bytearray)):
             text = np.frombuffer(bytes(text), dtype=np.uint8)
         if isinstance(text, np.ndarray):
-            text = torch.from_numpy(np.ascontiguousarray(text, dtype=np.uint8))
+            text = torch.from_numpy(np.array(text, dtype=np.uint8, copy=True))
         if text.device != dev:
             text = text.to(dev)
         text = text.contiguous()
