@@ -77,23 +77,33 @@ __device__ __forceinline__ uint32_t bwt_code(const IndexView& ix, uint32_t row) 
     return 2u + (uint32_t)((b->p0[hs] >> bit) & 1ull) + 2u * (uint32_t)((b->p1[hs] >> bit) & 1ull);
 }
 
-// FMI_FollowLetter: returns true and updates [top,bot] when the extended string occurs
-__device__ __forceinline__ bool follow(const IndexView& ix, uint32_t c, uint32_t& top, uint32_t& bot) {
-    uint32_t nt, nb;
+// The two rank queries of FMI_FollowLetter for letter id c on [top,bot]:
+//   nt  = C[c] + occ(c, rows < top)        new top
+//   nb1 = C[c] + occ(c, rows <= bot)       one past the new bottom
+// so nb1 - nt = number of rows of [top,bot] whose BWT letter is c (0: the extension does not occur).
+__device__ __forceinline__ void occ_pair(const IndexView& ix, uint32_t c, uint32_t top, uint32_t bot, uint32_t& nt,
+                                         uint32_t& nb1) {
     if (c >= 2u) {
         uint32_t bi_t = top >> kFmRowsLog2, bi_b = (bot + 1u) >> kFmRowsLog2;
         Blk kt = load_blk(ix.fm, bi_t);
         nt = occ_lt(kt, c - 2u, top & (kFmRows - 1u));
-        if (bi_b == bi_t) nb = occ_lt(kt, c - 2u, (bot + 1u) & (kFmRows - 1u));
-        else { Blk kb = load_blk(ix.fm, bi_b); nb = occ_lt(kb, c - 2u, (bot + 1u) & (kFmRows - 1u)); }
-    } else {  // N: C[N] = 1 (only '$' is smaller)
-        if (ix.num_n == 0) return false;
+        if (bi_b == bi_t) nb1 = occ_lt(kt, c - 2u, (bot + 1u) & (kFmRows - 1u));
+        else { Blk kb = load_blk(ix.fm, bi_b); nb1 = occ_lt(kb, c - 2u, (bot + 1u) & (kFmRows - 1u)); }
+    } else if (ix.num_n == 0) {
+        nt = nb1 = 1u;
+    } else {  // N: C[N] = 1 (only '$' is smaller); rank through the sorted list of N rows
         nt = 1u + n_rows_lt(ix, top);
-        nb = 1u + n_rows_lt(ix, bot + 1u);
+        nb1 = 1u + n_rows_lt(ix, bot + 1u);
     }
-    if (nt >= nb) return false;  // nb is one past the new bottom
+}
+
+// FMI_FollowLetter: returns true and updates [top,bot] when the extended string occurs
+__device__ __forceinline__ bool follow(const IndexView& ix, uint32_t c, uint32_t& top, uint32_t& bot) {
+    uint32_t nt, nb1;
+    occ_pair(ix, c, top, bot, nt, nb1);
+    if (nt >= nb1) return false;
     top = nt;
-    bot = nb - 1u;
+    bot = nb1 - 1u;
     return true;
 }
 
@@ -163,6 +173,40 @@ __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint
     k++;
 }
 
+// Rows of the pending interval [top,bot] (match of length `depth` starting at query position `pos`) and of
+// every ancestor interval still >= min_len deep, filtered for left-maximality (slamem.c:139-193).
+//   same_left = number of rows of [top,bot] whose BWT letter equals the query's next letter to the left
+//               (it falls out of the rank queries of the NEXT backward step, so the common single-row case
+//               needs no extra BWT access: the reference reads FMI_GetCharAtBWTPos per row, slamem.c:141,166)
+//   pub       = upper bound on the depth of the parent of [top,bot]; tightened to the exact value when read.
+//               While pub < min_len no ancestor can qualify and GetEnclosingLCPInterval (slamem.c:192) is skipped.
+__device__ __forceinline__ void emit_levels(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t top,
+                                            uint32_t bot, int depth, uint32_t pos, uint32_t left, uint32_t same_left,
+                                            int& pub) {
+    const IndexView& ix = A.ix;
+    const int L = (int)A.min_len;
+    uint32_t size = bot - top + 1u;
+    if (same_left < size) {
+        if (size == 1u) emit(A, blockid, k, top, pos, (uint32_t)depth);
+        else
+            for (uint32_t row = top; row <= bot; row++)  // slamem.c:140
+                if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)depth);
+    }
+    if (pub < L) return;
+    uint32_t t = top, b = bot, pt = top, pb = bot;
+    int msz = parent(ix, t, b);
+    pub = msz;
+    while (msz >= L) {
+        for (uint32_t row = t; row != pt; row++)  // new rows above (slamem.c:140)
+            if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)msz);
+        for (uint32_t row = b; row != pb; row--)  // new rows below, bottom-up (slamem.c:165)
+            if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)msz);
+        pt = t;
+        pb = b;
+        msz = parent(ix, t, b);  // slamem.c:192
+    }
+}
+
 __global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t nblocks = (uint64_t)A.num_queries * A.strands;
@@ -172,41 +216,38 @@ __global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
     uint64_t o0 = A.offsets[qi], o1 = A.offsets[qi + 1];
     uint32_t len = (uint32_t)(o1 - o0);
     const IndexView& ix = A.ix;
-    const uint32_t L = A.min_len;
+    const int L = (int)A.min_len;
 
     QueryCursor qc;
     qc.init(A.qwords, o0, len, rev);
 
     uint32_t top = 0, bot = ix.n;  // root: all rows  (slamem.c:110-111)
     int depth = 0;
+    int pub = -1;       // bound on the parent depth of [top,bot]: the root has no parent
+    bool pend = false;  // position j+1 matched >= min_len characters: its rows wait for the left letter
     uint32_t k = 0;
-    uint32_t cur = len ? qc.at(len - 1u) : 0u;
     for (uint32_t j = len; j-- > 0u;) {  // slamem.c:114
-        uint32_t c = cur;
-        uint32_t left = j ? qc.at(j - 1u) : 0xFFu;  // next character to the left; nothing at j == 0 (slamem.c:137-138)
-        cur = left;
+        uint32_t c = qc.at(j);
+        uint32_t nt, nb1;
+        occ_pair(ix, c, top, bot, nt, nb1);
+        if (pend) emit_levels(A, (uint32_t)g, k, top, bot, depth, j + 1u, c, nb1 - nt, pub);
         // extend to the left, widening to parent intervals while the extension fails (slamem.c:121-128)
-        for (;;) {
-            if (follow(ix, c, top, bot)) break;
+        while (nt >= nb1) {
             int d = parent(ix, top, bot);
             depth = d;
             if (d < 0) break;  // root and the letter does not occur at all
+            pub = d - 1;       // the parent of an interval of depth d is shallower than d
+            occ_pair(ix, c, top, bot, nt, nb1);
+        }
+        if (nt < nb1) {
+            top = nt;
+            bot = nb1 - 1u;
+            pub++;  // parent depth of cW <= parent depth of W + 1
         }
         depth++;  // slamem.c:129
-        if ((uint32_t)depth >= L && depth > 0) {  // slamem.c:130
-            uint32_t t = top, b = bot, pt = bot + 1u, pb = bot;
-            int msz = depth;
-            while (msz >= (int)L) {  // this interval and every ancestor that is still deep enough (slamem.c:139)
-                for (uint32_t row = t; row != pt; row++)  // new rows above (slamem.c:140)
-                    if (bwt_code(ix, row) != left) emit(A, (uint32_t)g, k, row, j, (uint32_t)msz);
-                for (uint32_t row = b; row != pb; row--)  // new rows below, bottom-up (slamem.c:165)
-                    if (bwt_code(ix, row) != left) emit(A, (uint32_t)g, k, row, j, (uint32_t)msz);
-                pt = t;
-                pb = b;
-                msz = parent(ix, t, b);  // slamem.c:192
-            }
-        }
+        pend = depth >= L && depth > 0;  // slamem.c:130
     }
+    if (pend) emit_levels(A, (uint32_t)g, k, top, bot, depth, 0u, 0xFFu, 0u, pub);  // j == 0: nothing to the left (slamem.c:138)
     A.block_counts[g] = k;
 }
 

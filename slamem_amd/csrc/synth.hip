@@ -53,3 +53,42 @@ extern "C" int slamem_synth_reads(const void* ref_dev, uint64_t n, void* out_dev
                        (const uint8_t*)ref_dev, n, (uint8_t*)out_dev, first, count, length, thr, seed, rc_percent);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Random 64-byte-line gather ceiling (SURVEY.md 7.2 "Roofline honesty"): every lane walks ILP independent
+// chains of dependent random reads of whole 64-B blocks (4 x 16-B loads, the access shape of an FM-block
+// rank query in k_find_mems).  Also the calibration workload for FETCH_SIZE on this access pattern:
+// exactly lanes * iters * ILP block reads of 64 B each.
+// ---------------------------------------------------------------------------------------------------
+template <int ILP>
+__global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ table, uint64_t nblk, uint32_t iters,
+                                                uint64_t* __restrict__ sink) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s[ILP];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; k++) s[k] = draw(0x1234u + k, g);
+    for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < ILP; k++) {
+            uint64_t b = s[k] % nblk;
+            const uint4* p = table + b * 4;
+            uint4 a = p[0], c = p[1], d = p[2], e = p[3];
+            uint64_t v = a.x ^ c.y ^ d.z ^ e.w;
+            acc += v;
+            s[k] = draw(s[k] + v, it);  // next index depends on the loaded data
+        }
+    }
+    if (acc == 0x9999999999999999ull) sink[0] = acc;  // keep the loads alive
+}
+
+extern "C" int slamem_gather_bench(const void* table_dev, uint64_t nblk, uint64_t lanes, uint32_t iters, int ilp,
+                                   void* sink_dev, void* stream) {
+    dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (ilp == 1) hipLaunchKernelGGL(k_gather<1>, grid, block, 0, st, (const uint4*)table_dev, nblk, iters, (uint64_t*)sink_dev);
+    else if (ilp == 2) hipLaunchKernelGGL(k_gather<2>, grid, block, 0, st, (const uint4*)table_dev, nblk, iters, (uint64_t*)sink_dev);
+    else if (ilp == 4) hipLaunchKernelGGL(k_gather<4>, grid, block, 0, st, (const uint4*)table_dev, nblk, iters, (uint64_t*)sink_dev);
+    else return -1;
+    return (int)hipGetLastError();
+}
