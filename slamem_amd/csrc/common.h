@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 1;
+constexpr uint32_t kArenaVersion = 2;
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -33,6 +33,17 @@ struct __attribute__((aligned(64))) FMBlock {
 };
 static_assert(sizeof(FMBlock) == 64, "FM block must be one 64-byte line");
 
+// Per-row record: everything the parent-interval operation and locate need about a row in ONE 16-byte
+// load (two rows = one round trip; rows t and t+1 share a 64-byte line 3 times out of 4).
+//   lcp1 = LCP[row] + 1 (0 = the -1 sentinel of rows 0 and n+1, lcparray.c:624,667)
+//   psv  = nearest row above with a smaller LCP, nsv = nearest row below with a smaller LCP
+//          (what the reference's sampled prefix links encode, lcparray.c:782-989)
+//   sa   = SA[row] (the reference samples every 32nd row and LF-walks, bwtindex.c:402-420)
+struct __attribute__((aligned(16))) RowRec {
+    uint32_t lcp1, psv, nsv, sa;
+};
+static_assert(sizeof(RowRec) == 16, "row record must be 16 bytes");
+
 // Arena header (first 4 KiB of the index arena; also the on-disk header).
 struct ArenaHeader {
     uint32_t magic_lo, magic_hi;
@@ -40,11 +51,7 @@ struct ArenaHeader {
     uint32_t n;           // text length; rows = n + 1
     uint64_t total_bytes;
     uint64_t off_fm;      // FMBlock[nblocks]
-    uint64_t off_l8;      // uint8 [n+2]   min(LCP+1, 255)
-    uint64_t off_l32;     // uint32[n+2]   LCP+1  (0 at rows 0 and n+1)
-    uint64_t off_psv;     // uint32[n+2]
-    uint64_t off_nsv;     // uint32[n+2]
-    uint64_t off_sa;      // uint32[n+1]
+    uint64_t off_rec;     // RowRec[n+2]    per-row {LCP+1, PSV, NSV, SA}
     uint64_t off_nrows;   // uint32[num_n]  sorted BWT rows holding N
     uint32_t nblocks;
     uint32_t dollar_row;
@@ -59,11 +66,7 @@ static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 // What the kernels see (passed by value).
 struct IndexView {
     const FMBlock* fm;
-    const uint8_t* l8;
-    const uint32_t* l32;
-    const uint32_t* psv;
-    const uint32_t* nsv;
-    const uint32_t* sa;
+    const RowRec* rec;
     const uint32_t* nrows;
     uint32_t n;
     uint32_t nblocks;

@@ -212,8 +212,7 @@ constexpr uint32_t kLcpChunk = 32;
 
 __global__ void __launch_bounds__(256) k_lcp_kasai(const uint64_t* __restrict__ pk, const uint32_t* __restrict__ sa,
                                                    const uint32_t* __restrict__ rank, uint32_t rows,
-                                                   uint32_t* __restrict__ l32, uint8_t* __restrict__ l8,
-                                                   uint32_t* __restrict__ max_lcp) {
+                                                   uint32_t* __restrict__ l32, uint32_t* __restrict__ max_lcp) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t i0 = t * kLcpChunk;
     if (i0 >= rows) return;
@@ -231,18 +230,31 @@ __global__ void __launch_bounds__(256) k_lcp_kasai(const uint64_t* __restrict__ 
             h += 16;
         }
         l32[r] = h + 1;
-        l8[r] = (uint8_t)(h + 1 < 255u ? h + 1 : 255u);
         mx = h > mx ? h : mx;
         if (h) h--;
     }
     if (mx) atomicMax(max_lcp, mx);
 }
 
-__global__ void k_lcp_sentinels(uint32_t rows, uint32_t* l32, uint8_t* l8, uint32_t* psv, uint32_t* nsv) {
+__global__ void k_lcp_sentinels(uint32_t rows, uint32_t* l32, uint32_t* psv, uint32_t* nsv) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        l32[0] = 0; l8[0] = 0; l32[rows] = 0; l8[rows] = 0;  // LCP[0] = LCP[n+1] = -1   (lcparray.c:624,667)
+        l32[0] = 0; l32[rows] = 0;  // LCP[0] = LCP[n+1] = -1   (lcparray.c:624,667)
         psv[0] = 0; nsv[0] = rows; psv[rows] = 0; nsv[rows] = rows;
     }
+}
+
+// interleave the four per-row arrays into the 16-byte row records
+__global__ void __launch_bounds__(256) k_pack_records(const uint32_t* __restrict__ l32, const uint32_t* __restrict__ psv,
+                                                      const uint32_t* __restrict__ nsv, const uint32_t* __restrict__ sa,
+                                                      uint32_t rows, RowRec* __restrict__ rec) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > rows) return;
+    RowRec r;
+    r.lcp1 = l32[i];
+    r.psv = psv[i];
+    r.nsv = nsv[i];
+    r.sa = i < rows ? sa[i] : 0u;
+    rec[i] = r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -361,9 +373,13 @@ __global__ void __launch_bounds__(256) k_bwt_codes(IndexView ix, uint8_t* __rest
     out[r] = (uint8_t)code;
 }
 
-__global__ void __launch_bounds__(256) k_lcp_minus1(const uint32_t* __restrict__ l32, uint64_t count, int32_t* __restrict__ out) {
+// field 0: LCP (as int32, -1 sentinels), 1: PSV, 2: NSV, 3: SA
+__global__ void __launch_bounds__(256) k_rec_field(const RowRec* __restrict__ rec, uint64_t count, int field,
+                                                   uint32_t* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = (int32_t)l32[i] - 1;
+    if (i >= count) return;
+    RowRec r = rec[i];
+    out[i] = field == 0 ? r.lcp1 - 1u : field == 1 ? r.psv : field == 2 ? r.nsv : r.sa;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -394,11 +410,7 @@ void make_view(slamem_index* idx) {
     char* base = static_cast<char*>(idx->arena);
     const ArenaHeader& h = idx->hdr;
     idx->view.fm = reinterpret_cast<const FMBlock*>(base + h.off_fm);
-    idx->view.l8 = reinterpret_cast<const uint8_t*>(base + h.off_l8);
-    idx->view.l32 = reinterpret_cast<const uint32_t*>(base + h.off_l32);
-    idx->view.psv = reinterpret_cast<const uint32_t*>(base + h.off_psv);
-    idx->view.nsv = reinterpret_cast<const uint32_t*>(base + h.off_nsv);
-    idx->view.sa = reinterpret_cast<const uint32_t*>(base + h.off_sa);
+    idx->view.rec = reinterpret_cast<const RowRec*>(base + h.off_rec);
     idx->view.nrows = reinterpret_cast<const uint32_t*>(base + h.off_nrows);
     idx->view.n = h.n;
     idx->view.nblocks = h.nblocks;
@@ -455,11 +467,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     for (int c = 2; c < 6; c++) hdr.C[c] = hdr.C[c - 1] + h_scal[c - 1];
     uint64_t off = kHeaderBytes;
     hdr.off_fm = off;    off = align_up(off + (uint64_t)nblocks * sizeof(FMBlock), 256);
-    hdr.off_l8 = off;    off = align_up(off + (R + 1), 256);
-    hdr.off_l32 = off;   off = align_up(off + (R + 1) * 4, 256);
-    hdr.off_psv = off;   off = align_up(off + (R + 1) * 4, 256);
-    hdr.off_nsv = off;   off = align_up(off + (R + 1) * 4, 256);
-    hdr.off_sa = off;    off = align_up(off + R * 4, 256);
+    hdr.off_rec = off;   off = align_up(off + (R + 1) * sizeof(RowRec), 256);
     hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
     hdr.total_bytes = off;
 
@@ -470,23 +478,20 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
     char* base = arena.as<char>();
     FMBlock* d_fm = reinterpret_cast<FMBlock*>(base + hdr.off_fm);
-    uint8_t* d_l8 = reinterpret_cast<uint8_t*>(base + hdr.off_l8);
-    uint32_t* d_l32 = reinterpret_cast<uint32_t*>(base + hdr.off_l32);
-    uint32_t* d_psv = reinterpret_cast<uint32_t*>(base + hdr.off_psv);
-    uint32_t* d_nsv = reinterpret_cast<uint32_t*>(base + hdr.off_nsv);
-    uint32_t* d_sa = reinterpret_cast<uint32_t*>(base + hdr.off_sa);
+    RowRec* d_rec = reinterpret_cast<RowRec*>(base + hdr.off_rec);
     uint32_t* d_nrows = reinterpret_cast<uint32_t*>(base + hdr.off_nrows);
     SLAMEM_HIP(hipMemsetAsync(base, 0, kHeaderBytes, stream));
 
     // ---- K2: suffix sort ----------------------------------------------------------------------
-    DevBuf keysA, keysB, valsA, valsB, rank, flagA, flagB, tmp32, gh, posA, posB, sorttmp;
-    if (keysA.alloc(R * 8) != hipSuccess || keysB.alloc(R * 8) != hipSuccess || valsA.alloc(R * 4) != hipSuccess ||
+    DevBuf keysA, keysB, valsA, valsB, rank, flagA, flagB, tmp32, gh, posA, posB, sorttmp, sabuf;
+    if (sabuf.alloc(R * 4) != hipSuccess || keysA.alloc(R * 8) != hipSuccess || keysB.alloc(R * 8) != hipSuccess || valsA.alloc(R * 4) != hipSuccess ||
         valsB.alloc(R * 4) != hipSuccess || rank.alloc(R * 4) != hipSuccess || flagA.alloc(R) != hipSuccess ||
         flagB.alloc(R) != hipSuccess || tmp32.alloc(R * 4) != hipSuccess || gh.alloc(R * 4) != hipSuccess ||
         posA.alloc(R * 4) != hipSuccess || posB.alloc(R * 4) != hipSuccess) {
         set_error("slamem_index_build: cannot allocate suffix-sort scratch (%llu rows)", (unsigned long long)R);
         return SLAMEM_ERR_NOMEM;
     }
+    uint32_t* d_sa = sabuf.as<uint32_t>();
     size_t tmp_bytes = 0, need = 0;
     SLAMEM_HIP(sort_pairs_u64_u32(nullptr, need, keysA.as<uint64_t>(), keysB.as<uint64_t>(), valsA.as<uint32_t>(),
                                   valsB.as<uint32_t>(), R, 0, 64, stream));
@@ -590,9 +595,19 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
 
     // ---- K5: LCP --------------------------------------------------------------------------------------
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
-    hipLaunchKernelGGL(k_lcp_sentinels, dim3(1), dim3(64), 0, stream, rows, d_l32, d_l8, d_psv, d_nsv);
+    // scratch reuse: the sort buffers are free now
+    DevBuf l32buf, psvbuf, nsvbuf;  // R+1 words each
+    if (l32buf.alloc((R + 1) * 4) != hipSuccess || psvbuf.alloc((R + 1) * 4) != hipSuccess ||
+        nsvbuf.alloc((R + 1) * 4) != hipSuccess) {
+        set_error("slamem_index_build: cannot allocate LCP scratch");
+        return SLAMEM_ERR_NOMEM;
+    }
+    uint32_t* d_l32 = l32buf.as<uint32_t>();
+    uint32_t* d_psv = psvbuf.as<uint32_t>();
+    uint32_t* d_nsv = nsvbuf.as<uint32_t>();
+    hipLaunchKernelGGL(k_lcp_sentinels, dim3(1), dim3(64), 0, stream, rows, d_l32, d_psv, d_nsv);
     hipLaunchKernelGGL(k_lcp_kasai, dim3(grid_for((R + kLcpChunk - 1) / kLcpChunk)), dim3(256), 0, stream,
-                       pk.as<uint64_t>(), d_sa, rank.as<uint32_t>(), rows, d_l32, d_l8, d_scal + 9);
+                       pk.as<uint64_t>(), d_sa, rank.as<uint32_t>(), rows, d_l32, d_scal + 9);
     SLAMEM_HIP(hipGetLastError());
     SLAMEM_HIP(hipEventRecord(ev.b, stream));
     SLAMEM_HIP(hipEventSynchronize(ev.b));
@@ -637,6 +652,8 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         hipLaunchKernelGGL(k_links, dim3(grid_for(n)), dim3(256), 0, stream, L, rows, d_psv, d_nsv);
         SLAMEM_HIP(hipGetLastError());
     }
+    hipLaunchKernelGGL(k_pack_records, dim3(grid_for(R + 1)), dim3(256), 0, stream, d_l32, d_psv, d_nsv, d_sa, rows, d_rec);
+    SLAMEM_HIP(hipGetLastError());
     SLAMEM_HIP(hipEventRecord(ev.b, stream));
     SLAMEM_HIP(hipMemcpyAsync(h_scal, d_scal, sizeof(h_scal), hipMemcpyDeviceToHost, stream));
     SLAMEM_HIP(hipStreamSynchronize(stream));
@@ -666,43 +683,35 @@ int download_array(const slamem_index* idx, int which, void* host_dst, uint64_t 
     SLAMEM_HIP(hipSetDevice(idx->device));
     const uint64_t R = (uint64_t)idx->hdr.n + 1;
     const IndexView& v = idx->view;
+    int field = -1;
+    uint64_t want = 0;
     switch (which) {
-    case SLAMEM_ARRAY_SA:
-        if (count != R) break;
-        SLAMEM_HIP(hipMemcpy(host_dst, v.sa, R * 4, hipMemcpyDeviceToHost));
-        return SLAMEM_OK;
-    case SLAMEM_ARRAY_PSV:
-        if (count != R + 1) break;
-        SLAMEM_HIP(hipMemcpy(host_dst, v.psv, (R + 1) * 4, hipMemcpyDeviceToHost));
-        return SLAMEM_OK;
-    case SLAMEM_ARRAY_NSV:
-        if (count != R + 1) break;
-        SLAMEM_HIP(hipMemcpy(host_dst, v.nsv, (R + 1) * 4, hipMemcpyDeviceToHost));
-        return SLAMEM_OK;
-    case SLAMEM_ARRAY_BWT: {
-        if (count != R) break;
-        DevBuf d;
+    case SLAMEM_ARRAY_SA: field = 3; want = R; break;
+    case SLAMEM_ARRAY_LCP: field = 0; want = R + 1; break;
+    case SLAMEM_ARRAY_PSV: field = 1; want = R + 1; break;
+    case SLAMEM_ARRAY_NSV: field = 2; want = R + 1; break;
+    case SLAMEM_ARRAY_BWT: want = R; break;
+    default:
+        set_error("slamem_index_download: unknown array id %d", which);
+        return SLAMEM_ERR_ARG;
+    }
+    if (count != want) {
+        set_error("slamem_index_download: wrong element count for array %d", which);
+        return SLAMEM_ERR_ARG;
+    }
+    DevBuf d;
+    if (which == SLAMEM_ARRAY_BWT) {
         SLAMEM_HIP(d.alloc(R));
         hipLaunchKernelGGL(k_bwt_codes, dim3(grid_for(R)), dim3(256), 0, 0, v, d.as<uint8_t>());
         SLAMEM_HIP(hipGetLastError());
         SLAMEM_HIP(hipMemcpy(host_dst, d.p, R, hipMemcpyDeviceToHost));
         return SLAMEM_OK;
     }
-    case SLAMEM_ARRAY_LCP: {
-        if (count != R + 1) break;
-        DevBuf d;
-        SLAMEM_HIP(d.alloc((R + 1) * 4));
-        hipLaunchKernelGGL(k_lcp_minus1, dim3(grid_for(R + 1)), dim3(256), 0, 0, v.l32, R + 1, d.as<int32_t>());
-        SLAMEM_HIP(hipGetLastError());
-        SLAMEM_HIP(hipMemcpy(host_dst, d.p, (R + 1) * 4, hipMemcpyDeviceToHost));
-        return SLAMEM_OK;
-    }
-    default:
-        set_error("slamem_index_download: unknown array id %d", which);
-        return SLAMEM_ERR_ARG;
-    }
-    set_error("slamem_index_download: wrong element count for array %d", which);
-    return SLAMEM_ERR_ARG;
+    SLAMEM_HIP(d.alloc(want * 4));
+    hipLaunchKernelGGL(k_rec_field, dim3(grid_for(want)), dim3(256), 0, 0, v.rec, want, field, d.as<uint32_t>());
+    SLAMEM_HIP(hipGetLastError());
+    SLAMEM_HIP(hipMemcpy(host_dst, d.p, want * 4, hipMemcpyDeviceToHost));
+    return SLAMEM_OK;
 }
 
 }  // namespace slamem

@@ -7,9 +7,9 @@
 //   FMI_PositionInText        bwtindex.c:402-420   -> one read of the full suffix array
 //   GetEnclosingLCPInterval   lcparray.c:330-423   -> parent()  (semantics of lcparray.c:514-523)
 //   GetLcpPosFromBwtPos / GetLcpValueFromLcpPos / GetBwtPosFromLcpPos / GetPrefixLinkFromLcpPos / IsTopCorner
-//                             lcparray.c:119-328   -> subsumed: LCP and both links are stored for EVERY row
-//                                                     (1 + 4 + 4 + 4 bytes per row in HBM instead of a sampled
-//                                                     structure that costs 4-6 dependent probes per parent call)
+//                             lcparray.c:119-328   -> subsumed: LCP, both links and SA are stored for EVERY row in one
+//                                                     16-byte record (one round trip per parent call instead of
+//                                                     the 4-6 dependent probes of the sampled structure)
 //   ReverseComplementSequence sequence.c:413-430   -> folded into the query fetch of the reverse-strand lane
 //
 // Work mapping: one lane per (query record, strand) -- the scan of one strand is a chain of ~2 dependent
@@ -77,18 +77,34 @@ __device__ __forceinline__ uint32_t bwt_code(const IndexView& ix, uint32_t row) 
     return 2u + (uint32_t)((b->p0[hs] >> bit) & 1ull) + 2u * (uint32_t)((b->p1[hs] >> bit) & 1ull);
 }
 
-// The two rank queries of FMI_FollowLetter for letter id c on [top,bot]:
+// The FM blocks of rows `top` and `bot+1`, kept in registers across retries: after a parent step the widened
+// interval usually still starts / ends in the same 128-row block, so the retry costs no memory access.
+struct BlkCache {
+    Blk t, b;
+    uint32_t it, ib;  // block indices held (0xFFFFFFFF = none)
+};
+
+__device__ __forceinline__ void cache_blocks(const IndexView& ix, BlkCache& bc, uint32_t top, uint32_t bot) {
+    uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
+    if (bt != bc.it) {
+        if (bt == bc.ib) bc.t = bc.b; else bc.t = load_blk(ix.fm, bt);
+        bc.it = bt;
+    }
+    if (bb != bc.ib) {
+        if (bb == bc.it) bc.b = bc.t; else bc.b = load_blk(ix.fm, bb);
+        bc.ib = bb;
+    }
+}
+
+// The two rank queries of FMI_FollowLetter for letter id c on [top,bot] (blocks already in `bc`):
 //   nt  = C[c] + occ(c, rows < top)        new top
 //   nb1 = C[c] + occ(c, rows <= bot)       one past the new bottom
 // so nb1 - nt = number of rows of [top,bot] whose BWT letter is c (0: the extension does not occur).
-__device__ __forceinline__ void occ_pair(const IndexView& ix, uint32_t c, uint32_t top, uint32_t bot, uint32_t& nt,
-                                         uint32_t& nb1) {
+__device__ __forceinline__ void occ_pair(const IndexView& ix, const BlkCache& bc, uint32_t c, uint32_t top,
+                                         uint32_t bot, uint32_t& nt, uint32_t& nb1) {
     if (c >= 2u) {
-        uint32_t bi_t = top >> kFmRowsLog2, bi_b = (bot + 1u) >> kFmRowsLog2;
-        Blk kt = load_blk(ix.fm, bi_t);
-        nt = occ_lt(kt, c - 2u, top & (kFmRows - 1u));
-        if (bi_b == bi_t) nb1 = occ_lt(kt, c - 2u, (bot + 1u) & (kFmRows - 1u));
-        else { Blk kb = load_blk(ix.fm, bi_b); nb1 = occ_lt(kb, c - 2u, (bot + 1u) & (kFmRows - 1u)); }
+        nt = occ_lt(bc.t, c - 2u, top & (kFmRows - 1u));
+        nb1 = occ_lt(bc.b, c - 2u, (bot + 1u) & (kFmRows - 1u));
     } else if (ix.num_n == 0) {
         nt = nb1 = 1u;
     } else {  // N: C[N] = 1 (only '$' is smaller); rank through the sorted list of N rows
@@ -99,8 +115,11 @@ __device__ __forceinline__ void occ_pair(const IndexView& ix, uint32_t c, uint32
 
 // FMI_FollowLetter: returns true and updates [top,bot] when the extended string occurs
 __device__ __forceinline__ bool follow(const IndexView& ix, uint32_t c, uint32_t& top, uint32_t& bot) {
+    BlkCache bc;
+    bc.it = bc.ib = 0xFFFFFFFFu;
+    cache_blocks(ix, bc, top, bot);
     uint32_t nt, nb1;
-    occ_pair(ix, c, top, bot, nt, nb1);
+    occ_pair(ix, bc, c, top, bot, nt, nb1);
     if (nt >= nb1) return false;
     top = nt;
     bot = nb1 - 1u;
@@ -109,13 +128,13 @@ __device__ __forceinline__ bool follow(const IndexView& ix, uint32_t c, uint32_t
 
 // GetEnclosingLCPInterval: parent LCP-interval of [top,bot]; returns its depth, -1 at the root.
 __device__ __forceinline__ int parent(const IndexView& ix, uint32_t& top, uint32_t& bot) {
-    uint32_t a = ix.l8[top], b = ix.l8[bot + 1u];
-    if (a == 255u) a = ix.l32[top];
-    if (b == 255u) b = ix.l32[bot + 1u];
-    uint32_t d = a > b ? a : b;  // values are LCP+1
+    const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
+    uint4 rt = R[top], rb = R[bot + 1u];  // {lcp+1, psv, nsv, sa} of both boundary rows: one round trip
+    uint32_t a = rt.x, b = rb.x;
+    uint32_t d = a > b ? a : b;
     if (d == 0u) return -1;
-    if (a == d) top = ix.psv[top];
-    if (b == d) bot = ix.nsv[bot + 1u] - 1u;
+    if (a == d) top = rt.y;        // closest row above with a smaller LCP   (lcparray.c:519)
+    if (b == d) bot = rb.z - 1u;   // closest row below with a smaller LCP   (lcparray.c:520-521)
     return (int)(d - 1u);
 }
 
@@ -145,18 +164,25 @@ struct SearchArgs {
 struct QueryCursor {
     const uint64_t* words;
     uint64_t base;    // byte offset of the record
+    uint64_t wlo, whi;  // first / last word index that holds characters of this record
     uint32_t len;
     uint32_t rev;     // reverse-complement view
-    uint64_t widx;
-    uint64_t w;
+    uint64_t widx, wnidx;
+    uint64_t w, wn;   // current word and the next one in scan direction (prefetched one word ahead)
     __device__ __forceinline__ void init(const uint64_t* q, uint64_t b, uint32_t l, uint32_t r) {
-        words = q; base = b; len = l; rev = r; widx = ~0ull; w = 0;
+        words = q; base = b; len = l; rev = r; widx = ~0ull; wnidx = ~0ull; w = 0; wn = 0;
+        wlo = b >> 3; whi = l ? (b + l - 1u) >> 3 : wlo;
     }
     // letter id of position j of the scanned strand
     __device__ __forceinline__ uint32_t at(uint32_t j) {
         uint64_t p = base + (rev ? (uint64_t)(len - 1u - j) : (uint64_t)j);
         uint64_t wi = p >> 3;
-        if (wi != widx) { w = words[wi]; widx = wi; }
+        if (wi != widx) {
+            w = (wi == wnidx) ? wn : words[wi];
+            widx = wi;
+            // the scan moves right-to-left on the strand: down in memory for forward, up for reverse
+            if (rev ? wi < whi : wi > wlo) { wnidx = rev ? wi + 1u : wi - 1u; wn = words[wnidx]; }
+        }
         uint32_t c = ascii_code_q((uint32_t)(w >> ((p & 7u) * 8u)) & 0xFFu);
         return (rev && c >= 2u) ? 7u - c : c;  // A<->T, C<->G; N stays N  (sequence.c:419-426)
     }
@@ -164,7 +190,7 @@ struct QueryCursor {
 
 __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t row, uint32_t j,
                                      uint32_t len) {
-    uint32_t r = A.ix.sa[row];  // FMI_PositionInText
+    uint32_t r = A.ix.rec[row].sa;  // FMI_PositionInText
     unsigned long long slot = atomicAdd(A.total, 1ull);  // the compiler aggregates this per wave
     if (slot < A.capacity) {
         A.raw_key[slot] = RawKey{blockid, k};
@@ -221,15 +247,18 @@ __global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
     QueryCursor qc;
     qc.init(A.qwords, o0, len, rev);
 
+    BlkCache bc;
+    bc.it = bc.ib = 0xFFFFFFFFu;
     uint32_t top = 0, bot = ix.n;  // root: all rows  (slamem.c:110-111)
     int depth = 0;
     int pub = -1;       // bound on the parent depth of [top,bot]: the root has no parent
     bool pend = false;  // position j+1 matched >= min_len characters: its rows wait for the left letter
     uint32_t k = 0;
     for (uint32_t j = len; j-- > 0u;) {  // slamem.c:114
+        cache_blocks(ix, bc, top, bot);  // issue the block loads first: they do not depend on the query letter
         uint32_t c = qc.at(j);
         uint32_t nt, nb1;
-        occ_pair(ix, c, top, bot, nt, nb1);
+        occ_pair(ix, bc, c, top, bot, nt, nb1);
         if (pend) emit_levels(A, (uint32_t)g, k, top, bot, depth, j + 1u, c, nb1 - nt, pub);
         // extend to the left, widening to parent intervals while the extension fails (slamem.c:121-128)
         while (nt >= nb1) {
@@ -237,7 +266,8 @@ __global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
             depth = d;
             if (d < 0) break;  // root and the letter does not occur at all
             pub = d - 1;       // the parent of an interval of depth d is shallower than d
-            occ_pair(ix, c, top, bot, nt, nb1);
+            cache_blocks(ix, bc, top, bot);
+            occ_pair(ix, bc, c, top, bot, nt, nb1);
         }
         if (nt < nb1) {
             top = nt;
@@ -291,7 +321,7 @@ __global__ void __launch_bounds__(256) k_locate_batch(IndexView ix, const uint32
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     uint32_t r = rows[i];
-    out[i] = r <= ix.n ? ix.sa[r] : 0xFFFFFFFFu;
+    out[i] = r <= ix.n ? ix.rec[r].sa : 0xFFFFFFFFu;
 }
 
 __global__ void __launch_bounds__(256) k_bwtchar_batch(IndexView ix, const uint32_t* __restrict__ rows, char* out,

@@ -20,15 +20,34 @@ from slamem_amd import capi  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calibrate", action="store_true", help="one launch per table size only (for --pmc runs)")
+    ap.add_argument("--modes", action="store_true", help="address-path experiment: lane / quad / row cooperative reads")
     a = ap.parse_args()
     S = capi.synth_lib()
     S.slamem_gather_bench.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    S.slamem_gather_modes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     dev = torch.device("cuda:0")
     sink = torch.zeros(8, dtype=torch.int64, device=dev)
     lanes = 256 * 32 * 64 * 4  # 4 full waves of the chip
     for mb in (2, 16, 50, 150, 1750, 8000):
         nblk = mb * (1 << 20) // 64
         table = torch.randint(0, 2 ** 31, (nblk * 16,), dtype=torch.int32, device=dev)
+        if a.modes:
+            for mode in (0, 1, 2):
+                iters = 64
+                S.slamem_gather_modes(table.data_ptr(), nblk, lanes, 4, mode, sink.data_ptr(), None)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                S.slamem_gather_modes(table.data_ptr(), nblk, lanes, iters, mode, sink.data_ptr(), None)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                lane_acc = lanes * iters
+                lines = lane_acc // (1 if mode == 0 else 4)
+                print(json.dumps({"table_MB": mb, "mode": ["lane16B", "quad64B", "row256B"][mode], "ms": ms,
+                                  "Glane_accesses_per_s": lane_acc / ms / 1e6, "Glines_per_s": lines / ms / 1e6}), flush=True)
+            del table
+            continue
         for ilp in ((1,) if a.calibrate else (1, 2, 4)):
             iters = 64 // ilp
             S.slamem_gather_bench(table.data_ptr(), nblk, lanes, 4, ilp, sink.data_ptr(), None)  # warm
