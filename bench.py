@@ -45,7 +45,7 @@ def parse_args():
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--rc-percent", type=int, default=50)
     p.add_argument("--forward-only", action="store_true")
-    p.add_argument("--cpu-sample-reads", type=int, default=40_000)
+    p.add_argument("--cpu-sample-reads", type=int, default=250_000)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
 
@@ -80,7 +80,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from slamem_amd import engine
+    from slamem_amd import engine, shard
 
     both = not a.forward_only
     n, M, L = a.ref_len, a.reads, a.read_len
@@ -101,15 +101,11 @@ def main():
         build_s = time.time() - t0
         build_t = {k: v for k, v in engine.timings().items() if k.startswith("build_")}
     if world > 1:
-        size = torch.zeros(1, dtype=torch.int64, device=dev)
-        if rank == 0:
-            size[0] = int(index.info.arena_bytes)
-        dist.broadcast(size, 0)
-        arena = index.export_arena() if rank == 0 else torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        arena = index.export_arena() if rank == 0 else None
         torch.cuda.synchronize(dev)
         dist.barrier()
         t0 = time.time()
-        dist.broadcast(arena, 0)
+        arena = shard.broadcast_arena(arena, dev, src=0)  # ONE RCCL broadcast of the whole index over xGMI
         torch.cuda.synchronize(dev)
         bcast_s = time.time() - t0
         if rank != 0:
@@ -119,15 +115,11 @@ def main():
     # ---- the timed hot path ------------------------------------------------------------------------------------
     matcher = index.matcher(M, both, mems_capacity=4 * M + 1024)
     counts_all = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step():
+        nonlocal counts_all
         total = matcher.run(reads, offsets, a.min_len)
-        if world > 1:
-            mine[0] = total
-            dist.all_gather_into_tensor(counts_all, mine)  # final gather of per-rank MEM counts
-        else:
-            counts_all[0] = total
+        counts_all = shard.gather_counts(total, dev)  # final gather of per-rank MEM counts (tiny; no data-path collective)
         return total
 
     for _ in range(a.warmup):

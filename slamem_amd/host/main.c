@@ -1,0 +1,211 @@
+/* main.c -- slaMEM-compatible command line in front of the MI355X engine.
+ *
+ *   slaMEM-hip (<options>) <reference_file> <query_file(s)>
+ *
+ * Keeps the reference's options, stdout shape and *-mems.txt format (slamem.c:528-672, 37-218); the
+ * index build and the MEM search run on the GPU through the C ABI of include/slamem_hip.h.
+ * There is no CPU fallback: without a usable GPU the program prints the library's error and exits 255.
+ *
+ * Environment: SLAMEM_DEVICE (default 0) selects the GPU; SLAMEM_VERBOSE=1 prints one line per loaded
+ * record and per strand for any number of records, as the reference does (default: first 100 only);
+ * SLAMEM_BATCH_MB bounds the query characters sent to the GPU per batch (default 1024).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../../include/slamem_hip.h"
+#include "slamem_host.h"
+
+#define VERSION "0.8.2"
+static const char MATCH_TYPE_CHAR[] = "EAU";
+
+static void exit_message(const char *msg) { /* tools.c:21-25 */
+    printf("> ERROR: %s\n", msg);
+    exit(-1);
+}
+
+static void gpu_fail(const char *what, int rc) {
+    printf("\n> ERROR: %s failed: %s (%s)\n", what, slamem_strerror(rc), slamem_last_error_message());
+    exit(-1);
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void usage(const char *prog) { /* slamem.c:533-553 */
+    printf("Usage:\n");
+    printf("\t%s (<options>) <reference_file> <query_file(s)>\n", prog);
+    printf("Options:\n");
+    printf("\t-mem\tfind MEMs: any number of occurrences in both ref and query (default)\n");
+    printf("\t-mam\tfind MAMs: unique in ref but any number in query\n");
+    printf("\t-l\tminimum match length (default=20)\n");
+    printf("\t-o\toutput file name (default=\"*-mems.txt\")\n");
+    printf("\t-b\tprocess both forward and reverse strands\n");
+    printf("\t-n\tdiscard 'N' characters in the sequences\n");
+    printf("\t-m\tminimum sequence size (e.g. to ignore small scaffolds)\n");
+    printf("\t-r\tload only the reference(s) whose name(s) contain(s) this string\n");
+    printf("Example:\n");
+    printf("\t%s -b -l 10 ./ref.fna ./query.fna\n", prog);
+}
+
+int main(int argc, char **argv) {
+    slh_options o;
+    slh_seqset ref, *qsets;
+    int i, f, num_qsets = 0, total_queries = 0, device = 0, numbering = 1;
+    long log_limit = 100;
+    uint64_t batch_bytes = 1024ull << 20;
+    const char *env;
+    char *out_name;
+    FILE *out;
+    slamem_index *idx = NULL;
+    int rc;
+    double t0;
+    long long total_matches = 0, total_sum = 0;
+    slh_buffer buf = {0, 0, 0};
+
+    printf("[ slaMEM v%s ]\n\n", VERSION);
+    if (slh_parse_options(argc, argv, &o) != 0) exit_message("Out of memory");
+    if (o.usage) { usage(argv[0]); return -1; }
+    if (o.hidden_sort || o.hidden_clean) exit_message("The -s / -c utilities are not part of this front end");
+    if (o.num_files < 2) exit_message("Not enough input sequence files provided");
+    if (o.ref_name_given && o.ref_name_empty) exit_message("No reference name string provided");
+    if (o.image_arg != -1) exit_message("The -v image tool is not part of this front end (use the reference's on the *-mems.txt output)");
+    if (o.match_type == 1) exit_message("MAM mode (-mam) is not implemented in this front end yet");
+    if ((env = getenv("SLAMEM_DEVICE")) != NULL) device = atoi(env);
+    if ((env = getenv("SLAMEM_VERBOSE")) != NULL && atoi(env) != 0) log_limit = 0;
+    if ((env = getenv("SLAMEM_BATCH_MB")) != NULL && atoll(env) > 0) batch_bytes = (uint64_t)atoll(env) << 20;
+
+    /* load everything (slamem.c:635-651) */
+    memset(&ref, 0, sizeof(ref));
+    qsets = (slh_seqset *)calloc((size_t)o.num_files, sizeof(slh_seqset));
+    if (!qsets) exit_message("Out of memory");
+    {
+        int have_ref = 0;
+        for (f = 0; f < o.num_files; f++) {
+            const char *path = argv[o.file_args[f]];
+            if (!have_ref) {
+                int n = slh_load_file(path, 1, o.no_ns, (uint32_t)o.min_seq_len, o.ref_name, numbering, log_limit, &ref, stdout);
+                if (n == 0) exit_message("No valid sequences found in reference file");
+                have_ref = 1;
+                numbering += n;
+                o.file_args[0] = o.file_args[f]; /* remember which argument was the reference */
+            } else {
+                int n = slh_load_file(path, 0, o.no_ns, (uint32_t)o.min_seq_len, NULL, numbering, log_limit, &qsets[num_qsets], stdout);
+                if (n != 0) { numbering += n; total_queries += n; num_qsets++; }
+            }
+        }
+    }
+    if (num_qsets == 0) exit_message("No query files provided"); /* slamem.c:648 */
+    printf("> %d reference%s and %d quer%s successfully loaded\n", ref.num, ref.num == 1 ? "" : "s", total_queries,
+           total_queries == 1 ? "y" : "ies");
+    if (o.min_mem_len < 1) exit_message("Minimum match length must be at least 1");
+
+    if (o.out_arg == -1) out_name = slh_append_to_basename(argv[o.file_args[0]], "-mems.txt");
+    else out_name = argv[o.out_arg];
+
+    /* GetMatches (slamem.c:37-218) */
+    printf("> Using options: minimum M%cM length = %d ; strand = %s\n", MATCH_TYPE_CHAR[o.match_type], o.min_mem_len,
+           o.both_strands == 0 ? "forward only" : "forward + reverse");
+    out = fopen(out_name, "w");
+    if (!out) {
+        printf("\n> ERROR: Cannot create output file <%s>\n", out_name);
+        exit(-1);
+    }
+    printf("> Building index for reference sequence");
+    if (ref.num == 1) printf(" \"%s\"", ref.recs[0].name);
+    else printf("s");
+    printf(" (%u Mbp) ...\n", (unsigned)(ref.total / 1000000U));
+    fflush(stdout);
+    t0 = now_s();
+    rc = slamem_index_build(ref.chars, (uint32_t)ref.total, device, &idx);
+    if (rc != SLAMEM_OK) gpu_fail("index construction on the GPU", rc);
+    {
+        slamem_index_info info;
+        slamem_timings tm;
+        slamem_index_get_info(idx, &info);
+        slamem_get_timings(&tm);
+        printf("> Suffix sort + BWT + LCP + parent links on GPU %d ... OK (%.3f s; device %.1f ms: sort %.1f, BWT %.1f, LCP %.1f, links %.1f; %u doubling rounds)\n",
+               device, now_s() - t0, tm.build_total_ms, tm.build_sort_ms, tm.build_bwt_ms, tm.build_lcp_ms, tm.build_links_ms,
+               info.sort_rounds);
+        printf(":: Index size = %.1f MB in HBM (FM blocks + 16 B per row) ; max LCP = %u\n", (double)info.arena_bytes / 1e6, info.max_lcp);
+    }
+    free(ref.chars); /* the reference frees the text here too (slamem.c:75-77) */
+    ref.chars = NULL;
+    printf("> Matching query sequences against index ...\n");
+    fflush(stdout);
+
+    {
+        int strands = o.both_strands ? 2 : 1;
+        long printed = 0;
+        for (f = 0; f < num_qsets; f++) {
+            slh_seqset *q = &qsets[f];
+            int first = 0;
+            while (first < q->num) { /* batches of records */
+                int last = first;
+                uint64_t base = q->offsets[first];
+                slamem_mem *mems = NULL;
+                uint64_t *boff = NULL, total = 0, *offs;
+                while (last < q->num && (last == first || q->offsets[last + 1] - base <= batch_bytes)) last++;
+                offs = (uint64_t *)malloc(((size_t)(last - first) + 1) * sizeof(uint64_t));
+                if (!offs) exit_message("Out of memory");
+                for (i = first; i <= last; i++) offs[i - first] = q->offsets[i] - base;
+                rc = slamem_find_mems_host(idx, q->chars + base, offs, (uint32_t)(last - first), (uint32_t)o.min_mem_len,
+                                           o.both_strands, &mems, &boff, &total);
+                if (rc != SLAMEM_OK) gpu_fail("MEM search on the GPU", rc);
+                for (i = first; i < last; i++) {
+                    int s;
+                    for (s = 0; s < strands; s++) {
+                        uint64_t b = (uint64_t)(i - first) * strands + s, cnt = boff[b + 1] - boff[b], sum = 0;
+                        if (slh_format_block(&buf, q->recs[i].name, s, (const uint32_t *)(mems + boff[b]), cnt, ref.recs,
+                                             ref.merged_start, ref.num, &sum))
+                            exit_message("Out of memory");
+                        total_matches += (long long)cnt;
+                        total_sum += (long long)sum;
+                        if (log_limit == 0 || printed < log_limit) { /* slamem.c:97,101,203 */
+                            int d, dots = slh_progress_dots(q->recs[i].size);
+                            printf(":: \"%s%s\" ", q->recs[i].name, s ? " Reverse" : "");
+                            for (d = 0; d < dots; d++) putchar('.');
+                            printf(" (%d M%cMs ; avg size = %d bp)\n", (int)cnt, MATCH_TYPE_CHAR[o.match_type],
+                                   (int)(cnt ? sum / cnt : 0));
+                            printed++;
+                        }
+                    }
+                    if (buf.len > (64u << 20)) {
+                        if (fwrite(buf.data, 1, buf.len, out) != buf.len) exit_message("Cannot write output file");
+                        buf.len = 0;
+                    }
+                }
+                slamem_host_free(mems);
+                slamem_host_free(boff);
+                free(offs);
+                first = last;
+            }
+        }
+        if (buf.len && fwrite(buf.data, 1, buf.len, out) != buf.len) exit_message("Cannot write output file");
+        if (log_limit != 0 && (long)total_queries * strands > log_limit)
+            printf(":: ... (%ld more strand blocks matched; set SLAMEM_VERBOSE=1 for a line each)\n",
+                   (long)total_queries * strands - log_limit);
+    }
+    slamem_index_free(idx);
+    if (total_queries != 1) /* slamem.c:210-212 (the reference divides by zero when nothing matched) */
+        printf(":: Average %d M%cMs found per query sequence (total = %lld, avg size = %d bp)\n",
+               (int)(total_matches / total_queries), MATCH_TYPE_CHAR[o.match_type], total_matches,
+               (int)(total_matches ? total_sum / total_matches : 0));
+    fflush(stdout);
+    printf("> Saving M%cMs to <%s> ... ", MATCH_TYPE_CHAR[o.match_type], out_name);
+    if (fclose(out) != 0) exit_message("Cannot write output file");
+    printf("OK\n");
+    if (o.out_arg == -1) free(out_name);
+    slh_buffer_free(&buf);
+    slh_free_seqset(&ref);
+    for (f = 0; f < num_qsets; f++) slh_free_seqset(&qsets[f]);
+    free(qsets);
+    slh_free_options(&o);
+    printf("> Done!\n");
+    return 0;
+}

@@ -1,0 +1,431 @@
+/* slamem_host.c -- FASTA loading, option parsing and MEM text formatting of the slaMEM-compatible
+ * front end.  Plain C, no GPU code; see slamem_host.h for the reference lines each piece restates. */
+#include "slamem_host.h"
+
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------ */
+/* FASTA                                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* InitCharsTable (sequence.c:61-81): A/C/G/T any case -> upper; other letters -> 'N' unless acgt_only;
+ * '>' ends a record; everything else (digits, blanks, '*', '-') is dropped. */
+static void init_table(char table[256], int allow_ns) {
+    int i;
+    memset(table, 0, 256);
+    if (allow_ns)
+        for (i = 'A'; i <= 'Z'; i++) { table[i] = 'N'; table[i + 32] = 'N'; }
+    table['A'] = table['a'] = 'A';
+    table['C'] = table['c'] = 'C';
+    table['G'] = table['g'] = 'G';
+    table['T'] = table['t'] = 'T';
+}
+
+typedef struct {
+    const unsigned char *p, *end;
+} reader;
+
+static int rd(reader *r) { return r->p < r->end ? (int)*r->p++ : EOF; }
+
+static int grow(char **buf, uint64_t *cap, uint64_t need) {
+    if (need <= *cap) return 0;
+    uint64_t nc = *cap ? *cap : (1u << 20);
+    while (nc < need) nc += nc / 2 + (1u << 20);
+    char *nb = (char *)realloc(*buf, nc);
+    if (!nb) return -1;
+    *buf = nb;
+    *cap = nc;
+    return 0;
+}
+
+void slh_free_seqset(slh_seqset *s) {
+    int i;
+    if (!s) return;
+    for (i = 0; i < s->num; i++) free(s->recs[i].name);
+    free(s->recs);
+    free(s->chars);
+    free(s->offsets);
+    free(s->merged_start);
+    memset(s, 0, sizeof(*s));
+}
+
+int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, const char *name_filter,
+                  int first_number, long log_limit, slh_seqset *out, FILE *log) {
+    FILE *f;
+    unsigned char *data = NULL;
+    long fsize;
+    char table[256];
+    reader r;
+    int c, k, numseqs = 0, reccap = 0, matchpos, desclen;
+    uint64_t seqlen = 0, maxseqlen = 0, cap = 0, offcap = 0;
+    uint32_t seqsize;
+    long logged = 0;
+    char *chars = NULL;
+
+    memset(out, 0, sizeof(*out));
+    if (log) fprintf(log, "> Loading sequences from file <%s> ... ", path);
+    f = fopen(path, "rb");
+    if (!f) {
+        if (log) fprintf(log, "\n> WARNING: Sequence file not found\n");
+        return 0;
+    }
+    fseek(f, 0L, SEEK_END);
+    fsize = ftell(f);
+    rewind(f);
+    if (log) fprintf(log, "(%ld bytes)\n", fsize);
+    data = (unsigned char *)malloc(fsize > 0 ? (size_t)fsize : 1);
+    if (!data || (fsize > 0 && fread(data, 1, (size_t)fsize, f) != (size_t)fsize)) {
+        if (log) fprintf(log, "> WARNING: Cannot read file\n");
+        free(data);
+        fclose(f);
+        return 0;
+    }
+    fclose(f);
+    out->file_bytes = fsize;
+    r.p = data;
+    r.end = data + fsize;
+    c = rd(&r);
+    if (c != '>') {
+        if (log) fprintf(log, "> WARNING: Invalid FASTA file\n");
+        free(data);
+        return 0;
+    }
+    init_table(table, !acgt_only);
+    for (;;) { /* all records of the file (sequence.c:128) */
+        const unsigned char *name_start;
+        int quiet;
+        while (c != EOF && c != '>') c = rd(&r);
+        if (c == EOF) break;
+        quiet = !log || (log_limit > 0 && logged >= log_limit);
+        if (!quiet) fprintf(log, "# %02d [", first_number + numseqs);
+        name_start = r.p;
+        matchpos = 0;
+        desclen = 0;
+        while ((c = rd(&r)) != EOF && c != '\n' && c != '\r') {
+            if (!quiet && desclen < 50) fputc(c, log);
+            if (name_filter && name_filter[matchpos] != '\0') { /* sequence.c:137-140 */
+                if (name_filter[matchpos] == (char)c) matchpos++;
+                else matchpos = 0;
+            }
+            desclen++;
+        }
+        if (!quiet) {
+            for (k = desclen; k < 50; k++) fputc(' ', log);
+            fprintf(log, "] ");
+        }
+        if (name_filter && name_filter[matchpos] != '\0') {
+            if (!quiet) { fprintf(log, "NAME DOES NOT MATCH\n"); logged++; }
+            continue;
+        }
+        seqsize = 0;
+        if (!merge) {
+            maxseqlen = seqlen; /* every query record is its own sequence */
+        } else if (numseqs == 0) {
+            seqlen = 0; /* sequence.c:151-155 */
+            maxseqlen = 0;
+        }
+        {
+            uint64_t rec_start = seqlen;
+            while ((c = rd(&r)) != '>' && c != EOF) {
+                char t = table[c];
+                if (t) {
+                    if (grow(&chars, &cap, seqlen + 3)) goto oom;
+                    if (seqlen == maxseqlen) { /* sequence.c:160-166 */
+                        maxseqlen += (1u << 20);
+                        if (merge && numseqs != 0 && seqsize == 0) chars[seqlen++] = 'N';
+                    }
+                    chars[seqlen++] = t;
+                    seqsize++;
+                    if (seqlen >= 0xFFFFFFF0ull) {
+                        if (log) fprintf(log, "\n> WARNING: Sequence lengths of more than %u bp are not supported\n", UINT_MAX);
+                        goto fail;
+                    }
+                }
+            }
+            if (merge) {
+                if (seqlen != 0) maxseqlen = seqlen; /* sequence.c:172-176 */
+            }
+            if (seqsize == 0) {
+                if (!quiet) { fprintf(log, "EMPTY\n"); logged++; }
+                continue;
+            }
+            if (min_len != 0 && seqsize < min_len) {
+                if (!quiet) { fprintf(log, "(%u bp) TOO SHORT\n", seqsize); logged++; }
+                if (merge) seqlen -= seqsize; /* sequence.c:200: the separator 'N' stays */
+                else seqlen = rec_start;
+                continue;
+            }
+            if (!quiet) fprintf(log, "(%u bp) ", seqsize);
+            if (numseqs == reccap) {
+                int nc = reccap ? reccap * 2 : 64;
+                slh_record *nr = (slh_record *)realloc(out->recs, (size_t)nc * sizeof(slh_record));
+                if (!nr) goto oom;
+                out->recs = nr;
+                reccap = nc;
+            }
+            out->recs[numseqs].name = (char *)malloc((size_t)desclen + 1);
+            if (!out->recs[numseqs].name) goto oom;
+            memcpy(out->recs[numseqs].name, name_start, (size_t)desclen);
+            out->recs[numseqs].name[desclen] = '\0';
+            out->recs[numseqs].size = seqsize;
+            if (!merge) {
+                if ((uint64_t)numseqs + 2 > offcap) {
+                    uint64_t nc = offcap ? offcap * 2 : 1024;
+                    uint64_t *no = (uint64_t *)realloc(out->offsets, nc * sizeof(uint64_t));
+                    if (!no) goto oom;
+                    out->offsets = no;
+                    offcap = nc;
+                }
+                out->offsets[numseqs] = rec_start;
+                out->offsets[numseqs + 1] = seqlen;
+            }
+            numseqs++;
+            out->num = numseqs;
+            if (!quiet) { fprintf(log, "OK\n"); logged++; }
+            else if (log && log_limit > 0 && logged == log_limit) {
+                fprintf(log, "# ... (further records of this file are loaded without a line each)\n");
+                logged++;
+            }
+        }
+    }
+    free(data);
+    data = NULL;
+    if (numseqs == 0) {
+        free(chars);
+        slh_free_seqset(out);
+        return 0;
+    }
+    if (grow(&chars, &cap, seqlen + 16)) goto oom;
+    memset(chars + seqlen, 0, 16);
+    out->chars = chars;
+    out->total = seqlen;
+    if (merge) { /* sequence.c:258-265 */
+        out->merged_start = (uint32_t *)malloc((size_t)numseqs * sizeof(uint32_t));
+        if (!out->merged_start) { chars = NULL; goto oom; }
+        out->merged_start[0] = 0;
+        for (k = 1; k < numseqs; k++) out->merged_start[k] = out->merged_start[k - 1] + out->recs[k - 1].size + 1;
+    } else if (!out->offsets) {
+        goto oom;
+    }
+    return numseqs;
+oom:
+    if (log) fprintf(log, "\n> ERROR: Out of memory while loading <%s>\n", path);
+fail:
+    free(data);
+    if (chars != out->chars) free(chars);
+    slh_free_seqset(out);
+    return 0;
+}
+
+int slh_seq_id_from_merged_pos(const uint32_t *starts, int num, uint32_t *pos) {
+    int lo = 0, hi = num - 1;
+    while (lo != hi) { /* binary search for the last start <= pos */
+        int mid = (lo + hi + 1) / 2;
+        if (*pos >= starts[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    *pos -= starts[lo];
+    return lo;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* options                                                                                           */
+/* ------------------------------------------------------------------------------------------------ */
+
+int slh_parse_argument(int argc, char **argv, const char *optionchars, int parse) {
+    char uc[2] = {0, 0}, lc[2] = {0, 0};
+    int i;
+    for (i = 0; i < 2 && optionchars[i] != '\0'; i++) { /* only the first two characters of the option name count */
+        char ch = optionchars[i];
+        if (ch >= 'A' && ch <= 'Z') { uc[i] = ch; lc[i] = (char)(ch + 32); }
+        else { uc[i] = (char)(ch - 32); lc[i] = ch; }
+    }
+    for (i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        /* a one-letter option must be exactly two characters long: its third must equal the '\0' in uc[1] */
+        if (a[0] == '-' && a[1] != '\0' && (a[1] == lc[0] || a[1] == uc[0]) && (a[2] == lc[1] || a[2] == uc[1])) {
+            if (parse) {
+                if (i == argc - 1) return -1; /* nothing in front of it */
+                if (parse == 1) return atoi(argv[i + 1]);
+                return i + 1;
+            }
+            return 1;
+        }
+    }
+    return parse ? -1 : 0;
+}
+
+char *slh_append_to_basename(const char *filename, const char *extra) {
+    int n = (int)strlen(filename), i;
+    char *res;
+    for (i = n - 1; i > 0; i--)
+        if (filename[i] == '.') break;
+    if (i <= 0) i = n;
+    res = (char *)calloc((size_t)i + strlen(extra) + 1, 1);
+    if (!res) return NULL;
+    memcpy(res, filename, (size_t)i);
+    strcat(res, extra);
+    return res;
+}
+
+void slh_free_options(slh_options *o) {
+    free(o->ref_name);
+    free(o->file_args);
+    memset(o, 0, sizeof(*o));
+}
+
+int slh_parse_options(int argc, char **argv, slh_options *o) {
+    int i, j, n = 0, ref_arg;
+    char oc;
+    memset(o, 0, sizeof(*o));
+    o->image_arg = o->out_arg = -1;
+    o->min_mem_len = 20;
+    if (argc < 3) { o->usage = 1; return 0; }
+    o->hidden_sort = slh_parse_argument(argc, argv, "S", 0);
+    o->hidden_clean = slh_parse_argument(argc, argv, "C", 0);
+    o->file_args = (int *)calloc((size_t)argc, sizeof(int));
+    if (!o->file_args) return -1;
+    for (i = 1; i < argc; i++) { /* which arguments are FASTA files (slamem.c:574-600) */
+        if (argv[i][0] == '-') {
+            oc = argv[i][1];
+            if (oc >= 'A' && oc <= 'Z') oc = (char)('a' + (oc - 'A'));
+            if (oc == 'l' || oc == 'o' || oc == 'm' || oc == 'v') i++; /* any option starting with l/o/m/v eats the next argument */
+            else if (oc == 'r') {
+                i++;
+                if (i == argc) break;
+                j = 0;
+                oc = argv[i][0];
+                if (oc == '\'' || oc == '\"') j = 1;
+                else oc = '\0';
+                n = 0;
+                while (argv[i][j] != oc) {
+                    if (argv[i][j] == '\0') {
+                        i++;
+                        if (i == argc) break;
+                        j = 0;
+                    } else j++;
+                    n++;
+                }
+            }
+            continue;
+        }
+        o->file_args[o->num_files++] = i;
+    }
+    o->no_ns = slh_parse_argument(argc, argv, "N", 0);
+    o->min_seq_len = slh_parse_argument(argc, argv, "M", 1);
+    if (o->min_seq_len == -1) o->min_seq_len = 0;
+    ref_arg = slh_parse_argument(argc, argv, "R", 2);
+    if (ref_arg != -1) { /* slamem.c:605-629 */
+        o->ref_name_given = 1;
+        if (n == 0) o->ref_name_empty = 1;
+        else {
+            o->ref_name = (char *)calloc((size_t)n + 1, 1);
+            if (!o->ref_name) return -1;
+            i = ref_arg;
+            j = 0;
+            oc = argv[i][0];
+            if (oc == '\'' || oc == '\"') j = 1;
+            else oc = '\0';
+            n = 0;
+            while (argv[i][j] != oc) {
+                if (argv[i][j] == '\0') {
+                    i++;
+                    if (i == argc) break;
+                    j = 0;
+                    o->ref_name[n] = ' ';
+                } else {
+                    o->ref_name[n] = argv[i][j];
+                    j++;
+                }
+                n++;
+            }
+            o->ref_name[n] = '\0';
+        }
+    }
+    o->image_arg = slh_parse_argument(argc, argv, "V", 2);
+    o->match_type = slh_parse_argument(argc, argv, "MA", 0) ? 1 : 0;
+    o->both_strands = slh_parse_argument(argc, argv, "B", 0);
+    o->min_mem_len = slh_parse_argument(argc, argv, "L", 1);
+    if (o->min_mem_len == -1) o->min_mem_len = 20;
+    o->out_arg = slh_parse_argument(argc, argv, "O", 2);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* output                                                                                            */
+/* ------------------------------------------------------------------------------------------------ */
+
+void slh_buffer_free(slh_buffer *b) {
+    free(b->data);
+    b->data = NULL;
+    b->len = b->cap = 0;
+}
+
+static int buf_reserve(slh_buffer *b, size_t extra) {
+    if (b->len + extra <= b->cap) return 0;
+    size_t nc = b->cap ? b->cap * 2 : (1u << 16);
+    while (nc < b->len + extra) nc *= 2;
+    char *nd = (char *)realloc(b->data, nc);
+    if (!nd) return -1;
+    b->data = nd;
+    b->cap = nc;
+    return 0;
+}
+
+static inline char *put_u32(char *p, uint32_t v) {
+    char tmp[10];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+int slh_format_block(slh_buffer *buf, const char *query_name, int reverse, const uint32_t *mems, uint64_t count,
+                     const slh_record *refs, const uint32_t *merged_start, int num_refs, uint64_t *sum_len_out) {
+    size_t nl = strlen(query_name);
+    uint64_t i, sum = 0;
+    char *p;
+    if (buf_reserve(buf, nl + 16)) return -1;
+    p = buf->data + buf->len;
+    *p++ = '>';
+    memcpy(p, query_name, nl);
+    p += nl;
+    if (reverse) { memcpy(p, " Reverse", 8); p += 8; } /* slamem.c:102 */
+    *p++ = '\n';
+    buf->len = (size_t)(p - buf->data);
+    for (i = 0; i < count; i++) {
+        uint32_t rp = mems[3 * i], qp = mems[3 * i + 1], ln = mems[3 * i + 2];
+        size_t namelen = 0;
+        const char *rname = NULL;
+        if (num_refs != 1) { /* slamem.c:144-147 */
+            int id = slh_seq_id_from_merged_pos(merged_start, num_refs, &rp);
+            rname = refs[id].name;
+            namelen = strlen(rname);
+        }
+        if (buf_reserve(buf, namelen + 48)) return -1;
+        p = buf->data + buf->len;
+        if (rname) {
+            *p++ = ' ';
+            memcpy(p, rname, namelen);
+            p += namelen;
+            *p++ = '\t';
+        }
+        p = put_u32(p, rp + 1); /* slamem.c:148 */
+        *p++ = '\t';
+        p = put_u32(p, qp + 1);
+        *p++ = '\t';
+        p = put_u32(p, ln);
+        *p++ = '\n';
+        buf->len = (size_t)(p - buf->data);
+        sum += ln;
+    }
+    if (sum_len_out) *sum_len_out = sum;
+    return 0;
+}
+
+int slh_progress_dots(uint32_t textsize) {
+    uint32_t step = textsize / 10; /* slamem.c:94 */
+    return (int)(textsize / (step + 1)); /* one dot each time the counter reaches the step (slamem.c:116-120) */
+}

@@ -1,0 +1,89 @@
+/* slamem_host.h -- host side of the slaMEM-compatible front end (plain C, no GPU code).
+ *
+ * Written from scratch against the reference's observable behaviour:
+ *   - FASTA loading / normalisation / merging        sequence.c:61-81, 89-270, 272-301, 309-320
+ *   - command-line conventions                        slamem.c:528-663, tools.c:31-79
+ *   - the *-mems.txt text format                      slamem.c:98, 102, 144-148
+ * libslamem_host.so carries these for the CPU tests; slaMEM-hip links them with libslamem_hip.so.
+ */
+#ifndef SLAMEM_HOST_H
+#define SLAMEM_HOST_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    char *name;    /* full header line after '>' (sequence.c:213-217) */
+    uint32_t size; /* normalised characters of this record            */
+} slh_record;
+
+typedef struct {
+    slh_record *recs;
+    int num;                /* accepted records                                                      */
+    char *chars;            /* merge: rec0 'N' rec1 'N' ... ; otherwise the records back to back     */
+    uint64_t total;         /* bytes in chars (merge: what the reference stores as allSequences[0]->size) */
+    uint64_t *offsets;      /* !merge: num+1 start offsets into chars                                */
+    uint32_t *merged_start; /* merge: start of record k in chars (sequence.c:260-262)                */
+    long file_bytes;
+} slh_seqset;
+
+/* LoadSequencesFromFile (sequence.c:89-270).  merge=1 for the reference file (records joined by 'N',
+ * name filter applies), merge=0 for query files.  first_number: running record number for the
+ * "# NN [name]" log lines; log may be NULL.  log_limit: at most this many per-record lines are printed
+ * (the reference prints all; 0 = unlimited).  Returns the number of accepted records, 0 on any failure
+ * (message printed to log like the reference does). */
+int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, const char *name_filter,
+                  int first_number, long log_limit, slh_seqset *out, FILE *log);
+void slh_free_seqset(slh_seqset *s);
+
+/* GetSeqIdFromMergedSeqsPos (sequence.c:309-320). */
+int slh_seq_id_from_merged_pos(const uint32_t *starts, int num, uint32_t *pos);
+
+/* Options as the reference parses them (slamem.c:571-663; tools.c:31-62). */
+typedef struct {
+    int usage;          /* argc < 3                                          */
+    int hidden_sort;    /* -s given (not supported by this front end)        */
+    int hidden_clean;   /* -c given (not supported by this front end)        */
+    int image_arg;      /* index of the -v value, or -1                      */
+    int no_ns;          /* -n                                                */
+    int min_seq_len;    /* -m, 0 if absent                                   */
+    char *ref_name;     /* -r string (malloc'ed) or NULL                     */
+    int ref_name_given; /* -r present                                        */
+    int ref_name_empty; /* -r present without a string                       */
+    int match_type;     /* 0 MEM, 1 MAM (-ma...)                             */
+    int both_strands;   /* -b                                                */
+    int min_mem_len;    /* -l, default 20                                    */
+    int out_arg;        /* index of the -o value, or -1                      */
+    int num_files;
+    int *file_args;     /* indices into argv of the FASTA files, in order    */
+} slh_options;
+
+int slh_parse_options(int argc, char **argv, slh_options *o);
+void slh_free_options(slh_options *o);
+/* ParseArgument (tools.c:31-62) */
+int slh_parse_argument(int argc, char **argv, const char *optionchars, int parse);
+/* AppendToBasename (tools.c:65-79): everything before the last '.' of the whole path + extra */
+char *slh_append_to_basename(const char *filename, const char *extra);
+
+/* One strand block of the output file (slamem.c:98/102 header + :144-148 lines).
+ * mems: triples (ref_pos, query_pos, length), 0-based; printed 1-based.  When num_refs > 1 every line is
+ * prefixed by " <record name>\t" and ref_pos is made relative to the record.  Appends to buf (realloc'ed). */
+typedef struct {
+    char *data;
+    size_t len, cap;
+} slh_buffer;
+int slh_format_block(slh_buffer *buf, const char *query_name, int reverse, const uint32_t *mems, uint64_t count,
+                     const slh_record *refs, const uint32_t *merged_start, int num_refs, uint64_t *sum_len_out);
+void slh_buffer_free(slh_buffer *b);
+
+/* number of progress dots the reference prints for a strand of this length (slamem.c:94,116-120) */
+int slh_progress_dots(uint32_t textsize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

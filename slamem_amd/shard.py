@@ -1,0 +1,91 @@
+"""Multi-GPU plumbing of the MEM path: one process per GPU over torch.distributed (backend "nccl" = RCCL on
+ROCm, "gloo" in the CPU tests).  The path shards by query record with NO data-path collective:
+
+* the index is built once on rank 0 and replicated with ONE broadcast of its arena (a single contiguous
+  HBM buffer, see include/slamem_hip.h) -- xGMI is point-to-point, so one large transfer per peer beats
+  many small ones;
+* every rank matches a contiguous range of the query records (balanced by total bases);
+* results stay on the rank that produced them; only per-rank MEM counts (and, on request, the
+  variable-length MEM arrays) are gathered.  Concatenating in rank order restores input order because
+  the ranges are contiguous.
+
+Everything here is device-agnostic tensor plumbing; no compute.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world() -> tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(offsets: np.ndarray, world_size: int) -> np.ndarray:
+    """Split records 0..num-1 into world_size contiguous ranges with (almost) equal total bases.
+
+    offsets: uint64[num+1] record start offsets.  Returns int64[world_size+1] record boundaries."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    num = offsets.shape[0] - 1
+    total = int(offsets[-1] - offsets[0])
+    bounds = np.zeros(world_size + 1, dtype=np.int64)
+    bounds[-1] = num
+    for r in range(1, world_size):
+        target = int(offsets[0]) + (total * r) // world_size
+        # first record whose start is >= target
+        bounds[r] = int(np.searchsorted(offsets[:-1], np.uint64(target), side="left"))
+    bounds = np.maximum.accumulate(bounds)
+    bounds[-1] = num
+    return bounds
+
+
+def broadcast_arena(arena: torch.Tensor | None, device, src: int = 0) -> torch.Tensor:
+    """Replicate the index arena (uint8 tensor) from rank `src` to every rank: size first, then the bytes."""
+    rank, ws = world()
+    if ws == 1:
+        assert arena is not None
+        return arena
+    size = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == src:
+        size[0] = arena.numel()
+    dist.broadcast(size, src)
+    if rank != src:
+        arena = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(arena, src)
+    return arena
+
+
+def gather_counts(count: int, device) -> torch.Tensor:
+    """All ranks learn every rank's MEM count (int64[world])."""
+    rank, ws = world()
+    mine = torch.tensor([count], dtype=torch.int64, device=device)
+    if ws == 1:
+        return mine
+    out = torch.zeros(ws, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine) if device.type == "cuda" else dist.all_gather(list(out.split(1)), mine)
+    return out
+
+
+def gather_variable(rows: torch.Tensor, counts: torch.Tensor, dst: int = 0) -> torch.Tensor | None:
+    """Gather per-rank (count_r, k) int32 row blocks on rank `dst`, concatenated in rank order."""
+    rank, ws = world()
+    if ws == 1:
+        return rows
+    k = rows.shape[1]
+    if rank == dst:
+        parts = []
+        for r in range(ws):
+            if r == dst:
+                parts.append(rows)
+            else:
+                buf = torch.empty((int(counts[r].item()), k), dtype=rows.dtype, device=rows.device)
+                if buf.numel():
+                    dist.recv(buf, src=r)
+                parts.append(buf)
+        return torch.cat(parts, dim=0)
+    if rows.numel():
+        dist.send(rows.contiguous(), dst=dst)
+    return None

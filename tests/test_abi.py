@@ -1,0 +1,54 @@
+"""The C-ABI library loads and exports every symbol include/slamem_hip.h declares (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "slamem_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slamem_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from slamem_amd import capi
+    L = capi.lib()
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"libslamem_hip.so does not export {n}"
+    assert set(names) == set(capi.ABI_SYMBOLS)
+    assert L.slamem_abi_version() == 1
+    assert L.slamem_strerror(0) == b"ok"
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU every compute entry point must fail with an error code and a message."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from slamem_amd import capi, engine
+    L = capi.lib()
+    h = C.c_void_p()
+    rc = L.slamem_index_build(b"ACGTACGT", 8, 0, C.byref(h))
+    assert rc == capi.SLAMEM_ERR_NO_DEVICE and not h.value
+    assert b"no CPU" in L.slamem_last_error_message()
+    with pytest.raises(RuntimeError):
+        engine.Index.build(b"ACGT")
+
+
+def test_product_does_not_reference_the_oracle():
+    """oracle/ is test infrastructure: nothing under slamem_amd/ or include/ may import, include or link it."""
+    bad = []
+    for base in ("slamem_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                    s = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"(from|import)\s+oracle|oracle\.h|liboracle|pyoracle", s):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

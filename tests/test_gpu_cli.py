@@ -1,0 +1,41 @@
+"""The C front end (slaMEM-hip) on the golden fixtures: its *-mems.txt must be byte-identical to the file the
+real reference wrote for the same command line."""
+import os
+import subprocess
+
+import pytest
+
+import hostlib
+from golden_cases import CASES, MANIFEST, case_paths
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cli_output_file_is_byte_identical(case, tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    ref_fa, q_fa, exp_mems, _ = case_paths(case)
+    out = str(tmp_path / "out-mems.txt")
+    r = subprocess.run([exe] + MANIFEST[case]["opts"] + ["-o", out, ref_fa, q_fa], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    assert open(out, "rb").read() == open(exp_mems, "rb").read()
+    assert b"> Done!" in r.stdout and b"> Saving MEMs to <" in r.stdout
+
+
+def test_cli_default_output_name_and_batches(tmp_path):
+    import shutil
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    ref_fa, q_fa, exp_mems, _ = case_paths("acgt_l20_both")
+    shutil.copy(ref_fa, tmp_path / "myref.fa")
+    env = dict(os.environ, SLAMEM_BATCH_MB="1")
+    r = subprocess.run([exe, "-b", "-l", "20", str(tmp_path / "myref.fa"), q_fa], stdout=subprocess.PIPE, env=env)
+    assert r.returncode == 0
+    assert open(tmp_path / "myref-mems.txt", "rb").read() == open(exp_mems, "rb").read()

@@ -1,0 +1,115 @@
+"""The front end's host logic (slamem_amd/host/slamem_host.c) against the reference's observable behaviour."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import hostlib
+from golden_cases import CASES, MANIFEST, case_paths, opt_value
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_loader_reports_the_same_records_as_the_reference(case):
+    """Record names, sizes and accept/reject decisions equal the '# NN [name] (len bp) OK' lines the reference printed."""
+    opts = MANIFEST[case]["opts"]
+    ref_fa, q_fa, _, exp_stdout = case_paths(case)
+    acgt = 1 if "-n" in opts else 0
+    m = int(opt_value(opts, "-m", 0))
+    ref = hostlib.Loaded(ref_fa, 1, acgt, m, opt_value(opts, "-r"))
+    qs = hostlib.Loaded(q_fa, 0, acgt, m, None)
+    got = [(n[:50].decode(), s) for n, s in zip(ref.names + qs.names, ref.sizes + qs.sizes)]
+    exp = [(mm.group(1).rstrip(), int(mm.group(2))) for mm in
+           re.finditer(r"^# \d+ \[(.{50})\] \((\d+) bp\) OK$", open(exp_stdout, encoding="latin1").read(), re.M)]
+    assert [(a.rstrip(), b) for a, b in got] == exp
+    mm = re.search(r"^> (\d+) references? and (\d+) quer", open(exp_stdout, encoding="latin1").read(), re.M)
+    assert (ref.n, qs.n) == (int(mm.group(1)), int(mm.group(2)))
+    # merged text: records joined by single N separators, start positions as sequence.c:260-262
+    assert ref.merged_start[0] == 0
+    for k in range(1, ref.n):
+        assert ref.merged_start[k] == ref.merged_start[k - 1] + ref.sizes[k - 1] + 1
+        assert ref.chars[ref.merged_start[k] - 1:ref.merged_start[k]] == b"N"
+
+
+def test_normalisation_table(tmp_path):
+    p = tmp_path / "x.fa"
+    p.write_bytes(b">r one\r\nacgtNRYK*-12 xq\nACGT>r2\nnnAC\n>empty\n\n>r3\nTT")
+    a = hostlib.Loaded(str(p), 0, 0)
+    assert a.names == [b"r one", b"r2", b"r3"] and a.chars == b"ACGTNNNNNNACGT" + b"NNAC" + b"TT"
+    assert a.offsets == [0, 14, 18, 20]
+    b = hostlib.Loaded(str(p), 0, 1)  # -n drops every non-ACGT letter
+    assert b.chars == b"ACGTACGT" + b"AC" + b"TT" and b.sizes == [8, 2, 2]
+    c = hostlib.Loaded(str(p), 1, 0, 3)  # merged, -m 3: the 2-letter record is dropped, its separator stays
+    assert c.names == [b"r one", b"r2"] and c.chars == b"ACGTNNNNNNACGT" + b"N" + b"NNAC" + b"N"
+    d = hostlib.Loaded(str(p), 1, 0, 0, "r2")
+    assert d.names == [b"r2"] and d.chars == b"NNAC"
+    q = tmp_path / "bad.fa"
+    q.write_bytes(b"ACGT\n")
+    assert hostlib.Loaded(str(q), 0).n == 0  # must start with '>'
+    assert hostlib.Loaded(str(tmp_path / "missing.fa"), 0).n == 0
+
+
+def test_option_parsing_quirks():
+    o = hostlib.parse_options(["slaMEM", "-b", "-l", "10", "ref.fa", "q1.fa", "q2.fa"])
+    assert o["both_strands"] == 1 and o["min_mem_len"] == 10 and o["files"] == ["ref.fa", "q1.fa", "q2.fa"]
+    o = hostlib.parse_options(["slaMEM", "ref.fa", "q.fa"])
+    assert o["min_mem_len"] == 20 and o["both_strands"] == 0 and o["out_arg"] == -1 and o["no_ns"] == 0
+    o = hostlib.parse_options(["slaMEM", "-B", "-N", "-L", "7", "-O", "x.txt", "-M", "50", "ref.fa", "q.fa"])
+    assert (o["both_strands"], o["no_ns"], o["min_mem_len"], o["min_seq_len"], o["out_arg"]) == (1, 1, 7, 50, 6)
+    # any option starting with l/o/m/v swallows the next argument, so "-mem" eats the reference
+    o = hostlib.parse_options(["slaMEM", "-mem", "ref.fa", "q.fa"])
+    assert o["files"] == ["q.fa"] and o["match_type"] == 0
+    o = hostlib.parse_options(["slaMEM", "-mam", "x", "ref.fa", "q.fa"])
+    assert o["match_type"] == 1 and o["files"] == ["ref.fa", "q.fa"]
+    o = hostlib.parse_options(["slaMEM", "-r", "'chr", "1'", "ref.fa", "q.fa"])
+    assert o["ref_name"] == "chr 1" and o["files"] == ["ref.fa", "q.fa"]
+    o = hostlib.parse_options(["slaMEM", "-r", "chrB", "ref.fa", "q.fa"])
+    assert o["ref_name"] == "chrB" and o["files"] == ["ref.fa", "q.fa"]
+    assert hostlib.parse_options(["slaMEM", "ref.fa"])["usage"] == 1
+    # a one-letter option must be exactly two characters: "-bx" is not -b
+    assert hostlib.parse_options(["slaMEM", "-bx", "ref.fa", "q.fa"])["both_strands"] == 0
+
+
+def test_default_output_name():
+    L = hostlib.lib()
+
+    def f(a):
+        p = L.slh_append_to_basename(a.encode(), b"-mems.txt")
+        return C.string_at(p).decode()
+    assert f("ref.fa") == "ref-mems.txt"
+    assert f("./dir.v2/ref") == "./dir-mems.txt"  # last '.' of the whole path
+    assert f("noext") == "noext-mems.txt"
+
+
+def test_progress_dots_and_merged_lookup():
+    L = hostlib.lib()
+    for n in (0, 1, 9, 10, 11, 150, 4557606):
+        step = n // 10
+        counter, dots = 0, 0
+        for _ in range(min(n, 200000)):
+            if counter == step:
+                dots += 1
+                counter = 0
+            else:
+                counter += 1
+        if n <= 200000:
+            assert L.slh_progress_dots(n) == dots
+    starts = (C.c_uint32 * 3)(0, 901, 2002)
+    for pos, (eid, epos) in [(0, (0, 0)), (900, (0, 900)), (901, (1, 0)), (2001, (1, 1100)), (2002, (2, 0)), (2700, (2, 698))]:
+        p = C.c_uint32(pos)
+        assert (L.slh_seq_id_from_merged_pos(starts, 3, C.byref(p)), p.value) == (eid, epos)
+
+
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    """No CPU fallback: on a box without a GPU the front end must stop with the library's error, status 255."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", hostlib.HOST_DIR], stdout=subprocess.DEVNULL)
+    ref_fa, q_fa, _, _ = case_paths("acgt_l20_fwd")
+    r = subprocess.run([exe, "-o", str(tmp_path / "o.txt"), ref_fa, q_fa], stdout=subprocess.PIPE)
+    assert r.returncode == 255 and b"no CPU" in r.stdout
