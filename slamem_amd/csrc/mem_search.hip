@@ -127,15 +127,19 @@ __device__ __forceinline__ bool follow(const IndexView& ix, uint32_t c, uint32_t
 }
 
 // GetEnclosingLCPInterval: parent LCP-interval of [top,bot]; returns its depth, -1 at the root.
-__device__ __forceinline__ int parent(const IndexView& ix, uint32_t& top, uint32_t& bot) {
-    const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
-    uint4 rt = R[top], rb = R[bot + 1u];  // {lcp+1, psv, nsv, sa} of both boundary rows: one round trip
-    uint32_t a = rt.x, b = rb.x;
+__device__ __forceinline__ int parent_from(const uint4& rt, const uint4& rb, uint32_t& top, uint32_t& bot) {
+    uint32_t a = rt.x, b = rb.x;   // {lcp+1, psv, nsv, sa} of rows top and bot+1
     uint32_t d = a > b ? a : b;
     if (d == 0u) return -1;
     if (a == d) top = rt.y;        // closest row above with a smaller LCP   (lcparray.c:519)
     if (b == d) bot = rb.z - 1u;   // closest row below with a smaller LCP   (lcparray.c:520-521)
     return (int)(d - 1u);
+}
+
+__device__ __forceinline__ int parent(const IndexView& ix, uint32_t& top, uint32_t& bot) {
+    const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
+    uint4 rt = R[top], rb = R[bot + 1u];  // both boundary rows: one round trip
+    return parent_from(rt, rb, top, bot);
 }
 
 __device__ __forceinline__ uint32_t ascii_code_q(uint32_t ch) {
@@ -153,13 +157,21 @@ struct SearchArgs {
     uint32_t num_queries;
     uint32_t strands;          // 1 or 2
     uint32_t min_len;
+    int32_t spec_depth;        // v2: at or below this match length the parent records are fetched with the FM blocks
+    uint32_t chunk;            // v2: strand blocks owned by one wave
     uint32_t pad;
     uint64_t capacity;         // raw records that fit
     unsigned long long* total; // running number of MEMs
     RawKey* raw_key;
     slamem_mem* raw_mem;
     uint32_t* block_counts;    // [num_blocks + 1]
+    struct RawRow* inline_rows; // v3: kInlineMems slots per strand block, addressed directly (no atomics)
 };
+
+// v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
+struct RawRow { uint32_t row, pos, len; };
+constexpr uint32_t kInlineMems = 4;     // MEMs per strand block stored in place; more go to the overflow list
+constexpr uint32_t kChunkMax = 512;     // strand blocks per wave (bounds the LDS copy of the record offsets)
 
 struct QueryCursor {
     const uint64_t* words;
@@ -281,6 +293,230 @@ __global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
     A.block_counts[g] = k;
 }
 
+// ------------------------------------------------------------------------------------------
+// K8 v3: the same scan as a persistent, desynchronised state machine with ONE memory phase per trip.
+//
+// k_find_mems (v1) walks all 64 strands of a wave through position j in lockstep.  Per-lane rare events (a
+// failed extension, an emitted MEM, a record that starts) are per-wave COMMON events, and each one is a
+// dependent round trip that stalls the whole wave with a handful of loads in flight: measured 66 requests in
+// flight per CU, TA 75 % busy, 1100-cycle request latency -- latency-bound far below the random-line ceiling.
+//
+// Here every loop trip issues all of its loads up front from addresses known since the previous trip -- FM block
+// of `top`, FM block of `bot+1`, the two row records, the next query word -- waits once, and then every lane
+// advances its OWN strand by what arrived: a successful extension moves to the next position, a failed one
+// applies the parent step and retries in the next trip (state REC when the records were not fetched).
+//   * MEMs are stored without any returned atomic: the first kInlineMems of a strand go to a directly addressed
+//     slot (block*kInlineMems + k), the BWT row is kept and resolved to SA[row] by K9;
+//   * a finished lane takes the next strand of its wave's chunk (ballot + prefix count), record offsets come from
+//     an LDS copy made once per wave;
+//   * only genuinely rare work (intervals of several rows, ancestors that are still >= min_len deep, the letter N,
+//     more than kInlineMems MEMs in one strand) takes divergent dependent loads.
+// Results are identical to v1: same MEMs, same per-strand emission order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit3(const SearchArgs& A, uint32_t g, uint32_t& k, uint32_t row, uint32_t pos,
+                                      uint32_t len) {
+    if (k < kInlineMems) {
+        A.inline_rows[(uint64_t)g * kInlineMems + k] = RawRow{row, pos, len};
+    } else {
+        unsigned long long slot = atomicAdd(A.total, 1ull);
+        if (slot < A.capacity) {
+            A.raw_key[slot] = RawKey{g, k};
+            A.raw_mem[slot] = slamem_mem{row, pos, len};  // ref_pos holds the ROW until K9
+        }
+    }
+    k++;
+}
+
+#ifndef SLAMEM_V3_WAVES
+#define SLAMEM_V3_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
+    __shared__ uint64_t lds_off[4][kChunkMax + 8];
+    const IndexView& ix = A.ix;
+    const int L = (int)A.min_len;
+    const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
+    const uint64_t nblocks = (uint64_t)A.num_queries * A.strands;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t next = wave * A.chunk;  // wave-uniform: first unassigned strand block of this wave's chunk
+    if (next > nblocks) next = nblocks;
+    const uint64_t chunk_end = next + A.chunk < nblocks ? next + A.chunk : nblocks;
+    const uint64_t q_first = next / A.strands;
+    {   // record offsets of the chunk -> LDS (one coalesced read per wave instead of a round trip per record)
+        uint32_t cnt = next < chunk_end ? (uint32_t)((chunk_end - 1) / A.strands - q_first) + 2u : 0u;
+        for (uint32_t i = lane; i < cnt; i += 64u) lds_off[wv][i] = A.offsets[q_first + i];
+    }
+    __syncthreads();
+
+    bool active = false, st_rec = false, pend = false;
+    uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
+    int depth = 0, pub = -1;
+    QueryCursor qc;
+    qc.init(A.qwords, 0, 0, 0);
+    // FM blocks of `top` / `bot+1`, kept across trips: after a parent step the widened interval usually still
+    // starts and ends in the same 128-row blocks, so the retry fetches nothing
+    Blk kt, kb;
+    kt.a = kt.b = kt.c = kt.d = make_uint4(0, 0, 0, 0);
+    kb = kt;
+    uint32_t tag_t = 0xFFFFFFFFu, tag_b = 0xFFFFFFFFu;
+
+    for (;;) {
+        // ---- hand the next strands of the chunk to idle lanes -------------------------------------------
+        unsigned long long idle = __ballot(!active);
+        if (idle != 0ull && next < chunk_end) {
+            uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            uint64_t cand = next + rank;
+            if (!active && cand < chunk_end) {
+                g = (uint32_t)cand;
+                uint32_t qi = A.strands == 2 ? g >> 1 : g;
+                uint64_t o0 = lds_off[wv][qi - q_first], o1 = lds_off[wv][qi - q_first + 1];
+                qc.init(A.qwords, o0, (uint32_t)(o1 - o0), A.strands == 2 ? (g & 1u) : 0u);
+                j = qc.len;
+                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st_rec = false; k = 0;
+                if (j == 0) A.block_counts[g] = 0;  // empty record: nothing to scan
+                else active = true;
+            }
+            next += (uint64_t)__popcll(idle);
+        }
+        if (__ballot(active) == 0ull) {
+            if (next >= chunk_end) break;
+            continue;
+        }
+        if (!active) continue;
+
+        // ---- memory phase: every load of this trip, no use in between -----------------------------------------
+        uint4 rt = make_uint4(0, 0, 0, 0), rb = rt;
+        bool want_rec = st_rec;
+        uint32_t c = 0;
+        if (!st_rec) {
+            uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
+            if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
+            if (bb != bt && bb != tag_b) { kb = load_blk(ix.fm, bb); tag_b = bb; }
+            // while the match is short the extension is likely to fail (parent step); a pending position whose
+            // parent may still be >= min_len deep needs the records for the ancestor walk
+            want_rec = depth <= A.spec_depth || (pend && pub >= L);
+        }
+        if (want_rec) { rt = R[top]; rb = R[bot + 1u]; }
+        if (!st_rec) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
+
+        // ---- compute phase -----------------------------------------------------------------------------------
+        bool consumed = false;
+        if (st_rec) {  // a deep match ended at this letter: widen, retry next trip
+            st_rec = false;
+            int d = parent_from(rt, rb, top, bot);
+            if (d < 0) { depth = 0; pub = -1; consumed = true; }
+            else { depth = d; pub = d - 1; }
+        } else {
+            uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
+            uint32_t nt, nb1;
+            if (c >= 2u) {
+                nt = occ_lt(kt, c - 2u, top & (kFmRows - 1u));
+                // (never form a reference to "kb or kt": that forces both blocks into scratch memory)
+                nb1 = bb == bt ? occ_lt(kt, c - 2u, (bot + 1u) & (kFmRows - 1u))
+                               : occ_lt(kb, c - 2u, (bot + 1u) & (kFmRows - 1u));
+            } else if (ix.num_n == 0) {
+                nt = nb1 = 1u;
+            } else {
+                nt = 1u + n_rows_lt(ix, top);
+                nb1 = 1u + n_rows_lt(ix, bot + 1u);
+            }
+            // rows of the previous position wait for this letter (left-maximality), slamem.c:139-193
+            if (pend) {
+                pend = false;
+                uint32_t size = bot - top + 1u, same_left = nb1 - nt;
+                if (same_left < size) {
+                    if (size == 1u) emit3(A, g, k, top, j, (uint32_t)depth);
+                    else
+                        for (uint32_t row = top; row <= bot; row++)
+                            if (bwt_code(ix, row) != c) emit3(A, g, k, row, j, (uint32_t)depth);
+                }
+                if (pub >= L) {  // its records are in registers (want_rec)
+                    uint32_t t = top, b = bot, pt = top, pb = bot;
+                    int msz = parent_from(rt, rb, t, b);
+                    pub = msz;
+                    while (msz >= L) {
+                        for (uint32_t row = t; row != pt; row++)
+                            if (bwt_code(ix, row) != c) emit3(A, g, k, row, j, (uint32_t)msz);
+                        for (uint32_t row = b; row != pb; row--)
+                            if (bwt_code(ix, row) != c) emit3(A, g, k, row, j, (uint32_t)msz);
+                        pt = t;
+                        pb = b;
+                        msz = parent(ix, t, b);
+                    }
+                }
+            }
+            if (nt < nb1) {  // the extension occurs (slamem.c:121)
+                top = nt;
+                bot = nb1 - 1u;
+                pub++;  // parent depth of cW <= parent depth of W + 1
+                depth++;
+                consumed = true;
+            } else if (want_rec) {
+                int d = parent_from(rt, rb, top, bot);
+                if (d < 0) { depth = 0; pub = -1; consumed = true; }  // root, letter absent (slamem.c:125)
+                else { depth = d; pub = d - 1; }                      // widened; retry the letter next trip
+            } else {
+                st_rec = true;  // fetch the records in the next trip
+            }
+        }
+        if (consumed) {
+            j--;
+            pend = depth >= L && depth > 0;  // slamem.c:130
+            if (j == 0u) {                   // strand finished: nothing to the left (slamem.c:138)
+                if (pend) {
+                    pend = false;
+                    uint32_t size = bot - top + 1u;
+                    for (uint32_t row = top; row < top + size; row++) emit3(A, g, k, row, 0u, (uint32_t)depth);
+                    if (pub >= L) {
+                        uint32_t t = top, b = bot, pt = top, pb = bot;
+                        int msz = parent(ix, t, b);
+                        while (msz >= L) {
+                            for (uint32_t row = t; row != pt; row++) emit3(A, g, k, row, 0u, (uint32_t)msz);
+                            for (uint32_t row = b; row != pb; row--) emit3(A, g, k, row, 0u, (uint32_t)msz);
+                            pt = t;
+                            pb = b;
+                            msz = parent(ix, t, b);
+                        }
+                    }
+                }
+                A.block_counts[g] = k;
+                active = false;
+            }
+        }
+    }
+}
+
+// K9 for v3: inline slots and overflow records -> grouped output, BWT rows resolved to text positions here
+__global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__ inl, const uint32_t* __restrict__ counts,
+                                                      const uint64_t* __restrict__ block_offsets, uint64_t nblocks,
+                                                      const RowRec* __restrict__ rec, uint64_t capacity,
+                                                      slamem_mem* __restrict__ out) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nblocks) return;
+    uint32_t cnt = counts[g];
+    if (cnt > kInlineMems) cnt = kInlineMems;
+    uint64_t off = block_offsets[g];
+    for (uint32_t i = 0; i < cnt; i++) {
+        if (off + i >= capacity) return;
+        RawRow r = inl[g * kInlineMems + i];
+        out[off + i] = slamem_mem{rec[r.row].sa, r.pos, r.len};
+    }
+}
+
+__global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict__ key, const slamem_mem* __restrict__ raw,
+                                                        uint64_t count, const uint64_t* __restrict__ block_offsets,
+                                                        const RowRec* __restrict__ rec, uint64_t capacity,
+                                                        slamem_mem* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    RawKey kk = key[i];
+    slamem_mem m = raw[i];
+    uint64_t pos = block_offsets[kk.block] + kk.k;
+    if (pos >= capacity) return;
+    m.ref_pos = rec[m.ref_pos].sa;
+    out[pos] = m;
+}
+
 // K9: raw list -> grouped output
 __global__ void __launch_bounds__(256) k_scatter_mems(const RawKey* __restrict__ key, const slamem_mem* __restrict__ raw,
                                                       uint64_t count, const uint64_t* __restrict__ block_offsets,
@@ -341,7 +577,7 @@ inline unsigned grid_for(uint64_t items, unsigned block = 256) { return (unsigne
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    uint64_t off_total, off_counts, off_rawkey, off_rawmem, off_scan, scan_bytes, bytes;
+    uint64_t off_total, off_counts, off_rawkey, off_rawmem, off_inline, off_scan, scan_bytes, bytes;
 };
 
 WorkspaceLayout layout_workspace(uint64_t num_blocks, uint64_t capacity) {
@@ -351,6 +587,7 @@ WorkspaceLayout layout_workspace(uint64_t num_blocks, uint64_t capacity) {
     w.off_counts = off;  off = align_up(off + (num_blocks + 1) * 4, 256);
     w.off_rawkey = off;  off = align_up(off + capacity * sizeof(RawKey), 256);
     w.off_rawmem = off;  off = align_up(off + capacity * sizeof(slamem_mem), 256);
+    w.off_inline = off;  off = align_up(off + num_blocks * kInlineMems * sizeof(RawRow), 256);
     size_t need = 0;
     (void)scan_sum_exclusive_u32_u64(nullptr, need, nullptr, nullptr, num_blocks, 0);
     w.scan_bytes = need;
@@ -421,8 +658,28 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         A.raw_key = reinterpret_cast<RawKey*>(ws + w.off_rawkey);
         A.raw_mem = reinterpret_cast<slamem_mem*>(ws + w.off_rawmem);
         A.block_counts = d_counts;
+        A.inline_rows = reinterpret_cast<RawRow*>(ws + w.off_inline);
+        {   // random text of n characters stops matching at about log4(n) characters
+            int lg = 0;
+            for (uint64_t v = idx->hdr.n; v > 1; v >>= 2) lg++;
+            A.spec_depth = -1;  // measured: fetching the records speculatively costs more lines than the trips it saves
+            (void)lg;
+            const char* e1 = getenv("SLAMEM_SPEC_DEPTH");
+            if (e1) A.spec_depth = atoi(e1);
+            A.chunk = 128;
+            const char* e2 = getenv("SLAMEM_CHUNK");
+            if (e2 && atoi(e2) > 0) A.chunk = (uint32_t)atoi(e2);
+            if (A.chunk > kChunkMax) A.chunk = kChunkMax;
+            A.chunk &= ~1u;  // both strands of a record stay in one chunk
+            if (A.chunk < 2) A.chunk = 2;
+        }
+        static const int kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
         (void)hipEventRecord(e0, stream);
-        if (num_blocks) {
+        if (num_blocks && kernel_version == 3) {
+            uint64_t waves = (num_blocks + A.chunk - 1) / A.chunk;
+            hipLaunchKernelGGL(k_find_mems_v3, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
+            if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_find_mems_v3", __FILE__, __LINE__); break; }
+        } else if (num_blocks) {
             hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
             if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_find_mems", __FILE__, __LINE__); break; }
         }
@@ -431,16 +688,28 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         if ((e = scan_sum_exclusive_u32_u64(ws + w.off_scan, need, d_counts, block_offsets_dev, num_blocks, stream)) != hipSuccess) {
             rc = hip_fail(e, "scan", __FILE__, __LINE__); break;
         }
-        unsigned long long total = 0;
-        if ((e = hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) { rc = hip_fail(e, "memcpy", __FILE__, __LINE__); break; }
+        unsigned long long listed = 0, total = 0;  // listed: records in the atomic list; total: all MEMs
+        if ((e = hipMemcpyAsync(&listed, d_total, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) { rc = hip_fail(e, "memcpy", __FILE__, __LINE__); break; }
+        if ((e = hipMemcpyAsync(&total, block_offsets_dev + num_blocks, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) { rc = hip_fail(e, "memcpy", __FILE__, __LINE__); break; }
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) { rc = hip_fail(e, "k_find_mems (sync)", __FILE__, __LINE__); break; }
         *total_out = total;
-        if (total > mems_capacity) {
+        if (total > mems_capacity || listed > mems_capacity) {
             set_error("slamem_find_mems_device: %llu MEMs found, output capacity is %llu", total, (unsigned long long)mems_capacity);
             rc = SLAMEM_ERR_CAPACITY;
-        } else if (total) {
-            hipLaunchKernelGGL(k_scatter_mems, dim3(grid_for(total)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                               (uint64_t)total, block_offsets_dev, mems_dev);
+        } else if (kernel_version == 3) {
+            if (total) {
+                hipLaunchKernelGGL(k_place_inline, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A.inline_rows, d_counts,
+                                   block_offsets_dev, num_blocks, idx->view.rec, mems_capacity, mems_dev);
+                if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_place_inline", __FILE__, __LINE__); break; }
+            }
+            if (listed) {
+                hipLaunchKernelGGL(k_place_overflow, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
+                                   (uint64_t)listed, block_offsets_dev, idx->view.rec, mems_capacity, mems_dev);
+                if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_place_overflow", __FILE__, __LINE__); break; }
+            }
+        } else if (listed) {
+            hipLaunchKernelGGL(k_scatter_mems, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
+                               (uint64_t)listed, block_offsets_dev, mems_dev);
             if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_scatter_mems", __FILE__, __LINE__); break; }
         }
         (void)hipEventRecord(e2, stream);
