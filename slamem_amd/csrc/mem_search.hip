@@ -313,18 +313,58 @@ __global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
 //     more than kInlineMems MEMs in one strand) takes divergent dependent loads.
 // Results are identical to v1: same MEMs, same per-strand emission order.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void emit3(const SearchArgs& A, uint32_t g, uint32_t& k, uint32_t row, uint32_t pos,
-                                      uint32_t len) {
-    if (k < kInlineMems) {
-        A.inline_rows[(uint64_t)g * kInlineMems + k] = RawRow{row, pos, len};
+// store MEM number kk of strand block g (kk is assigned by the caller)
+__device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t row, uint32_t pos,
+                                         uint32_t len) {
+    if (kk < kInlineMems) {
+        A.inline_rows[(uint64_t)g * kInlineMems + kk] = RawRow{row, pos, len};
     } else {
         unsigned long long slot = atomicAdd(A.total, 1ull);
         if (slot < A.capacity) {
-            A.raw_key[slot] = RawKey{g, k};
+            A.raw_key[slot] = RawKey{g, kk};
             A.raw_mem[slot] = slamem_mem{row, pos, len};  // ref_pos holds the ROW until K9
         }
     }
-    k++;
+}
+
+// One enumeration job of ONE strand, executed by the WHOLE wave (every argument is wave-uniform): all rows of
+// [t,b] at depth `msz` (only if `level0`), then of every ancestor interval still >= L deep, the new rows above
+// ascending and the new rows below descending (slamem.c:139-193).  The 64 lanes test 64 rows at a time for
+// left-maximality (BWT letter != left); __ballot + prefix popcount give each surviving row its MEM number, so the
+// strand's emission order is exactly the reference's.  This is what makes repeats (intervals of thousands of
+// rows) cost rows/64 steps instead of rows.  Returns the strand's new MEM count; *first_parent = depth of the
+// parent of [t,b] (the exact value of `pub`).
+__device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t lane, uint32_t g, uint32_t k,
+                                                   uint32_t t, uint32_t b, int msz, bool level0, bool walk_up,
+                                                   uint32_t pos, uint32_t left, int L, int* first_parent) {
+    const IndexView& ix = A.ix;
+    uint32_t pt = level0 ? b + 1u : t, pb = b;  // rows already reported: [pt, pb]
+    bool first = true;
+    *first_parent = -2;
+    for (;;) {
+        for (uint32_t base = t; base < pt; base += 64u) {  // new rows above, ascending (slamem.c:140)
+            uint32_t row = base + lane;
+            bool ok = row < pt && bwt_code(ix, row) != left;
+            unsigned long long m = __ballot(ok);
+            if (ok) emit3_at(A, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), row, pos, (uint32_t)msz);
+            k += (uint32_t)__popcll(m);
+        }
+        for (uint32_t done = 0; done < b - pb; done += 64u) {  // new rows below, bottom-up (slamem.c:165)
+            uint32_t off = done + lane;
+            uint32_t row = b - off;
+            bool ok = off < b - pb && bwt_code(ix, row) != left;
+            unsigned long long m = __ballot(ok);
+            if (ok) emit3_at(A, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), row, pos, (uint32_t)msz);
+            k += (uint32_t)__popcll(m);
+        }
+        if (!walk_up) break;
+        pt = t;
+        pb = b;
+        msz = parent(ix, t, b);  // same address in every lane: one line, broadcast (slamem.c:192)
+        if (first) { *first_parent = msz; first = false; }
+        if (msz < L) break;
+    }
+    return k;
 }
 
 #ifndef SLAMEM_V3_WAVES
@@ -348,17 +388,16 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     }
     __syncthreads();
 
-    bool active = false, st_rec = false, pend = false;
+    bool active = false, st_rec = false, st_flush = false, pend = false;
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
     int depth = 0, pub = -1;
     QueryCursor qc;
     qc.init(A.qwords, 0, 0, 0);
-    // FM blocks of `top` / `bot+1`, kept across trips: after a parent step the widened interval usually still
-    // starts and ends in the same 128-row blocks, so the retry fetches nothing
-    Blk kt, kb;
+    // FM block of `top`, kept across trips: after a parent step the widened interval usually still lies in the
+    // same 128-row block, so the retry fetches nothing
+    Blk kt;
     kt.a = kt.b = kt.c = kt.d = make_uint4(0, 0, 0, 0);
-    kb = kt;
-    uint32_t tag_t = 0xFFFFFFFFu, tag_b = 0xFFFFFFFFu;
+    uint32_t tag_t = 0xFFFFFFFFu;
 
     for (;;) {
         // ---- hand the next strands of the chunk to idle lanes -------------------------------------------
@@ -372,7 +411,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 uint64_t o0 = lds_off[wv][qi - q_first], o1 = lds_off[wv][qi - q_first + 1];
                 qc.init(A.qwords, o0, (uint32_t)(o1 - o0), A.strands == 2 ? (g & 1u) : 0u);
                 j = qc.len;
-                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st_rec = false; k = 0;
+                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st_rec = false; st_flush = false; k = 0;
                 if (j == 0) A.block_counts[g] = 0;  // empty record: nothing to scan
                 else active = true;
             }
@@ -382,106 +421,122 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             if (next >= chunk_end) break;
             continue;
         }
-        if (!active) continue;
 
-        // ---- memory phase: every load of this trip, no use in between -----------------------------------------
-        uint4 rt = make_uint4(0, 0, 0, 0), rb = rt;
-        bool want_rec = st_rec;
-        uint32_t c = 0;
-        if (!st_rec) {
-            uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
-            if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
-            if (bb != bt && bb != tag_b) { kb = load_blk(ix.fm, bb); tag_b = bb; }
-            // while the match is short the extension is likely to fail (parent step); a pending position whose
-            // parent may still be >= min_len deep needs the records for the ancestor walk
-            want_rec = depth <= A.spec_depth || (pend && pub >= L);
-        }
-        if (want_rec) { rt = R[top]; rb = R[bot + 1u]; }
-        if (!st_rec) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
+        // enumeration job of this trip (rare): rows that the lane does not emit itself
+        bool e_on = false, e_level0 = false, e_up = false;
+        uint32_t e_pos = 0, e_left = 0;
+        bool consumed = false, finished = false;
 
-        // ---- compute phase -----------------------------------------------------------------------------------
-        bool consumed = false;
-        if (st_rec) {  // a deep match ended at this letter: widen, retry next trip
-            st_rec = false;
-            int d = parent_from(rt, rb, top, bot);
-            if (d < 0) { depth = 0; pub = -1; consumed = true; }
-            else { depth = d; pub = d - 1; }
-        } else {
-            uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
-            uint32_t nt, nb1;
-            if (c >= 2u) {
-                nt = occ_lt(kt, c - 2u, top & (kFmRows - 1u));
-                // (never form a reference to "kb or kt": that forces both blocks into scratch memory)
-                nb1 = bb == bt ? occ_lt(kt, c - 2u, (bot + 1u) & (kFmRows - 1u))
-                               : occ_lt(kb, c - 2u, (bot + 1u) & (kFmRows - 1u));
-            } else if (ix.num_n == 0) {
-                nt = nb1 = 1u;
-            } else {
-                nt = 1u + n_rows_lt(ix, top);
-                nb1 = 1u + n_rows_lt(ix, bot + 1u);
+        if (active) {
+            // ---- memory phase: every load of this trip, no use in between -------------------------------------
+            uint4 rt = make_uint4(0, 0, 0, 0), rb = rt;
+            const bool rec_only = st_rec || st_flush;
+            bool want_rec = rec_only;
+            uint32_t c = 0;
+            Blk kb;  // block of bot+1 when it differs from top's (wide intervals only: not kept across trips)
+            kb.a = kb.b = kb.c = kb.d = make_uint4(0, 0, 0, 0);
+            if (!rec_only) {
+                uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
+                if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
+                if (bb != bt) kb = load_blk(ix.fm, bb);
+                // records together with the blocks: when a pending position's parent may still be >= min_len deep
+                // (its depth is needed now), or speculatively while the match is short (off by default)
+                want_rec = depth <= A.spec_depth || (pend && pub >= L);
             }
-            // rows of the previous position wait for this letter (left-maximality), slamem.c:139-193
-            if (pend) {
+            if (want_rec) { rt = R[top]; rb = R[bot + 1u]; }
+            if (!rec_only) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
+
+            // ---- compute phase -------------------------------------------------------------------------------
+            if (st_flush) {  // the strand ended on a match whose parent may qualify too: its depth has arrived
+                st_flush = false;
+                uint32_t t2 = top, b2 = bot;
+                pub = parent_from(rt, rb, t2, b2);
+                if (pub < L && top == bot) { emit3_at(A, g, k, top, 0u, (uint32_t)depth); k++; }
+                else { e_on = true; e_level0 = true; e_up = pub >= L; e_pos = 0u; e_left = 0xFFu; }
                 pend = false;
-                uint32_t size = bot - top + 1u, same_left = nb1 - nt;
-                if (same_left < size) {
-                    if (size == 1u) emit3(A, g, k, top, j, (uint32_t)depth);
-                    else
-                        for (uint32_t row = top; row <= bot; row++)
-                            if (bwt_code(ix, row) != c) emit3(A, g, k, row, j, (uint32_t)depth);
+                finished = true;
+            } else if (st_rec) {  // a deep match ended at this letter: widen, retry next trip
+                st_rec = false;
+                int d = parent_from(rt, rb, top, bot);
+                if (d < 0) { depth = 0; pub = -1; consumed = true; }
+                else { depth = d; pub = d - 1; }
+            } else {
+                uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
+                uint32_t nt, nb1;
+                if (c >= 2u) {
+                    nt = occ_lt(kt, c - 2u, top & (kFmRows - 1u));
+                    // (never form a reference to "kb or kt": that forces both blocks into scratch memory)
+                    nb1 = bb == bt ? occ_lt(kt, c - 2u, (bot + 1u) & (kFmRows - 1u))
+                                   : occ_lt(kb, c - 2u, (bot + 1u) & (kFmRows - 1u));
+                } else if (ix.num_n == 0) {
+                    nt = nb1 = 1u;
+                } else {
+                    nt = 1u + n_rows_lt(ix, top);
+                    nb1 = 1u + n_rows_lt(ix, bot + 1u);
                 }
-                if (pub >= L) {  // its records are in registers (want_rec)
-                    uint32_t t = top, b = bot, pt = top, pb = bot;
-                    int msz = parent_from(rt, rb, t, b);
-                    pub = msz;
-                    while (msz >= L) {
-                        for (uint32_t row = t; row != pt; row++)
-                            if (bwt_code(ix, row) != c) emit3(A, g, k, row, j, (uint32_t)msz);
-                        for (uint32_t row = b; row != pb; row--)
-                            if (bwt_code(ix, row) != c) emit3(A, g, k, row, j, (uint32_t)msz);
-                        pt = t;
-                        pb = b;
-                        msz = parent(ix, t, b);
+                // rows of the previous position wait for this letter (left-maximality), slamem.c:139-193
+                if (pend) {
+                    uint32_t size = bot - top + 1u, same_left = nb1 - nt;
+                    bool lvl0 = same_left < size, anc = false;
+                    if (pub >= L) {  // read the exact parent depth from the records fetched with this trip
+                        uint32_t t2 = top, b2 = bot;
+                        pub = parent_from(rt, rb, t2, b2);
+                        anc = pub >= L;
+                    }
+                    if (!anc && (!lvl0 || size == 1u)) {  // the common case: at most this one row, no ancestors
+                        if (lvl0) { emit3_at(A, g, k, top, j, (uint32_t)depth); k++; }
+                        pend = false;
+                    } else {  // several rows and/or ancestors: the wave does it together, below; this trip only emits
+                        e_on = true; e_level0 = lvl0; e_up = anc; e_pos = j; e_left = c;
+                    }
+                }
+                if (!e_on) {
+                    if (nt < nb1) {  // the extension occurs (slamem.c:121)
+                        top = nt;
+                        bot = nb1 - 1u;
+                        pub++;  // parent depth of cW <= parent depth of W + 1
+                        depth++;
+                        consumed = true;
+                    } else if (want_rec) {
+                        int d = parent_from(rt, rb, top, bot);
+                        if (d < 0) { depth = 0; pub = -1; consumed = true; }  // root, letter absent (slamem.c:125)
+                        else { depth = d; pub = d - 1; }                      // widened; retry the letter next trip
+                    } else {
+                        st_rec = true;  // fetch the records in the next trip
                     }
                 }
             }
-            if (nt < nb1) {  // the extension occurs (slamem.c:121)
-                top = nt;
-                bot = nb1 - 1u;
-                pub++;  // parent depth of cW <= parent depth of W + 1
-                depth++;
-                consumed = true;
-            } else if (want_rec) {
-                int d = parent_from(rt, rb, top, bot);
-                if (d < 0) { depth = 0; pub = -1; consumed = true; }  // root, letter absent (slamem.c:125)
-                else { depth = d; pub = d - 1; }                      // widened; retry the letter next trip
-            } else {
-                st_rec = true;  // fetch the records in the next trip
+            if (consumed) {
+                j--;
+                pend = depth >= L && depth > 0;  // slamem.c:130
+                if (j == 0u) {  // strand finished; rows still pending have nothing to their left (slamem.c:138)
+                    finished = true;
+                    if (pend && pub >= L) { st_flush = true; finished = false; }  // parent depth needed: next trip
+                    else if (pend && top == bot) { emit3_at(A, g, k, top, 0u, (uint32_t)depth); k++; pend = false; }
+                    else if (pend) { e_on = true; e_level0 = true; e_up = false; e_pos = 0u; e_left = 0xFFu; }
+                }
             }
         }
-        if (consumed) {
-            j--;
-            pend = depth >= L && depth > 0;  // slamem.c:130
-            if (j == 0u) {                   // strand finished: nothing to the left (slamem.c:138)
-                if (pend) {
-                    pend = false;
-                    uint32_t size = bot - top + 1u;
-                    for (uint32_t row = top; row < top + size; row++) emit3(A, g, k, row, 0u, (uint32_t)depth);
-                    if (pub >= L) {
-                        uint32_t t = top, b = bot, pt = top, pb = bot;
-                        int msz = parent(ix, t, b);
-                        while (msz >= L) {
-                            for (uint32_t row = t; row != pt; row++) emit3(A, g, k, row, 0u, (uint32_t)msz);
-                            for (uint32_t row = b; row != pb; row--) emit3(A, g, k, row, 0u, (uint32_t)msz);
-                            pt = t;
-                            pb = b;
-                            msz = parent(ix, t, b);
-                        }
-                    }
-                }
-                A.block_counts[g] = k;
-                active = false;
+
+        // ---- enumeration jobs, one strand at a time, all 64 lanes on its rows (every lane reaches this point) ----
+        for (unsigned long long em = __ballot(e_on); em != 0ull; em &= em - 1ull) {
+            int owner = __ffsll((long long)em) - 1;
+            uint32_t o_g = __shfl(g, owner), o_k = __shfl(k, owner), o_t = __shfl(top, owner), o_b = __shfl(bot, owner);
+            int o_depth = __shfl(depth, owner);
+            uint32_t o_pos = __shfl(e_pos, owner), o_left = __shfl(e_left, owner);
+            bool o_l0 = __shfl((int)e_level0, owner) != 0, o_up = __shfl((int)e_up, owner) != 0;
+            int fp;
+            uint32_t nk = wave_enumerate(A, lane, o_g, o_k, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp);
+            if ((int)lane == owner) {
+                k = nk;
+                if (o_up) pub = fp;
+                pend = false;  // the next trip extends from the same interval with the same letter
             }
+        }
+
+        if (active && finished) {
+            A.block_counts[g] = k;
+            active = false;
         }
     }
 }
