@@ -2,6 +2,7 @@
 // radix-sort entry point.  See prims.h.
 #include "prims.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -13,11 +14,32 @@ struct U4Plus {
     }
 };
 
+hipError_t radix_sort_pairs_u64_u32(void* tmp, size_t& tmp_bytes, uint64_t* keys_in, uint64_t* keys_out,
+                                    uint32_t* vals_in, uint32_t* vals_out, size_t n, int begin_bit, int end_bit,
+                                    hipStream_t stream);  // radix_sort.hip (hand-written)
+
+// SLAMEM_SORT=rocprim selects rocPRIM's onesweep sort (kept for A/B timing and as a cross-check of radix_sort.hip)
+static bool use_rocprim_sort() {
+    static const bool v = [] { const char* e = getenv("SLAMEM_SORT"); return e && strcmp(e, "rocprim") == 0; }();
+    return v;
+}
+
 hipError_t sort_pairs_u64_u32(void* tmp, size_t& tmp_bytes, uint64_t* keys_in, uint64_t* keys_out,
                               uint32_t* vals_in, uint32_t* vals_out, size_t n, int begin_bit, int end_bit,
                               hipStream_t stream) {
-    return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n,
-                                     (unsigned)begin_bit, (unsigned)end_bit, stream);
+    if (tmp == nullptr) {  // size query: enough for either implementation
+        size_t a = 0, b = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, a, keys_in, keys_out, vals_in, vals_out, n,
+                                                 (unsigned)begin_bit, (unsigned)end_bit, stream);
+        if (e != hipSuccess) return e;
+        e = radix_sort_pairs_u64_u32(nullptr, b, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, stream);
+        tmp_bytes = a > b ? a : b;
+        return e;
+    }
+    if (use_rocprim_sort())
+        return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n,
+                                         (unsigned)begin_bit, (unsigned)end_bit, stream);
+    return radix_sort_pairs_u64_u32(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, stream);
 }
 
 hipError_t scan_max_inclusive_u32(void* tmp, size_t& tmp_bytes, const uint32_t* in, uint32_t* out, size_t n,
