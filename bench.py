@@ -47,6 +47,8 @@ def parse_args():
     p.add_argument("--forward-only", action="store_true")
     p.add_argument("--cpu-sample-reads", type=int, default=250_000)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
+                                                     "N>1 path on a box with fewer GPUs than ranks)")
     return p.parse_args()
 
 
@@ -74,11 +76,16 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank if a.backend == "nccl" else local_rank % ndev)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")  # where collective buffers live
 
     from slamem_amd import engine, shard
 
@@ -101,11 +108,11 @@ def main():
         build_s = time.time() - t0
         build_t = {k: v for k, v in engine.timings().items() if k.startswith("build_")}
     if world > 1:
-        arena = index.export_arena() if rank == 0 else None
+        arena = index.export_arena().to(cdev) if rank == 0 else None
         torch.cuda.synchronize(dev)
         dist.barrier()
         t0 = time.time()
-        arena = shard.broadcast_arena(arena, dev, src=0)  # ONE RCCL broadcast of the whole index over xGMI
+        arena = shard.broadcast_arena(arena, cdev, src=0).to(dev)  # ONE RCCL broadcast of the whole index over xGMI
         torch.cuda.synchronize(dev)
         bcast_s = time.time() - t0
         if rank != 0:
@@ -114,12 +121,12 @@ def main():
 
     # ---- the timed hot path ------------------------------------------------------------------------------------
     matcher = index.matcher(M, both, mems_capacity=4 * M + 1024)
-    counts_all = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts_all = torch.zeros(world, dtype=torch.int64, device=cdev)
 
     def step():
         nonlocal counts_all
         total = matcher.run(reads, offsets, a.min_len)
-        counts_all = shard.gather_counts(total, dev)  # final gather of per-rank MEM counts (tiny; no data-path collective)
+        counts_all = shard.gather_counts(total, cdev)  # final gather of per-rank MEM counts (tiny; no data-path collective)
         return total
 
     for _ in range(a.warmup):
@@ -136,8 +143,8 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     tm = engine.timings()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    kms = torch.tensor([tm["search_kernel_ms_sum"] / max(1, tm["search_launches"])], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    kms = torch.tensor([tm["search_kernel_ms_sum"] / max(1, tm["search_launches"])], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)

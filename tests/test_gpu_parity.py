@@ -142,3 +142,39 @@ def test_arena_export_attach_save_load(eng, tmp_path):
     assert np.array_equal(a, ref) and np.array_equal(aoff, refoff)
     with pytest.raises(Exception):
         eng.Index.attach(torch.zeros(8192, dtype=torch.uint8, device="cuda:0"))
+
+
+def test_config2_known_answer_full_size(eng):
+    """BASELINE.json configs[1] at full size: 100 Mbp reference, 1 M x 150 bp reads, forward, -l 20.
+    Known answers recorded from the REAL reference in SURVEY.md Appendix C.3 (2,412,288 MEMs, sum of lengths
+    133,301,375, sha256 prefix 9d583ab9312e1698 of the numerically sorted 'ref<TAB>query<TAB>len' lines)."""
+    import hashlib
+    import torch
+    n, nreads, L = 100_000_000, 1_000_000, 150
+    ref = eng.synth_reference(n, 42, "cuda:0")
+    reads = eng.synth_reads(ref, 0, nreads, L, 0.02, 42, 0)
+    offsets = torch.arange(nreads + 1, dtype=torch.int64, device="cuda:0") * L
+    idx = eng.Index.build(ref, "cuda:0")
+    m = idx.matcher(nreads, False, 4 * nreads)
+    total = m.run(reads, offsets, 20)
+    assert total == 2_412_288
+    mems = m.mems[:total].cpu().numpy().view(np.uint32).astype(np.int64)
+    assert int(mems[:, 2].sum()) == 133_301_375
+    assert int(mems[:, 2].max()) == 150
+    # size-independent properties: every MEM is a real match inside the read, maximal on both sides
+    ref_h = ref.cpu().numpy()
+    reads_h = reads[: nreads * L].cpu().numpy().reshape(nreads, L)
+    boff = m.block_offsets[: nreads + 1].cpu().numpy()
+    rid = np.repeat(np.arange(nreads), np.diff(boff))
+    r, q, ln = mems[:, 0], mems[:, 1], mems[:, 2]
+    assert (q + ln <= L).all() and (r + ln <= n).all() and (ln >= 20).all()
+    sel = np.random.default_rng(0).choice(total, size=20000, replace=False)
+    for i in sel:
+        a, b, c, d = int(r[i]), int(q[i]), int(ln[i]), int(rid[i])
+        assert (ref_h[a:a + c] == reads_h[d, b:b + c]).all()
+        assert a == 0 or b == 0 or ref_h[a - 1] != reads_h[d, b - 1]
+        assert a + c == n or b + c == L or ref_h[a + c] != reads_h[d, b + c]
+    order = np.lexsort((ln, q, r))
+    lines = b"".join(b"%d\t%d\t%d\n" % (r[i] + 1, q[i] + 1, ln[i]) for i in order)
+    assert hashlib.sha256(lines).hexdigest().startswith("9d583ab9312e1698")
+    idx.close()
