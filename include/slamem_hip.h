@@ -123,6 +123,25 @@ enum {
 };
 int slamem_index_download(const slamem_index *idx, int which, void *host_dst, uint64_t count);
 
+/* What the reference's sampled structure (SSILCP, lcparray.c:46-57) WOULD hold for this text, computed on the
+ * device from the per-row records: the quantities BuildSampledLCPArray prints (lcparray.c:709-711, 999-1000).
+ *   sample        = BWT row i with LCP[i] != LCP[i+1]                        (lcparray.c:677-678)
+ *   oversized lcp = sample whose value is -1 or >= 255                       (lcparray.c:688-697)
+ *   link          = top corner (LCP[i+1] > LCP[i]): PSV[i];  bottom corner: NSV[i+1]-1   (lcparray.c:827-912)
+ *   oversized link= |distance| >= 128, plus the first and the last sample    (lcparray.c:755, 840, 890, 966-970)
+ * Used by the front end to print the reference's statistics lines and by the tests as a check of rows a9-a11. */
+typedef struct {
+    uint64_t num_samples;
+    uint64_t num_oversized_lcp;
+    int64_t sum_lcp;            /* sum over rows 1..n+1 (the last one counts -1), lcparray.c:668 */
+    uint32_t max_lcp;
+    uint32_t pad;
+    uint64_t num_oversized_links;
+    uint64_t sum_link_distance;
+    uint64_t max_link_distance;
+} slamem_sslcp_stats;
+int slamem_index_sampled_lcp_stats(const slamem_index *idx, slamem_sslcp_stats *out);
+
 /* ---- fine-grained operations, batched (one lane per element) ------------ */
 /* FMI_FollowLetter (bwtindex.h:8 / bwtindex.c:359): in-place on top/bottom; size_out[i] = new
  * interval size or 0 (then top/bottom are left unchanged). */

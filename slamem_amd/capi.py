@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "slamem_get_timings", "slamem_reset_timings",
     "slamem_index_build", "slamem_index_build_device", "slamem_index_free", "slamem_index_get_info",
     "slamem_index_arena", "slamem_index_export", "slamem_index_attach", "slamem_index_save", "slamem_index_load",
-    "slamem_index_download",
+    "slamem_index_download", "slamem_index_sampled_lcp_stats",
     "slamem_follow_letter_batch", "slamem_enclosing_interval_batch", "slamem_position_in_text_batch",
     "slamem_char_at_bwt_pos_batch",
     "slamem_find_mems_workspace_bytes", "slamem_find_mems_device", "slamem_find_mems_host", "slamem_host_free",
@@ -46,6 +46,12 @@ class IndexInfo(C.Structure):
     _fields_ = [("text_length", C.c_uint32), ("bwt_size", C.c_uint32), ("num_n_rows", C.c_uint32),
                 ("dollar_row", C.c_uint32), ("max_lcp", C.c_uint32), ("sort_rounds", C.c_uint32),
                 ("arena_bytes", C.c_uint64), ("device", C.c_int32), ("owns_arena", C.c_int32)]
+
+
+class SslcpStats(C.Structure):
+    _fields_ = [("num_samples", C.c_uint64), ("num_oversized_lcp", C.c_uint64), ("sum_lcp", C.c_int64),
+                ("max_lcp", C.c_uint32), ("pad", C.c_uint32), ("num_oversized_links", C.c_uint64),
+                ("sum_link_distance", C.c_uint64), ("max_link_distance", C.c_uint64)]
 
 
 class Timings(C.Structure):
@@ -80,6 +86,7 @@ def _declare(L):
     L.slamem_index_save.argtypes = [vp, C.c_char_p]
     L.slamem_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.slamem_index_download.argtypes = [vp, i32, vp, u64]
+    L.slamem_index_sampled_lcp_stats.argtypes = [vp, C.POINTER(SslcpStats)]
     L.slamem_follow_letter_batch.argtypes = [vp, vp, vp, vp, vp, u64, vp]
     L.slamem_enclosing_interval_batch.argtypes = [vp, vp, vp, vp, u64, vp]
     L.slamem_position_in_text_batch.argtypes = [vp, vp, vp, u64, vp]

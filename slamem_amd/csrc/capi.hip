@@ -30,6 +30,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 Timings& thread_timings() { return g_tm; }
 
 int download_array(const slamem_index* idx, int which, void* host_dst, uint64_t count);
+int sampled_lcp_stats(const slamem_index* idx, slamem_sslcp_stats* out);
 int follow_letter_batch(const slamem_index*, const char*, uint32_t*, uint32_t*, uint32_t*, uint64_t, hipStream_t);
 int enclosing_interval_batch(const slamem_index*, uint32_t*, uint32_t*, int32_t*, uint64_t, hipStream_t);
 int position_in_text_batch(const slamem_index*, const uint32_t*, uint32_t*, uint64_t, hipStream_t);
@@ -249,6 +250,11 @@ int slamem_index_load(const char* path, int device, slamem_index** out) {
 int slamem_index_download(const slamem_index* idx, int which, void* host_dst, uint64_t count) {
     if (!idx || !host_dst) return SLAMEM_ERR_ARG;
     return download_array(idx, which, host_dst, count);
+}
+
+int slamem_index_sampled_lcp_stats(const slamem_index* idx, slamem_sslcp_stats* out) {
+    if (!idx || !out) return SLAMEM_ERR_ARG;
+    return sampled_lcp_stats(idx, out);
 }
 
 int slamem_follow_letter_batch(const slamem_index* idx, const char* letters_dev, uint32_t* top_dev, uint32_t* bottom_dev,

@@ -679,6 +679,63 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     return SLAMEM_OK;
 }
 
+// K6: the reference's run-sampling of the LCP array (lcparray.c:627-706) and its corner links (lcparray.c:782-956),
+// as statistics over the per-row records.  acc: [0] samples [1] oversized lcp [2] sum lcp (as u64 two's complement)
+// [3] max lcp [4] oversized links [5] sum |distance| [6] max |distance|
+__global__ void __launch_bounds__(256) k_sampled_stats(const RowRec* __restrict__ rec, uint32_t n,
+                                                       unsigned long long* __restrict__ acc) {
+    __shared__ unsigned long long sh[7];
+    if (threadIdx.x < 7) sh[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // row 0..n
+    if (i <= n) {
+        RowRec a = rec[i], b = rec[i + 1];
+        long long lcp = (long long)a.lcp1 - 1, nxt = (long long)b.lcp1 - 1;
+        // sum / max run over rows 1..n+1 (value of the NEXT row), lcparray.c:668-669
+        atomicAdd(&sh[2], (unsigned long long)nxt);
+        if (nxt > 0) atomicMax(&sh[3], (unsigned long long)nxt);
+        if (lcp != nxt) {
+            atomicAdd(&sh[0], 1ull);
+            if (lcp == -1 || lcp >= 255) atomicAdd(&sh[1], 1ull);
+            long long dist = -1;
+            if (nxt > lcp) { if (i != 0) dist = (long long)i - (long long)a.psv; }          // top corner -> PSV
+            else { if (i != n) dist = (long long)b.nsv - 1 - (long long)i; }                // bottom corner -> NSV-1
+            if (dist >= 0) {
+                atomicAdd(&sh[5], (unsigned long long)dist);
+                atomicMax(&sh[6], (unsigned long long)dist);
+                if (dist >= 128) atomicAdd(&sh[4], 1ull);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 7 && sh[threadIdx.x]) {
+        if (threadIdx.x == 3 || threadIdx.x == 6) atomicMax(&acc[threadIdx.x], sh[threadIdx.x]);
+        else atomicAdd(&acc[threadIdx.x], sh[threadIdx.x]);
+    }
+}
+
+int sampled_lcp_stats(const slamem_index* idx, slamem_sslcp_stats* out) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    DevBuf d;
+    SLAMEM_HIP(d.alloc(8 * 8));
+    SLAMEM_HIP(hipMemset(d.p, 0, 64));
+    const uint64_t R = (uint64_t)idx->hdr.n + 1;
+    hipLaunchKernelGGL(k_sampled_stats, dim3(grid_for(R)), dim3(256), 0, 0, idx->view.rec, idx->hdr.n,
+                       d.as<unsigned long long>());
+    SLAMEM_HIP(hipGetLastError());
+    unsigned long long h[8];
+    SLAMEM_HIP(hipMemcpy(h, d.p, 64, hipMemcpyDeviceToHost));
+    out->num_samples = h[0];
+    out->num_oversized_lcp = h[1];
+    out->sum_lcp = (int64_t)h[2];
+    out->max_lcp = (uint32_t)h[3];
+    out->pad = 0;
+    out->num_oversized_links = h[4] + 2;  // the first and the last sample are stored as oversized (lcparray.c:755,966-970)
+    out->sum_link_distance = h[5];
+    out->max_link_distance = h[6];
+    return SLAMEM_OK;
+}
+
 int download_array(const slamem_index* idx, int which, void* host_dst, uint64_t count) {
     SLAMEM_HIP(hipSetDevice(idx->device));
     const uint64_t R = (uint64_t)idx->hdr.n + 1;

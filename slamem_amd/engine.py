@@ -121,6 +121,12 @@ class Index:
         capi.check(capi.lib().slamem_index_download(self._h, which, out.ctypes.data, shape))
         return out
 
+    def sampled_lcp_stats(self) -> dict:
+        """What BuildSampledLCPArray would report for this text (lcparray.c:709-711, 999-1000)."""
+        st = capi.SslcpStats()
+        capi.check(capi.lib().slamem_index_sampled_lcp_stats(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in capi.SslcpStats._fields_ if k != "pad"}
+
     # ---- fine-grained operations, batched ------------------------------------------------------------
     def follow_letter(self, letters: bytes, top, bottom):
         """FMI_FollowLetter (bwtindex.c:359) for arrays of (letter, top, bottom) -> (size, top, bottom)."""

@@ -132,7 +132,21 @@ int main(int argc, char **argv) {
         printf("> Suffix sort + BWT + LCP + parent links on GPU %d ... OK (%.3f s; device %.1f ms: sort %.1f, BWT %.1f, LCP %.1f, links %.1f; %u doubling rounds)\n",
                device, now_s() - t0, tm.build_total_ms, tm.build_sort_ms, tm.build_bwt_ms, tm.build_lcp_ms, tm.build_links_ms,
                info.sort_rounds);
-        printf(":: Index size = %.1f MB in HBM (FM blocks + 16 B per row) ; max LCP = %u\n", (double)info.arena_bytes / 1e6, info.max_lcp);
+        printf(":: Index size = %.1f MB in HBM (FM blocks + 16 B per row)\n", (double)info.arena_bytes / 1e6);
+        {   /* the statistics lines of BuildSampledLCPArray (lcparray.c:709-711, 999-1000), from the per-row records */
+            slamem_sslcp_stats st;
+            unsigned bwt_len = info.bwt_size;
+            rc = slamem_index_sampled_lcp_stats(idx, &st);
+            if (rc != SLAMEM_OK) gpu_fail("LCP sampling statistics", rc);
+            printf(":: %.2lf%% samples (%u of %u)\n", ((double)st.num_samples / (double)bwt_len) * 100.0, (unsigned)st.num_samples, bwt_len);
+            printf(":: %.2lf%% oversized samples (%d of %u)\n", ((double)st.num_oversized_lcp / (double)st.num_samples) * 100.0,
+                   (int)st.num_oversized_lcp, (unsigned)st.num_samples);
+            printf(":: Average LCP value = %d (max=%lld)\n", (int)(st.sum_lcp / (long long)bwt_len), (long long)st.max_lcp);
+            printf(":: %.2lf%% oversized values (%d of %u)\n", ((double)st.num_oversized_links / (double)st.num_samples) * 100.0,
+                   (int)st.num_oversized_links, (unsigned)st.num_samples);
+            printf(":: Average SV distance = %.2lf (max=%lld)\n", (double)st.sum_link_distance / (double)st.num_samples,
+                   (long long)st.max_link_distance);
+        }
     }
     free(ref.chars); /* the reference frees the text here too (slamem.c:75-77) */
     ref.chars = NULL;

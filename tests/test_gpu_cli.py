@@ -39,3 +39,25 @@ def test_cli_default_output_name_and_batches(tmp_path):
     r = subprocess.run([exe, "-b", "-l", "20", str(tmp_path / "myref.fa"), q_fa], stdout=subprocess.PIPE, env=env)
     assert r.returncode == 0
     assert open(tmp_path / "myref-mems.txt", "rb").read() == open(exp_mems, "rb").read()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cli_prints_the_reference_structure_statistics(case, tmp_path):
+    """BuildSampledLCPArray's statistics (sample count, oversized samples, average / max LCP, oversized links,
+    average / max link distance; lcparray.c:709-711, 999-1000) are reproduced from the per-row records."""
+    import re
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    ref_fa, q_fa, _, exp_stdout = case_paths(case)
+    r = subprocess.run([exe] + MANIFEST[case]["opts"] + ["-o", str(tmp_path / "o.txt"), ref_fa, q_fa], stdout=subprocess.PIPE)
+    assert r.returncode == 0
+    ours = r.stdout.decode(errors="replace")
+    exp = open(exp_stdout, encoding="latin1").read()
+    pats = [r"^:: [0-9.]+% samples \(\d+ of \d+\)$", r"^:: [0-9.]+% oversized samples \(\d+ of \d+\)$",
+            r"^:: Average LCP value = -?\d+ \(max=\d+\)$", r"^:: [0-9.]+% oversized values \(\d+ of \d+\)$",
+            r"^:: Average SV distance = [0-9.]+ \(max=\d+\)$"]
+    for p in pats:
+        a, b = re.search(p, ours, re.M), re.search(p, exp, re.M)
+        assert a and b and a.group(0) == b.group(0), (p, a and a.group(0), b and b.group(0))

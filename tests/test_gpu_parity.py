@@ -155,6 +155,11 @@ def test_config2_known_answer_full_size(eng):
     reads = eng.synth_reads(ref, 0, nreads, L, 0.02, 42, 0)
     offsets = torch.arange(nreads + 1, dtype=torch.int64, device="cuda:0") * L
     idx = eng.Index.build(ref, "cuda:0")
+    # structure statistics the reference printed for this text
+    st = idx.sampled_lcp_stats()
+    assert st["num_samples"] == 85_214_690 and st["num_oversized_lcp"] == 1
+    assert st["num_oversized_links"] == 1_573_293 and st["max_lcp"] == 26
+    assert st["sum_lcp"] // (n + 1) == 12 and round(st["sum_link_distance"] / st["num_samples"], 2) == 43.93
     m = idx.matcher(nreads, False, 4 * nreads)
     total = m.run(reads, offsets, 20)
     assert total == 2_412_288
