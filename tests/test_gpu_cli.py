@@ -61,3 +61,32 @@ def test_cli_prints_the_reference_structure_statistics(case, tmp_path):
     for p in pats:
         a, b = re.search(p, ours, re.M), re.search(p, exp, re.M)
         assert a and b and a.group(0) == b.group(0), (p, a and a.group(0), b and b.group(0))
+
+
+def test_cli_config2_full_size_output_hash(tmp_path):
+    """BASELINE.json configs[1] end to end through the C front end: FASTA files of the SURVEY.md C.2 generator
+    (their sha256 equal the ones recorded when the REAL reference was run, App. C.3) -> slaMEM-hip -l 20 ->
+    the output file must be the reference's, byte for byte: 44,723,866 bytes, sha256 8f711ed6cd088ee1…."""
+    import hashlib
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    root = hostlib.ROOT
+    gen = os.path.join(root, "tools", "gen_synth.py")
+    d = str(tmp_path)
+    g = subprocess.run([sys.executable, gen, "100000000", "1000000", "150", "0.02", "42", "0", d], stdout=subprocess.PIPE)
+    assert g.returncode == 0
+    out = g.stdout.decode()
+    assert "ref.fa f6bcf2e657079fdf" in out and "qry.fa 81ac1e6c4b633fa3" in out
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    r = subprocess.run([exe, "-l", "20", "-o", os.path.join(d, "out.txt"), os.path.join(d, "ref.fa"),
+                        os.path.join(d, "qry.fa")], stdout=subprocess.PIPE)
+    assert r.returncode == 0
+    assert b"(total = 2412288, avg size = 55 bp)" in r.stdout
+    h = hashlib.sha256()
+    with open(os.path.join(d, "out.txt"), "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    assert os.path.getsize(os.path.join(d, "out.txt")) == 44_723_866
+    assert h.hexdigest().startswith("8f711ed6cd088ee1")
