@@ -120,7 +120,7 @@ def main():
     arena_bytes = int(index.info.arena_bytes)
 
     # ---- the timed hot path ------------------------------------------------------------------------------------
-    matcher = index.matcher(M, both, mems_capacity=4 * M + 1024)
+    matcher = index.matcher(M, both, mems_capacity=4 * M + 1024, query_bytes=M * L)
     counts_all = torch.zeros(world, dtype=torch.int64, device=cdev)
 
     def step():

@@ -167,6 +167,8 @@ int slamem_char_at_bwt_pos_batch(const slamem_index *idx, const uint32_t *rows_d
  *   queries_dev       concatenated query characters (A,C,G,T,N; other bytes = N);
  *                     8-byte aligned and readable up to the next multiple of 8 bytes
  *   offsets_dev       uint64[num_queries+1]; record i is [offsets[i], offsets[i+1])
+ *   query_bytes       offsets[num_queries] (total characters; sizes the work-item tables: records longer than 4096
+ *                     characters are cut into slices that different lanes scan)
  *   strand blocks     block b = 2*i + strand when both_strands, else b = i
  *   mems_dev          out: slamem_mem[mems_capacity], grouped by block, inside a
  *                     block in the reference's emission order (slamem.c:139-193)
@@ -175,10 +177,10 @@ int slamem_char_at_bwt_pos_batch(const slamem_index *idx, const uint32_t *rows_d
  *   total_out         number of MEMs found (also when SLAMEM_ERR_CAPACITY is returned)
  *
  * Synchronous with respect to the stream on return (it has to read the total). */
-int slamem_find_mems_workspace_bytes(uint32_t num_queries, int both_strands, uint64_t mems_capacity,
-                                     uint64_t *bytes_out);
+int slamem_find_mems_workspace_bytes(uint32_t num_queries, int both_strands, uint64_t query_bytes,
+                                     uint64_t mems_capacity, uint64_t *bytes_out);
 int slamem_find_mems_device(const slamem_index *idx, const void *queries_dev, const uint64_t *offsets_dev,
-                            uint32_t num_queries, uint32_t min_len, int both_strands,
+                            uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands,
                             slamem_mem *mems_dev, uint64_t mems_capacity, uint64_t *block_offsets_dev,
                             void *workspace_dev, uint64_t workspace_bytes, void *stream, uint64_t *total_out);
 

@@ -91,8 +91,8 @@ def _declare(L):
     L.slamem_enclosing_interval_batch.argtypes = [vp, vp, vp, vp, u64, vp]
     L.slamem_position_in_text_batch.argtypes = [vp, vp, vp, u64, vp]
     L.slamem_char_at_bwt_pos_batch.argtypes = [vp, vp, vp, u64, vp]
-    L.slamem_find_mems_workspace_bytes.argtypes = [u32, i32, u64, C.POINTER(u64)]
-    L.slamem_find_mems_device.argtypes = [vp, vp, vp, u32, u32, i32, vp, u64, vp, vp, u64, vp, C.POINTER(u64)]
+    L.slamem_find_mems_workspace_bytes.argtypes = [u32, i32, u64, u64, C.POINTER(u64)]
+    L.slamem_find_mems_device.argtypes = [vp, vp, vp, u32, u64, u32, i32, vp, u64, vp, vp, u64, vp, C.POINTER(u64)]
     L.slamem_find_mems_host.argtypes = [vp, C.c_char_p, vp, u32, u32, i32, C.POINTER(C.POINTER(Mem)),
                                         C.POINTER(C.POINTER(u64)), C.POINTER(u64)]
     L.slamem_host_free.argtypes = [vp]

@@ -281,18 +281,20 @@ int slamem_char_at_bwt_pos_batch(const slamem_index* idx, const uint32_t* rows_d
     return char_at_bwt_pos_batch(idx, rows_dev, chars_out_dev, count, static_cast<hipStream_t>(stream));
 }
 
-int slamem_find_mems_workspace_bytes(uint32_t num_queries, int both_strands, uint64_t mems_capacity, uint64_t* bytes_out) {
+int slamem_find_mems_workspace_bytes(uint32_t num_queries, int both_strands, uint64_t query_bytes, uint64_t mems_capacity,
+                                     uint64_t* bytes_out) {
     if (!bytes_out) return SLAMEM_ERR_ARG;
-    *bytes_out = find_mems_workspace_bytes((uint64_t)num_queries * (both_strands ? 2 : 1), mems_capacity);
+    *bytes_out = find_mems_workspace_bytes(num_queries, both_strands, query_bytes, mems_capacity);
     return SLAMEM_OK;
 }
 
 int slamem_find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
-                            uint32_t num_queries, uint32_t min_len, int both_strands, slamem_mem* mems_dev,
-                            uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
+                            uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands,
+                            slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
                             uint64_t workspace_bytes, void* stream, uint64_t* total_out) {
-    return find_mems_device(idx, queries_dev, offsets_dev, num_queries, min_len, both_strands, mems_dev, mems_capacity,
-                            block_offsets_dev, workspace_dev, workspace_bytes, static_cast<hipStream_t>(stream), total_out);
+    return find_mems_device(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, mems_dev,
+                            mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes, static_cast<hipStream_t>(stream),
+                            total_out);
 }
 
 void slamem_host_free(void* p) { free(p); }
@@ -320,10 +322,10 @@ int slamem_find_mems_host(const slamem_index* idx, const char* queries, const ui
     HOST_TRY(hipMemcpy(d_q, queries, qbytes, hipMemcpyHostToDevice));
     HOST_TRY(hipMemcpy(d_off, offsets, ((uint64_t)num_queries + 1) * 8, hipMemcpyHostToDevice));
     for (int attempt = 0; attempt < 3; attempt++) {
-        uint64_t ws_bytes = find_mems_workspace_bytes(num_blocks, cap);
+        uint64_t ws_bytes = find_mems_workspace_bytes(num_queries, both_strands, qbytes, cap);
         HOST_TRY(hipMalloc(&d_mems, cap * sizeof(slamem_mem) + 16));
         HOST_TRY(hipMalloc(&d_ws, ws_bytes));
-        rc = find_mems_device(idx, d_q, static_cast<const uint64_t*>(d_off), num_queries, min_len, both_strands,
+        rc = find_mems_device(idx, d_q, static_cast<const uint64_t*>(d_off), num_queries, qbytes, min_len, both_strands,
                               static_cast<slamem_mem*>(d_mems), cap, static_cast<uint64_t*>(d_boff), d_ws, ws_bytes,
                               nullptr, total_out);
         if (rc != SLAMEM_ERR_CAPACITY) break;

@@ -165,13 +165,30 @@ struct SearchArgs {
     RawKey* raw_key;
     slamem_mem* raw_mem;
     uint32_t* block_counts;    // [num_blocks + 1]
-    struct RawRow* inline_rows; // v3: kInlineMems slots per strand block, addressed directly (no atomics)
+    struct RawRow* inline_rows; // v3: kInlineMems slots per work item, addressed directly (no atomics)
+    const struct ItemDesc* items; // v3: work items in emission order
+    uint64_t num_items;
+    uint8_t* item_attempt;      // v3: attempt whose records are the valid ones
 };
 
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
 struct RawRow { uint32_t row, pos, len; };
-constexpr uint32_t kInlineMems = 4;     // MEMs per strand block stored in place; more go to the overflow list
-constexpr uint32_t kChunkMax = 512;     // strand blocks per wave (bounds the LDS copy of the record offsets)
+constexpr uint32_t kInlineMems = 4;     // MEMs per work item stored in place; more go to the overflow list
+constexpr uint32_t kChunkMax = 128;     // work items per wave (bounds the LDS copy of their descriptors)
+
+// Work item of K8 v3 = one strand of one query record, or -- for long records (genome against genome) -- one
+// slice of kSliceLen positions of it.  A slice [a,b) is scanned from e = b + warm-up: a scan that starts at e
+// finds min(true match length, e - j) at position j (the truncation property), so position j is exact
+// whenever its match does not reach e.  If a position of the slice does reach e, the lane restarts the item with a
+// four times longer warm-up (attempt tag in the records; at attempt 7 the scan starts at the record's end).
+constexpr uint32_t kSliceLen = 4096;
+constexpr uint32_t kWarmUp = 1024;
+constexpr uint32_t kMaxAttempt = 7;
+struct __attribute__((aligned(16))) ItemDesc {
+    uint64_t base;       // byte offset of the query record
+    uint32_t len;        // its length
+    uint32_t slice_rev;  // slice index | reverse strand << 31
+};
 
 struct QueryCursor {
     const uint64_t* words;
@@ -314,14 +331,14 @@ __global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
 // Results are identical to v1: same MEMs, same per-strand emission order.
 // ------------------------------------------------------------------------------------------
 // store MEM number kk of strand block g (kk is assigned by the caller)
-__device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t row, uint32_t pos,
-                                         uint32_t len) {
+__device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t tag, uint32_t row,
+                                         uint32_t pos, uint32_t len) {
     if (kk < kInlineMems) {
         A.inline_rows[(uint64_t)g * kInlineMems + kk] = RawRow{row, pos, len};
     } else {
         unsigned long long slot = atomicAdd(A.total, 1ull);
         if (slot < A.capacity) {
-            A.raw_key[slot] = RawKey{g, kk};
+            A.raw_key[slot] = RawKey{g, kk | tag};  // tag = attempt << 28: records of abandoned attempts are skipped
             A.raw_mem[slot] = slamem_mem{row, pos, len};  // ref_pos holds the ROW until K9
         }
     }
@@ -335,7 +352,7 @@ __device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32
 // rows) cost rows/64 steps instead of rows.  Returns the strand's new MEM count; *first_parent = depth of the
 // parent of [t,b] (the exact value of `pub`).
 __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t lane, uint32_t g, uint32_t k,
-                                                   uint32_t t, uint32_t b, int msz, bool level0, bool walk_up,
+                                                   uint32_t tag, uint32_t t, uint32_t b, int msz, bool level0, bool walk_up,
                                                    uint32_t pos, uint32_t left, int L, int* first_parent) {
     const IndexView& ix = A.ix;
     uint32_t pt = level0 ? b + 1u : t, pb = b;  // rows already reported: [pt, pb]
@@ -346,7 +363,7 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
             uint32_t row = base + lane;
             bool ok = row < pt && bwt_code(ix, row) != left;
             unsigned long long m = __ballot(ok);
-            if (ok) emit3_at(A, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), row, pos, (uint32_t)msz);
+            if (ok) emit3_at(A, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), tag, row, pos, (uint32_t)msz);
             k += (uint32_t)__popcll(m);
         }
         for (uint32_t done = 0; done < b - pb; done += 64u) {  // new rows below, bottom-up (slamem.c:165)
@@ -354,7 +371,7 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
             uint32_t row = b - off;
             bool ok = off < b - pb && bwt_code(ix, row) != left;
             unsigned long long m = __ballot(ok);
-            if (ok) emit3_at(A, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), row, pos, (uint32_t)msz);
+            if (ok) emit3_at(A, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), tag, row, pos, (uint32_t)msz);
             k += (uint32_t)__popcll(m);
         }
         if (!walk_up) break;
@@ -371,25 +388,24 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
 #define SLAMEM_V3_WAVES 1
 #endif
 __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
-    __shared__ uint64_t lds_off[4][kChunkMax + 8];
+    __shared__ ItemDesc lds_item[4][kChunkMax];
     const IndexView& ix = A.ix;
     const int L = (int)A.min_len;
     const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
-    const uint64_t nblocks = (uint64_t)A.num_queries * A.strands;
+    const uint64_t nitems = A.num_items;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    uint64_t next = wave * A.chunk;  // wave-uniform: first unassigned strand block of this wave's chunk
-    if (next > nblocks) next = nblocks;
-    const uint64_t chunk_end = next + A.chunk < nblocks ? next + A.chunk : nblocks;
-    const uint64_t q_first = next / A.strands;
-    {   // record offsets of the chunk -> LDS (one coalesced read per wave instead of a round trip per record)
-        uint32_t cnt = next < chunk_end ? (uint32_t)((chunk_end - 1) / A.strands - q_first) + 2u : 0u;
-        for (uint32_t i = lane; i < cnt; i += 64u) lds_off[wv][i] = A.offsets[q_first + i];
-    }
+    uint64_t next = wave * A.chunk;  // wave-uniform: first unassigned work item of this wave's chunk
+    if (next > nitems) next = nitems;
+    const uint64_t chunk_first = next;
+    const uint64_t chunk_end = next + A.chunk < nitems ? next + A.chunk : nitems;
+    // item descriptors of the chunk -> LDS (one coalesced read per wave instead of a round trip per item)
+    for (uint64_t i = chunk_first + lane; i < chunk_end; i += 64u) lds_item[wv][i - chunk_first] = A.items[i];
     __syncthreads();
 
     bool active = false, st_rec = false, st_flush = false, pend = false;
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
+    uint32_t a_pos = 0, b_pos = 0, attempt = 0;  // emitted slice [a_pos, b_pos) of the strand, warm-up attempt
     int depth = 0, pub = -1;
     QueryCursor qc;
     qc.init(A.qwords, 0, 0, 0);
@@ -400,19 +416,22 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     uint32_t tag_t = 0xFFFFFFFFu;
 
     for (;;) {
-        // ---- hand the next strands of the chunk to idle lanes -------------------------------------------
+        // ---- hand the next items of the chunk to idle lanes ------------------------------------------------
         unsigned long long idle = __ballot(!active);
         if (idle != 0ull && next < chunk_end) {
             uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             uint64_t cand = next + rank;
             if (!active && cand < chunk_end) {
                 g = (uint32_t)cand;
-                uint32_t qi = A.strands == 2 ? g >> 1 : g;
-                uint64_t o0 = lds_off[wv][qi - q_first], o1 = lds_off[wv][qi - q_first + 1];
-                qc.init(A.qwords, o0, (uint32_t)(o1 - o0), A.strands == 2 ? (g & 1u) : 0u);
-                j = qc.len;
+                ItemDesc d = lds_item[wv][cand - chunk_first];
+                qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
+                uint32_t sl = d.slice_rev & 0x7FFFFFFFu;
+                a_pos = sl * kSliceLen;
+                b_pos = d.len - a_pos < kSliceLen ? d.len : a_pos + kSliceLen;
+                attempt = 0;
+                j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
                 top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st_rec = false; st_flush = false; k = 0;
-                if (j == 0) A.block_counts[g] = 0;  // empty record: nothing to scan
+                if (d.len == 0) { A.block_counts[g] = 0; A.item_attempt[g] = 0; }  // empty record: nothing to scan
                 else active = true;
             }
             next += (uint64_t)__popcll(idle);
@@ -451,7 +470,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 st_flush = false;
                 uint32_t t2 = top, b2 = bot;
                 pub = parent_from(rt, rb, t2, b2);
-                if (pub < L && top == bot) { emit3_at(A, g, k, top, 0u, (uint32_t)depth); k++; }
+                if (pub < L && top == bot) { emit3_at(A, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; }
                 else { e_on = true; e_level0 = true; e_up = pub >= L; e_pos = 0u; e_left = 0xFFu; }
                 pend = false;
                 finished = true;
@@ -484,13 +503,16 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                         anc = pub >= L;
                     }
                     if (!anc && (!lvl0 || size == 1u)) {  // the common case: at most this one row, no ancestors
-                        if (lvl0) { emit3_at(A, g, k, top, j, (uint32_t)depth); k++; }
+                        if (lvl0) { emit3_at(A, g, k, attempt << 28, top, j, (uint32_t)depth); k++; }
                         pend = false;
                     } else {  // several rows and/or ancestors: the wave does it together, below; this trip only emits
                         e_on = true; e_level0 = lvl0; e_up = anc; e_pos = j; e_left = c;
                     }
                 }
-                if (!e_on) {
+                // a slice that does not start the strand ends here: position a_pos-1 was only needed as the left
+                // letter of position a_pos
+                if (a_pos != 0u && j == a_pos) finished = true;
+                if (!e_on && !finished) {
                     if (nt < nb1) {  // the extension occurs (slamem.c:121)
                         top = nt;
                         bot = nb1 - 1u;
@@ -507,12 +529,22 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 }
             }
             if (consumed) {
-                j--;
-                pend = depth >= L && depth > 0;  // slamem.c:130
-                if (j == 0u) {  // strand finished; rows still pending have nothing to their left (slamem.c:138)
+                j--;  // position j is done: it matched `depth` characters
+                bool in_slice = j >= a_pos && j < b_pos;
+                pend = depth >= L && depth > 0 && in_slice;  // slamem.c:130
+                // scan start of this attempt; a match that reaches it may be truncated: redo with a longer warm-up
+                uint32_t e = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
+                                                                                                   : b_pos + (kWarmUp << (2u * attempt));
+                if (in_slice && e < qc.len && (uint32_t)depth == e - j) {
+                    attempt++;
+                    j = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
+                                                                                            : b_pos + (kWarmUp << (2u * attempt));
+                    top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; k = 0;
+                    qc.widx = ~0ull; qc.wnidx = ~0ull;
+                } else if (j == 0u) {  // strand finished; rows still pending have nothing to their left (slamem.c:138)
                     finished = true;
                     if (pend && pub >= L) { st_flush = true; finished = false; }  // parent depth needed: next trip
-                    else if (pend && top == bot) { emit3_at(A, g, k, top, 0u, (uint32_t)depth); k++; pend = false; }
+                    else if (pend && top == bot) { emit3_at(A, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; pend = false; }
                     else if (pend) { e_on = true; e_level0 = true; e_up = false; e_pos = 0u; e_left = 0xFFu; }
                 }
             }
@@ -522,11 +554,12 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
         for (unsigned long long em = __ballot(e_on); em != 0ull; em &= em - 1ull) {
             int owner = __ffsll((long long)em) - 1;
             uint32_t o_g = __shfl(g, owner), o_k = __shfl(k, owner), o_t = __shfl(top, owner), o_b = __shfl(bot, owner);
+            uint32_t o_tag = __shfl(attempt, owner) << 28;
             int o_depth = __shfl(depth, owner);
             uint32_t o_pos = __shfl(e_pos, owner), o_left = __shfl(e_left, owner);
             bool o_l0 = __shfl((int)e_level0, owner) != 0, o_up = __shfl((int)e_up, owner) != 0;
             int fp;
-            uint32_t nk = wave_enumerate(A, lane, o_g, o_k, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp);
+            uint32_t nk = wave_enumerate(A, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp);
             if ((int)lane == owner) {
                 k = nk;
                 if (o_up) pub = fp;
@@ -536,6 +569,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
 
         if (active && finished) {
             A.block_counts[g] = k;
+            A.item_attempt[g] = (uint8_t)attempt;
             active = false;
         }
     }
@@ -543,14 +577,14 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
 
 // K9 for v3: inline slots and overflow records -> grouped output, BWT rows resolved to text positions here
 __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__ inl, const uint32_t* __restrict__ counts,
-                                                      const uint64_t* __restrict__ block_offsets, uint64_t nblocks,
+                                                      const uint64_t* __restrict__ item_off, uint64_t nitems,
                                                       const RowRec* __restrict__ rec, uint64_t capacity,
                                                       slamem_mem* __restrict__ out) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nblocks) return;
+    if (g >= nitems) return;
     uint32_t cnt = counts[g];
     if (cnt > kInlineMems) cnt = kInlineMems;
-    uint64_t off = block_offsets[g];
+    uint64_t off = item_off[g];
     for (uint32_t i = 0; i < cnt; i++) {
         if (off + i >= capacity) return;
         RawRow r = inl[g * kInlineMems + i];
@@ -559,17 +593,60 @@ __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__
 }
 
 __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict__ key, const slamem_mem* __restrict__ raw,
-                                                        uint64_t count, const uint64_t* __restrict__ block_offsets,
+                                                        uint64_t count, const uint64_t* __restrict__ item_off,
+                                                        const uint8_t* __restrict__ item_attempt,
                                                         const RowRec* __restrict__ rec, uint64_t capacity,
                                                         slamem_mem* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     RawKey kk = key[i];
+    if ((kk.k >> 28) != item_attempt[kk.block]) return;  // written by an attempt that was abandoned
     slamem_mem m = raw[i];
-    uint64_t pos = block_offsets[kk.block] + kk.k;
+    uint64_t pos = item_off[kk.block] + (kk.k & 0x0FFFFFFFu);
     if (pos >= capacity) return;
     m.ref_pos = rec[m.ref_pos].sa;
     out[pos] = m;
+}
+
+// ---- work items ------------------------------------------------------------------------------------------
+// slices per strand of every record (>= 1 so that empty records still own an (empty) output block)
+__global__ void __launch_bounds__(256) k_item_counts(const uint64_t* __restrict__ offsets, uint32_t nq, uint32_t slice_len,
+                                                     uint32_t* __restrict__ cnt) {
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nq) return;
+    uint32_t c = 0;
+    if (q < nq) {
+        uint64_t len = offsets[q + 1] - offsets[q];
+        c = slice_len ? (uint32_t)((len + slice_len - 1) / slice_len) : 1u;
+        if (c == 0) c = 1;
+    }
+    cnt[q] = c;  // cnt[nq] = 0: the scan of nq+1 values leaves the total in first[nq]
+}
+
+// items in emission order: per record the forward strand's slices right to left, then the reverse strand's
+__global__ void __launch_bounds__(256) k_item_fill(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ first,
+                                                   uint32_t nq, uint32_t strands, ItemDesc* __restrict__ items) {
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint64_t o0 = offsets[q];
+    uint32_t len = (uint32_t)(offsets[q + 1] - o0);
+    uint32_t f = first[q], cnt = first[q + 1] - f;
+    for (uint32_t s = 0; s < strands; s++)
+        for (uint32_t c = 0; c < cnt; c++)
+            items[(uint64_t)strands * f + (uint64_t)s * cnt + (cnt - 1u - c)] = ItemDesc{o0, len, c | (s << 31)};
+}
+
+// public strand blocks: block (q, s) starts where its first item starts
+__global__ void __launch_bounds__(256) k_block_offsets(const uint32_t* __restrict__ first, const uint64_t* __restrict__ item_off,
+                                                       uint32_t nq, uint32_t strands, uint64_t nitems,
+                                                       uint64_t* __restrict__ block_offsets) {
+    uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t nblocks = (uint64_t)nq * strands;
+    if (b > nblocks) return;
+    if (b == nblocks) { block_offsets[b] = item_off[nitems]; return; }
+    uint32_t q = (uint32_t)(b / strands), sidx = (uint32_t)(b % strands);
+    uint32_t f = first[q], cnt = first[q + 1] - f;
+    block_offsets[b] = item_off[(uint64_t)strands * f + (uint64_t)sidx * cnt];
 }
 
 // K9: raw list -> grouped output
@@ -632,33 +709,42 @@ inline unsigned grid_for(uint64_t items, unsigned block = 256) { return (unsigne
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    uint64_t off_total, off_counts, off_rawkey, off_rawmem, off_inline, off_scan, scan_bytes, bytes;
+    uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_itemoff, off_rawkey,
+        off_rawmem, off_inline, off_scan, scan_bytes, max_items, bytes;
 };
 
-WorkspaceLayout layout_workspace(uint64_t num_blocks, uint64_t capacity) {
+// max_items bounds the work items of ANY batch with this many records and characters
+WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_t query_bytes, uint64_t capacity) {
     WorkspaceLayout w;
+    w.max_items = strands * (num_queries + query_bytes / kSliceLen + 1);
     uint64_t off = 0;
-    w.off_total = off;   off = align_up(off + 64, 256);
-    w.off_counts = off;  off = align_up(off + (num_blocks + 1) * 4, 256);
-    w.off_rawkey = off;  off = align_up(off + capacity * sizeof(RawKey), 256);
-    w.off_rawmem = off;  off = align_up(off + capacity * sizeof(slamem_mem), 256);
-    w.off_inline = off;  off = align_up(off + num_blocks * kInlineMems * sizeof(RawRow), 256);
+    w.off_total = off;    off = align_up(off + 64, 256);
+    w.off_cnt = off;      off = align_up(off + (num_queries + 2) * 4, 256);
+    w.off_first = off;    off = align_up(off + (num_queries + 2) * 4, 256);
+    w.off_scan32 = off;   off = align_up(off + scan_u32_tmp_words(num_queries + 1) * 4, 256);
+    w.off_items = off;    off = align_up(off + w.max_items * sizeof(ItemDesc), 256);
+    w.off_counts = off;   off = align_up(off + (w.max_items + 1) * 4, 256);
+    w.off_attempt = off;  off = align_up(off + w.max_items, 256);
+    w.off_itemoff = off;  off = align_up(off + (w.max_items + 1) * 8, 256);
+    w.off_rawkey = off;   off = align_up(off + capacity * sizeof(RawKey), 256);
+    w.off_rawmem = off;   off = align_up(off + capacity * sizeof(slamem_mem), 256);
+    w.off_inline = off;   off = align_up(off + w.max_items * kInlineMems * sizeof(RawRow), 256);
     size_t need = 0;
-    (void)scan_sum_exclusive_u32_u64(nullptr, need, nullptr, nullptr, num_blocks, 0);
+    (void)scan_sum_exclusive_u32_u64(nullptr, need, nullptr, nullptr, w.max_items, 0);
     w.scan_bytes = need;
-    w.off_scan = off;    off = align_up(off + need, 256);
+    w.off_scan = off;     off = align_up(off + need, 256);
     w.bytes = off;
     return w;
 }
 }  // namespace
 
-uint64_t find_mems_workspace_bytes(uint64_t num_blocks, uint64_t mems_capacity) {
-    return layout_workspace(num_blocks, mems_capacity).bytes;
+uint64_t find_mems_workspace_bytes(uint64_t num_queries, int both_strands, uint64_t query_bytes, uint64_t mems_capacity) {
+    return layout_workspace(num_queries, both_strands ? 2 : 1, query_bytes, mems_capacity).bytes;
 }
 
 int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
-                     uint32_t num_queries, uint32_t min_len, int both_strands, slamem_mem* mems_dev,
-                     uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
+                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands,
+                     slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
                      uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out) {
     if (!idx || !offsets_dev || !block_offsets_dev || !workspace_dev || !total_out || (!mems_dev && mems_capacity) ||
         (!queries_dev && num_queries)) {
@@ -675,11 +761,11 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     }
     const uint32_t strands = both_strands ? 2u : 1u;
     const uint64_t num_blocks = (uint64_t)num_queries * strands;
-    if (num_blocks >= 0xFFFFFFFFull) {
-        set_error("slamem_find_mems_device: at most 2^32-2 strand blocks per call");
+    WorkspaceLayout w = layout_workspace(num_queries, strands, query_bytes, mems_capacity);
+    if (w.max_items >= 0xFFFFFFFFull) {
+        set_error("slamem_find_mems_device: at most 2^32-2 work items per call");
         return SLAMEM_ERR_ARG;
     }
-    WorkspaceLayout w = layout_workspace(num_blocks, mems_capacity);
     if (workspace_bytes < w.bytes) {
         set_error("slamem_find_mems_device: workspace too small (%llu < %llu bytes)",
                   (unsigned long long)workspace_bytes, (unsigned long long)w.bytes);
@@ -688,7 +774,11 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     SLAMEM_HIP(hipSetDevice(idx->device));
     char* ws = static_cast<char*>(workspace_dev);
     unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(ws + w.off_cnt);
+    uint32_t* d_first = reinterpret_cast<uint32_t*>(ws + w.off_first);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
+    uint64_t* d_itemoff = reinterpret_cast<uint64_t*>(ws + w.off_itemoff);
+    static const int kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
 
     Timings& tm = thread_timings();
     hipEvent_t e0, e1, e2;
@@ -698,8 +788,20 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     int rc = SLAMEM_OK;
     do {
         hipError_t e;
-        if ((e = hipMemsetAsync(d_total, 0, 64, stream)) != hipSuccess) { rc = hip_fail(e, "memset", __FILE__, __LINE__); break; }
-        if ((e = hipMemsetAsync(d_counts + num_blocks, 0, 4, stream)) != hipSuccess) { rc = hip_fail(e, "memset", __FILE__, __LINE__); break; }
+#define STEP(call, what) if ((e = (call)) != hipSuccess) { rc = hip_fail(e, what, __FILE__, __LINE__); break; }
+        STEP(hipMemsetAsync(d_total, 0, 64, stream), "memset");
+        // ---- work items: one per strand, long records cut into slices (v1 scans whole strands) ----------------
+        uint64_t nitems = num_blocks;
+        hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
+                           num_queries, kernel_version == 3 ? kSliceLen : 0u, d_cnt);
+        STEP(hipGetLastError(), "k_item_counts");
+        STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
+        uint32_t slices = 0;
+        STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
+        STEP(hipStreamSynchronize(stream), "item count (sync)");
+        nitems = (uint64_t)slices * strands;
+        if (nitems > w.max_items) { set_error("slamem_find_mems_device: query_bytes is smaller than the offsets say"); rc = SLAMEM_ERR_ARG; break; }
+        STEP(hipMemsetAsync(d_counts + nitems, 0, 4, stream), "memset");
         SearchArgs A;
         memset(&A, 0, sizeof(A));
         A.ix = idx->view;
@@ -714,61 +816,66 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         A.raw_mem = reinterpret_cast<slamem_mem*>(ws + w.off_rawmem);
         A.block_counts = d_counts;
         A.inline_rows = reinterpret_cast<RawRow*>(ws + w.off_inline);
-        {   // random text of n characters stops matching at about log4(n) characters
-            int lg = 0;
-            for (uint64_t v = idx->hdr.n; v > 1; v >>= 2) lg++;
+        A.items = reinterpret_cast<const ItemDesc*>(ws + w.off_items);
+        A.num_items = nitems;
+        A.item_attempt = reinterpret_cast<uint8_t*>(ws + w.off_attempt);
+        {
             A.spec_depth = -1;  // measured: fetching the records speculatively costs more lines than the trips it saves
-            (void)lg;
             const char* e1 = getenv("SLAMEM_SPEC_DEPTH");
             if (e1) A.spec_depth = atoi(e1);
-            A.chunk = 128;
+            A.chunk = kChunkMax;
             const char* e2 = getenv("SLAMEM_CHUNK");
             if (e2 && atoi(e2) > 0) A.chunk = (uint32_t)atoi(e2);
             if (A.chunk > kChunkMax) A.chunk = kChunkMax;
-            A.chunk &= ~1u;  // both strands of a record stay in one chunk
-            if (A.chunk < 2) A.chunk = 2;
         }
-        static const int kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
         (void)hipEventRecord(e0, stream);
-        if (num_blocks && kernel_version == 3) {
-            uint64_t waves = (num_blocks + A.chunk - 1) / A.chunk;
+        if (nitems && kernel_version == 3) {
+            hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first,
+                               num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items));
+            STEP(hipGetLastError(), "k_item_fill");
+            uint64_t waves = (nitems + A.chunk - 1) / A.chunk;
             hipLaunchKernelGGL(k_find_mems_v3, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
-            if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_find_mems_v3", __FILE__, __LINE__); break; }
-        } else if (num_blocks) {
+            STEP(hipGetLastError(), "k_find_mems_v3");
+        } else if (nitems) {
             hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
-            if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_find_mems", __FILE__, __LINE__); break; }
+            STEP(hipGetLastError(), "k_find_mems");
         }
         (void)hipEventRecord(e1, stream);
         size_t need = w.scan_bytes;
-        if ((e = scan_sum_exclusive_u32_u64(ws + w.off_scan, need, d_counts, block_offsets_dev, num_blocks, stream)) != hipSuccess) {
-            rc = hip_fail(e, "scan", __FILE__, __LINE__); break;
-        }
+        STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need, d_counts, d_itemoff, nitems, stream), "scan");
+        hipLaunchKernelGGL(k_block_offsets, dim3(grid_for(num_blocks + 1)), dim3(256), 0, stream, d_first, d_itemoff,
+                           num_queries, strands, nitems, block_offsets_dev);
+        STEP(hipGetLastError(), "k_block_offsets");
         unsigned long long listed = 0, total = 0;  // listed: records in the atomic list; total: all MEMs
-        if ((e = hipMemcpyAsync(&listed, d_total, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) { rc = hip_fail(e, "memcpy", __FILE__, __LINE__); break; }
-        if ((e = hipMemcpyAsync(&total, block_offsets_dev + num_blocks, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) { rc = hip_fail(e, "memcpy", __FILE__, __LINE__); break; }
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) { rc = hip_fail(e, "k_find_mems (sync)", __FILE__, __LINE__); break; }
+        STEP(hipMemcpyAsync(&listed, d_total, 8, hipMemcpyDeviceToHost, stream), "memcpy");
+        STEP(hipMemcpyAsync(&total, d_itemoff + nitems, 8, hipMemcpyDeviceToHost, stream), "memcpy");
+        STEP(hipStreamSynchronize(stream), "k_find_mems (sync)");
         *total_out = total;
         if (total > mems_capacity || listed > mems_capacity) {
-            set_error("slamem_find_mems_device: %llu MEMs found, output capacity is %llu", total, (unsigned long long)mems_capacity);
+            // the atomic list also holds the records of abandoned slice attempts: ask for room for those too
+            if (listed > total) *total_out = listed;
+            set_error("slamem_find_mems_device: %llu MEMs found, output capacity is %llu", (unsigned long long)*total_out,
+                      (unsigned long long)mems_capacity);
             rc = SLAMEM_ERR_CAPACITY;
         } else if (kernel_version == 3) {
             if (total) {
-                hipLaunchKernelGGL(k_place_inline, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A.inline_rows, d_counts,
-                                   block_offsets_dev, num_blocks, idx->view.rec, mems_capacity, mems_dev);
-                if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_place_inline", __FILE__, __LINE__); break; }
+                hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
+                                   d_itemoff, nitems, idx->view.rec, mems_capacity, mems_dev);
+                STEP(hipGetLastError(), "k_place_inline");
             }
             if (listed) {
                 hipLaunchKernelGGL(k_place_overflow, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                                   (uint64_t)listed, block_offsets_dev, idx->view.rec, mems_capacity, mems_dev);
-                if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_place_overflow", __FILE__, __LINE__); break; }
+                                   (uint64_t)listed, d_itemoff, A.item_attempt, idx->view.rec, mems_capacity, mems_dev);
+                STEP(hipGetLastError(), "k_place_overflow");
             }
         } else if (listed) {
             hipLaunchKernelGGL(k_scatter_mems, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                               (uint64_t)listed, block_offsets_dev, mems_dev);
-            if ((e = hipGetLastError()) != hipSuccess) { rc = hip_fail(e, "k_scatter_mems", __FILE__, __LINE__); break; }
+                               (uint64_t)listed, d_itemoff, mems_dev);
+            STEP(hipGetLastError(), "k_scatter_mems");
         }
         (void)hipEventRecord(e2, stream);
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) { rc = hip_fail(e, "k_scatter_mems (sync)", __FILE__, __LINE__); break; }
+        STEP(hipStreamSynchronize(stream), "K9 (sync)");
+#undef STEP
         float ms = 0;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
             tm.t.search_kernel_ms = ms;

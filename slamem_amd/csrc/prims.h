@@ -15,6 +15,10 @@ hipError_t sort_pairs_u64_u32(void* tmp, size_t& tmp_bytes, uint64_t* keys_in, u
                               uint32_t* vals_in, uint32_t* vals_out, size_t n, int begin_bit, int end_bit,
                               hipStream_t stream);
 
+// Hand-written exclusive sum scan of u32 (radix_sort.hip); in-place capable; tmp holds scan_u32_tmp_words(n) words.
+uint64_t scan_u32_tmp_words(uint64_t n);
+hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, hipStream_t stream);
+
 hipError_t scan_max_inclusive_u32(void* tmp, size_t& tmp_bytes, const uint32_t* in, uint32_t* out, size_t n,
                                   hipStream_t stream);
 // out[i] = sum_{j<i} in[j]  (u32 in, u64 out); out has n+1 entries, out[n] = total.

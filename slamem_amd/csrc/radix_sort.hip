@@ -80,8 +80,10 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t* __restrict__
     }
 }
 
-// in-place capable (in == out); tmp must hold scan_tmp_words(n) words
-uint64_t scan_tmp_words(uint64_t n) {
+}  // namespace
+
+// in-place capable (in == out); tmp must hold scan_u32_tmp_words(n) words
+uint64_t scan_u32_tmp_words(uint64_t n) {
     uint64_t w = 0;
     while (n > kScanTile) { n = (n + kScanTile - 1) / kScanTile; w += n; }
     return w + 1;
@@ -100,6 +102,8 @@ hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uin
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)blocks), dim3(256), 0, stream, in, n, (const uint32_t*)tmp, out);
     return hipGetLastError();
 }
+
+namespace {
 
 // ---------------------------------------------------------------------------------------------------
 // radix passes
@@ -213,7 +217,7 @@ hipError_t radix_sort_pairs_u64_u32(void* tmp, size_t& tmp_bytes, uint64_t* keys
                                     hipStream_t stream) {
     const uint64_t tiles = (n + kTile - 1) / kTile;
     const uint64_t table = 256 * (tiles ? tiles : 1);
-    const size_t need = (table + scan_tmp_words(table) + 64) * sizeof(uint32_t);
+    const size_t need = (table + scan_u32_tmp_words(table) + 64) * sizeof(uint32_t);
     if (tmp == nullptr) { tmp_bytes = need; return hipSuccess; }
     if (tmp_bytes < need) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;

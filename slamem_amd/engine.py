@@ -172,8 +172,8 @@ class Index:
         return o.cpu().numpy().tobytes()
 
     # ---- GetMatches (slamem.c:90-207) for a batch ---------------------------------------------------------
-    def matcher(self, num_queries: int, both_strands: bool, mems_capacity: int) -> "Matcher":
-        return Matcher(self, num_queries, both_strands, mems_capacity)
+    def matcher(self, num_queries: int, both_strands: bool, mems_capacity: int, query_bytes: int) -> "Matcher":
+        return Matcher(self, num_queries, both_strands, mems_capacity, query_bytes)
 
     def find_mems(self, queries, offsets, min_len: int = 20, both_strands: bool = False):
         """Convenience: host arrays in, (mems structured array, block_offsets) out."""
@@ -188,7 +188,7 @@ class Index:
         od = torch.from_numpy(offsets.view(np.int64)).to(dev)
         cap = max(1024, q.shape[0] // 8 + 4 * num)
         while True:
-            m = self.matcher(num, both_strands, cap)
+            m = self.matcher(num, both_strands, cap, int(offsets[-1]) if num else 0)
             try:
                 total = m.run(qd, od, min_len)
                 break
@@ -205,16 +205,17 @@ class Index:
 class Matcher:
     """Pre-allocated output + workspace buffers for repeated slamem_find_mems_device calls (bench loop)."""
 
-    def __init__(self, index: Index, num_queries: int, both_strands: bool, mems_capacity: int):
+    def __init__(self, index: Index, num_queries: int, both_strands: bool, mems_capacity: int, query_bytes: int):
         self.index = index
         self.num_queries = int(num_queries)
         self.both = bool(both_strands)
         self.capacity = int(mems_capacity)
+        self.query_bytes = int(query_bytes)
         dev = index.device
         nb = self.num_queries * (2 if self.both else 1)
         need = C.c_uint64()
-        capi.check(capi.lib().slamem_find_mems_workspace_bytes(self.num_queries, int(self.both), self.capacity,
-                                                               C.byref(need)))
+        capi.check(capi.lib().slamem_find_mems_workspace_bytes(self.num_queries, int(self.both), self.query_bytes,
+                                                               self.capacity, C.byref(need)))
         self.workspace = torch.empty(int(need.value), dtype=torch.uint8, device=dev)
         self.mems = torch.empty((max(self.capacity, 1), 3), dtype=torch.int32, device=dev)
         self.block_offsets = torch.empty(nb + 1, dtype=torch.int64, device=dev)
@@ -224,7 +225,8 @@ class Matcher:
         dev = self.index.device
         total = C.c_uint64()
         rc = capi.lib().slamem_find_mems_device(
-            self.index._h, _ptr(queries_dev), _ptr(offsets_dev), self.num_queries, int(min_len), int(self.both),
+            self.index._h, _ptr(queries_dev), _ptr(offsets_dev), self.num_queries, self.query_bytes, int(min_len),
+            int(self.both),
             _ptr(self.mems), self.capacity, _ptr(self.block_offsets), _ptr(self.workspace), self.workspace.numel(),
             _stream_handle(dev), C.byref(total))
         self.last_total = int(total.value)

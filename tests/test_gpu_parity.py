@@ -160,7 +160,7 @@ def test_config2_known_answer_full_size(eng):
     assert st["num_samples"] == 85_214_690 and st["num_oversized_lcp"] == 1
     assert st["num_oversized_links"] == 1_573_293 and st["max_lcp"] == 26
     assert st["sum_lcp"] // (n + 1) == 12 and round(st["sum_link_distance"] / st["num_samples"], 2) == 43.93
-    m = idx.matcher(nreads, False, 4 * nreads)
+    m = idx.matcher(nreads, False, 4 * nreads, nreads * L)
     total = m.run(reads, offsets, 20)
     assert total == 2_412_288
     mems = m.mems[:total].cpu().numpy().view(np.uint32).astype(np.int64)

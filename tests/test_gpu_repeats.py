@@ -48,3 +48,46 @@ def test_repeat_family_matches_oracle(copies, divergence, both):
         assert np.array_equal(gm[f], om[f]), f
     print(f"repeat family x{copies} div {divergence}: {len(gm)} MEMs from 64 reads in {dt * 1e3:.1f} ms")
     g.close()
+
+
+@pytest.mark.parametrize("both", [False, True])
+def test_long_queries_sliced_across_lanes(both):
+    """Records longer than one slice (4096) are cut into work items scanned by different lanes with a warm-up;
+    exact matches longer than the warm-up (1024, 4096, ...) force the in-kernel restart with a longer one.
+    Output must equal the oracle's whole-record scan, in order."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from oracle import pyoracle as po
+    from slamem_amd import engine
+    rng = np.random.default_rng(77)
+    n = 300_000
+    t = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def mutated(a, b, p):
+        s = t[a:b].copy()
+        m = rng.random(b - a) < p
+        s[m] = rng.choice(alpha, size=int(m.sum()))
+        return s
+    comp = np.zeros(256, dtype=np.uint8)
+    for x, y in zip(b"ACGT", b"TGCA"):
+        comp[x] = y
+    qs = [mutated(1000, 21000, 0.01),                                   # 20 kbp, short exact runs
+          np.concatenate([mutated(50000, 60000, 0.02), t[100000:130000], mutated(200000, 205000, 0.0)]),  # 30 kbp identical
+          t[5:4101].copy(),                                             # exactly one slice + 0
+          t[7000:7000 + 4097].copy(),                                   # slice + 1
+          comp[t[150000:170000][::-1]],                                 # reverse-complement of 20 kbp, identical
+          mutated(250000, 250150, 0.02), np.frombuffer(b"N" * 5000, dtype=np.uint8),
+          rng.choice(alpha, size=9000)]
+    q = np.concatenate(qs)
+    off = np.zeros(len(qs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in qs])
+    o = po.OracleIndex(t.tobytes())
+    om, obc = o.match_batch(q, off, 20, both)
+    g = engine.Index.build(t.tobytes())
+    gm, goff = g.find_mems(q, off, 20, both)
+    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+    for f in ("ref_pos", "query_pos", "length"):
+        assert np.array_equal(gm[f], om[f]), f
+    g.close()
