@@ -389,7 +389,8 @@ namespace {
 
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
@@ -471,17 +472,6 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
     hdr.total_bytes = off;
 
-    DevBuf arena;
-    if (arena.alloc(hdr.total_bytes) != hipSuccess) {
-        set_error("slamem_index_build: cannot allocate %llu bytes of HBM for the index", (unsigned long long)hdr.total_bytes);
-        return SLAMEM_ERR_NOMEM;
-    }
-    char* base = arena.as<char>();
-    FMBlock* d_fm = reinterpret_cast<FMBlock*>(base + hdr.off_fm);
-    RowRec* d_rec = reinterpret_cast<RowRec*>(base + hdr.off_rec);
-    uint32_t* d_nrows = reinterpret_cast<uint32_t*>(base + hdr.off_nrows);
-    SLAMEM_HIP(hipMemsetAsync(base, 0, kHeaderBytes, stream));
-
     // ---- K2: suffix sort ----------------------------------------------------------------------
     DevBuf keysA, keysB, valsA, valsB, rank, flagA, flagB, tmp32, gh, posA, posB, sorttmp, sabuf;
     if (sabuf.alloc(R * 4) != hipSuccess || keysA.alloc(R * 8) != hipSuccess || keysB.alloc(R * 8) != hipSuccess || valsA.alloc(R * 4) != hipSuccess ||
@@ -561,15 +551,30 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_sort_ms, ev.a, ev.b));
     hdr.sort_rounds = rounds;
     // rank[] is now the inverse suffix array.
+    // the sort's scratch is dead: free it before the arena and the LCP scratch are allocated (peak HBM at 3.1 Gbp:
+    // ~155 GB in the sort, ~145 GB afterwards)
+    keysB.release(); valsA.release(); valsB.release(); flagB.release(); tmp32.release(); gh.release();
+    posA.release(); posB.release();
+    DevBuf arena;
+    if (arena.alloc(hdr.total_bytes) != hipSuccess) {
+        set_error("slamem_index_build: cannot allocate %llu bytes of HBM for the index", (unsigned long long)hdr.total_bytes);
+        return SLAMEM_ERR_NOMEM;
+    }
+    char* base = arena.as<char>();
+    FMBlock* d_fm = reinterpret_cast<FMBlock*>(base + hdr.off_fm);
+    RowRec* d_rec = reinterpret_cast<RowRec*>(base + hdr.off_rec);
+    uint32_t* d_nrows = reinterpret_cast<uint32_t*>(base + hdr.off_nrows);
+    SLAMEM_HIP(hipMemsetAsync(base, 0, kHeaderBytes, stream));
+
 
     // ---- K3: BWT planes + rank samples ------------------------------------------------------------
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
     SLAMEM_HIP(hipMemsetAsync(d_fm, 0, (uint64_t)nblocks * sizeof(FMBlock), stream));
-    uint4* d_half = keysA.as<uint4>();            // 2*nblocks uint4  (scratch reuse: R*8 bytes >= nblocks*32)
-    uint4* d_blk = keysB.as<uint4>();             // nblocks uint4
-    uint4* d_pre = d_blk + nblocks;               // nblocks uint4   (nblocks*32 <= R*8 holds for R >= 4*nblocks)
+    uint4* d_half = keysA.as<uint4>();            // 2*nblocks uint4  (scratch reuse: 4*nblocks*16 <= R*8 for R >= 8*nblocks)
+    uint4* d_blk = d_half + 2 * (uint64_t)nblocks;  // nblocks uint4
+    uint4* d_pre = d_blk + nblocks;               // nblocks uint4
     DevBuf small;                                 // tiny texts: the aliasing bound above fails, use a private buffer
-    if ((uint64_t)nblocks * 32 > R * 8) {
+    if ((uint64_t)nblocks * 64 > R * 8) {
         SLAMEM_HIP(small.alloc((uint64_t)nblocks * 64));
         d_half = small.as<uint4>();
         d_blk = d_half + 2 * (uint64_t)nblocks;

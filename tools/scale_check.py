@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Large-n check of the index build and the search (sizes where no CPU oracle fits in the time budget):
+size-independent properties only -- every sampled MEM is a real match and maximal on both sides (checked
+against the text itself), MEMs per read and structure statistics stay where theory puts them.
+
+    tools/scale_check.py <n> [reads]        e.g. 1000000000, 2200000000 (> 2^31: 32-bit row arithmetic)
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from slamem_amd import engine  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1])
+    nreads = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+    L = 150
+    dev = torch.device("cuda:0")
+    ref = engine.synth_reference(n, 42, dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    idx = engine.Index.build(ref, dev)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    tm = {k: round(v, 1) for k, v in engine.timings().items() if k.startswith("build_")}
+    st = idx.sampled_lcp_stats()
+    reads = engine.synth_reads(ref, 0, nreads, L, 0.02, 42, 50)
+    offsets = torch.arange(nreads + 1, dtype=torch.int64, device=dev) * L
+    m = idx.matcher(nreads, True, 8 * nreads, nreads * L)
+    m.run(reads, offsets, 20)
+    engine.reset_timings()
+    total = m.run(reads, offsets, 20)
+    kms = engine.timings()["search_kernel_ms"]
+    mems = m.mems[:total].cpu().numpy().view(np.uint32).astype(np.int64)
+    boff = m.block_offsets[: 2 * nreads + 1].cpu().numpy()
+    blk = np.repeat(np.arange(2 * nreads), np.diff(boff))
+    ref_h = ref.cpu().numpy()
+    reads_h = reads[: nreads * L].cpu().numpy().reshape(nreads, L)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[:] = np.arange(256)
+    for x, y in zip(b"ACGT", b"TGCA"):
+        comp[x] = y
+    r, q, ln = mems[:, 0], mems[:, 1], mems[:, 2]
+    assert (ln >= 20).all() and (q + ln <= L).all() and (r + ln <= n).all()
+    bad = 0
+    sel = np.random.default_rng(0).choice(total, size=min(total, 50_000), replace=False)
+    for i in sel:
+        a, b, c, g = int(r[i]), int(q[i]), int(ln[i]), int(blk[i])
+        rd = reads_h[g >> 1]
+        if g & 1:
+            rd = comp[rd[::-1]]
+        ok = (ref_h[a:a + c] == rd[b:b + c]).all()
+        ok = ok and (a == 0 or b == 0 or ref_h[a - 1] != rd[b - 1])
+        ok = ok and (a + c == n or b + c == L or ref_h[a + c] != rd[b + c])
+        bad += not ok
+    out = {"n": n, "reads": nreads, "build_wall_s": round(build_s, 3), "build_ms": tm, "sort_rounds": int(idx.info.sort_rounds),
+           "max_lcp": int(idx.info.max_lcp), "index_GB": round(idx.info.arena_bytes / 1e9, 2),
+           "samples_pct": round(100.0 * st["num_samples"] / (n + 1), 2), "mean_lcp": st["sum_lcp"] // (n + 1),
+           "mems": int(total), "mems_per_read": round(total / nreads, 3), "checked": int(len(sel)), "bad": int(bad),
+           "search_kernel_ms": round(kms, 2), "Mreads_per_s": round(nreads / kms / 1e3, 2)}
+    print(json.dumps(out))
+    assert bad == 0
+
+
+if __name__ == "__main__":
+    main()
