@@ -91,3 +91,38 @@ def test_long_queries_sliced_across_lanes(both):
     for f in ("ref_pos", "query_pos", "length"):
         assert np.array_equal(gm[f], om[f]), f
     g.close()
+
+
+def test_reference_with_long_diverged_repeats_builds_exactly():
+    """SURVEY.md 8(d) repeat model: 0.5 % of the text copied as 1-10 kbp segments with 1 % divergence, plus one
+    exact 40 kbp duplication (LCP 40,000 -> 12 prefix-doubling rounds).  SA / LCP / links must equal the oracle's."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from oracle import pyoracle as po
+    from slamem_amd import capi, engine
+    rng = np.random.default_rng(123)
+    n = 3_000_000
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    t = rng.choice(alpha, size=n)
+    copied = 0
+    while copied < n // 200:
+        L = int(rng.integers(1000, 10000))
+        a, b = int(rng.integers(0, n - L)), int(rng.integers(0, n - L))
+        seg = t[a:a + L].copy()
+        m = rng.random(L) < 0.01
+        seg[m] = rng.choice(alpha, size=int(m.sum()))
+        t[b:b + L] = seg
+        copied += L
+    t[2_000_000:2_040_000] = t[500_000:540_000]
+    text = t.tobytes()
+    o = po.OracleIndex(text)
+    g = engine.Index.build(text)
+    assert int(g.info.max_lcp) >= 40_000 and int(g.info.sort_rounds) >= 12
+    assert np.array_equal(g.download(capi.ARRAY_SA).astype(np.int64), o.sa)
+    assert np.array_equal(g.download(capi.ARRAY_LCP).astype(np.int64), o.lcp)
+    assert np.array_equal(g.download(capi.ARRAY_PSV).astype(np.int64)[1:n + 1], o.psv[1:n + 1])
+    assert np.array_equal(g.download(capi.ARRAY_NSV).astype(np.int64)[1:n + 1], o.nsv[1:n + 1])
+    print("build timings", {k: round(v, 1) for k, v in engine.timings().items() if k.startswith("build_")},
+          "rounds", int(g.info.sort_rounds))
+    g.close()
