@@ -80,6 +80,8 @@ int main(int argc, char **argv) {
     if ((env = getenv("SLAMEM_VERBOSE")) != NULL && atoi(env) != 0) log_limit = 0;
     if ((env = getenv("SLAMEM_BATCH_MB")) != NULL && atoll(env) > 0) batch_bytes = (uint64_t)atoll(env) << 20;
 
+    double t_start = now_s(), t_load = 0, t_build = 0, t_gpu = 0, t_format = 0, t_write = 0;
+    int timing = getenv("SLAMEM_TIMING") != NULL;
     /* load everything (slamem.c:635-651) */
     memset(&ref, 0, sizeof(ref));
     qsets = (slh_seqset *)calloc((size_t)o.num_files, sizeof(slh_seqset));
@@ -101,6 +103,7 @@ int main(int argc, char **argv) {
         }
     }
     if (num_qsets == 0) exit_message("No query files provided"); /* slamem.c:648 */
+    t_load = now_s() - t_start;
     printf("> %d reference%s and %d quer%s successfully loaded\n", ref.num, ref.num == 1 ? "" : "s", total_queries,
            total_queries == 1 ? "y" : "ies");
     if (o.min_mem_len < 1) exit_message("Minimum match length must be at least 1");
@@ -148,6 +151,7 @@ int main(int argc, char **argv) {
                    (long long)st.max_link_distance);
         }
     }
+    t_build = now_s() - t0;
     free(ref.chars); /* the reference frees the text here too (slamem.c:75-77) */
     ref.chars = NULL;
     printf("> Matching query sequences against index ...\n");
@@ -168,9 +172,12 @@ int main(int argc, char **argv) {
                 offs = (uint64_t *)malloc(((size_t)(last - first) + 1) * sizeof(uint64_t));
                 if (!offs) exit_message("Out of memory");
                 for (i = first; i <= last; i++) offs[i - first] = q->offsets[i] - base;
+                double tg = now_s();
                 rc = slamem_find_mems_host(idx, q->chars + base, offs, (uint32_t)(last - first), (uint32_t)o.min_mem_len,
                                            o.both_strands, &mems, &boff, &total);
                 if (rc != SLAMEM_OK) gpu_fail("MEM search on the GPU", rc);
+                t_gpu += now_s() - tg;
+                tg = now_s();
                 for (i = first; i < last; i++) {
                     int s;
                     for (s = 0; s < strands; s++) {
@@ -190,10 +197,13 @@ int main(int argc, char **argv) {
                         }
                     }
                     if (buf.len > (64u << 20)) {
+                        double tw = now_s();
                         if (fwrite(buf.data, 1, buf.len, out) != buf.len) exit_message("Cannot write output file");
                         buf.len = 0;
+                        t_write += now_s() - tw;
                     }
                 }
+                t_format += now_s() - tg;
                 slamem_host_free(mems);
                 slamem_host_free(boff);
                 free(offs);
@@ -221,5 +231,8 @@ int main(int argc, char **argv) {
     free(qsets);
     slh_free_options(&o);
     printf("> Done!\n");
+    if (timing)
+        fprintf(stderr, "[timing] load %.3f s, index build %.3f s, GPU search incl. transfers %.3f s, format %.3f s (of which write %.3f s), total %.3f s\n",
+                t_load, t_build, t_gpu, t_format - t_write, t_write, now_s() - t_start);
     return 0;
 }

@@ -27,6 +27,29 @@ typedef struct {
     const unsigned char *p, *end;
 } reader;
 
+/* record names are carved out of large chunks (10 M reads = 10 M names: one malloc each would dominate) */
+typedef struct name_chunk {
+    struct name_chunk *next;
+    size_t used, cap;
+    char data[1];
+} name_chunk;
+
+static char *name_alloc(void **arena, size_t len) {
+    name_chunk *c = (name_chunk *)*arena;
+    if (!c || c->used + len > c->cap) {
+        size_t cap = len > (1u << 20) ? len : (1u << 20);
+        name_chunk *n = (name_chunk *)malloc(sizeof(name_chunk) + cap);
+        if (!n) return NULL;
+        n->next = c;
+        n->used = 0;
+        n->cap = cap;
+        *arena = n;
+        c = n;
+    }
+    c->used += len;
+    return c->data + c->used - len;
+}
+
 static int rd(reader *r) { return r->p < r->end ? (int)*r->p++ : EOF; }
 
 static int grow(char **buf, uint64_t *cap, uint64_t need) {
@@ -43,7 +66,12 @@ static int grow(char **buf, uint64_t *cap, uint64_t need) {
 void slh_free_seqset(slh_seqset *s) {
     int i;
     if (!s) return;
-    for (i = 0; i < s->num; i++) free(s->recs[i].name);
+    (void)i;
+    while (s->name_arena) {
+        name_chunk *c = (name_chunk *)s->name_arena;
+        s->name_arena = c->next;
+        free(c);
+    }
     free(s->recs);
     free(s->chars);
     free(s->offsets);
@@ -93,6 +121,8 @@ int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, 
         return 0;
     }
     init_table(table, !acgt_only);
+    table['>'] = (char)0xFF; /* record terminator for the fast path below */
+    if (grow(&chars, &cap, (uint64_t)fsize + 16)) goto oom; /* characters (+ separators) never outnumber the file's bytes */
     for (;;) { /* all records of the file (sequence.c:128) */
         const unsigned char *name_start;
         int quiet;
@@ -128,10 +158,25 @@ int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, 
         }
         {
             uint64_t rec_start = seqlen;
+            if (!merge) { /* query records: tight, branch-light copy loop (the 'N' separator logic is reference-only) */
+                const unsigned char *p = r.p, *pe = r.end;
+                unsigned char *dst = (unsigned char *)chars + seqlen;
+                while (p < pe) {
+                    unsigned char t = (unsigned char)table[*p];
+                    if (t == 0xFF) break;
+                    p++;
+                    *dst = t;
+                    dst += (t != 0);
+                }
+                seqsize = (uint32_t)(dst - ((unsigned char *)chars + seqlen));
+                seqlen += seqsize;
+                c = p < pe ? '>' : EOF;
+                r.p = p < pe ? p + 1 : p;
+                maxseqlen = seqlen;
+            } else
             while ((c = rd(&r)) != '>' && c != EOF) {
                 char t = table[c];
                 if (t) {
-                    if (grow(&chars, &cap, seqlen + 3)) goto oom;
                     if (seqlen == maxseqlen) { /* sequence.c:160-166 */
                         maxseqlen += (1u << 20);
                         if (merge && numseqs != 0 && seqsize == 0) chars[seqlen++] = 'N';
@@ -165,7 +210,7 @@ int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, 
                 out->recs = nr;
                 reccap = nc;
             }
-            out->recs[numseqs].name = (char *)malloc((size_t)desclen + 1);
+            out->recs[numseqs].name = name_alloc(&out->name_arena, (size_t)desclen + 1);
             if (!out->recs[numseqs].name) goto oom;
             memcpy(out->recs[numseqs].name, name_start, (size_t)desclen);
             out->recs[numseqs].name[desclen] = '\0';

@@ -29,6 +29,7 @@ typedef struct {
     uint64_t *offsets;      /* !merge: num+1 start offsets into chars                                */
     uint32_t *merged_start; /* merge: start of record k in chars (sequence.c:260-262)                */
     long file_bytes;
+    void *name_arena;       /* owns the name strings */
 } slh_seqset;
 
 /* LoadSequencesFromFile (sequence.c:89-270).  merge=1 for the reference file (records joined by 'N',

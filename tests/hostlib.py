@@ -13,7 +13,8 @@ class Record(C.Structure):
 
 class SeqSet(C.Structure):
     _fields_ = [("recs", C.POINTER(Record)), ("num", C.c_int), ("chars", C.POINTER(C.c_char)), ("total", C.c_uint64),
-                ("offsets", C.POINTER(C.c_uint64)), ("merged_start", C.POINTER(C.c_uint32)), ("file_bytes", C.c_long)]
+                ("offsets", C.POINTER(C.c_uint64)), ("merged_start", C.POINTER(C.c_uint32)), ("file_bytes", C.c_long),
+                ("name_arena", C.c_void_p)]
 
 
 class Options(C.Structure):

@@ -183,3 +183,31 @@ def test_config2_known_answer_full_size(eng):
     lines = b"".join(b"%d\t%d\t%d\n" % (r[i] + 1, q[i] + 1, ln[i]) for i in order)
     assert hashlib.sha256(lines).hexdigest().startswith("9d583ab9312e1698")
     idx.close()
+
+
+def test_capacity_error_reports_the_need_and_retry_succeeds(eng):
+    """SLAMEM_ERR_CAPACITY contract: the call fails loudly, total_out holds the room to ask for, a retry works."""
+    import torch
+    from slamem_amd import capi
+    rng = np.random.default_rng(21)
+    text = rand_text(rng, 20000, "ACGT", 30, max_rep=400)
+    qs = make_queries(rng, text, 200, "ACGT")
+    q, off = pack(qs)
+    idx = eng.Index.build(text)
+    qd = torch.zeros((len(q) + 15) // 8 * 8, dtype=torch.uint8, device="cuda:0")
+    qd[: len(q)] = torch.from_numpy(q.copy()).to("cuda:0")
+    od = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+    small = idx.matcher(len(qs), True, 3, int(off[-1]))
+    with pytest.raises(capi.SlamemError) as ei:
+        small.run(qd, od, 5)
+    assert ei.value.code == capi.SLAMEM_ERR_CAPACITY and small.last_total > 3
+    big = idx.matcher(len(qs), True, small.last_total, int(off[-1]))
+    total = big.run(qd, od, 5)
+    ref, _ = idx.find_mems(q, off, 5, True)
+    assert total == len(ref) <= small.last_total
+    got = big.mems[:total].cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[:, 0], ref["ref_pos"]) and np.array_equal(got[:, 2], ref["length"])
+    # degenerate batches
+    e, eo = idx.find_mems(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64), 20, True)
+    assert len(e) == 0 and list(eo) == [0]
+    idx.close()
