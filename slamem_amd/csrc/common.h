@@ -15,7 +15,8 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 2;
+constexpr uint32_t kArenaVersion = 3;
+constexpr uint32_t kFilterK = 18;  // letters per k-mer of the presence filter
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -53,6 +54,9 @@ struct ArenaHeader {
     uint64_t off_fm;      // FMBlock[nblocks]
     uint64_t off_rec;     // RowRec[n+2]    per-row {LCP+1, PSV, NSV, SA}
     uint64_t off_nrows;   // uint32[num_n]  sorted BWT rows holding N
+    uint64_t off_kfilter; // uint64[1 << kfilter_log2]  k-mer presence filter (0 = absent)
+    uint32_t kfilter_log2;
+    uint32_t kfilter_k;
     uint32_t nblocks;
     uint32_t dollar_row;
     uint32_t num_n;
@@ -68,11 +72,26 @@ struct IndexView {
     const FMBlock* fm;
     const RowRec* rec;
     const uint32_t* nrows;
+    const uint64_t* kfilter;  // nullptr when the index has no presence filter
     uint32_t n;
     uint32_t nblocks;
     uint32_t dollar_row;
     uint32_t num_n;
+    uint32_t kfilter_log2;
+    uint32_t kfilter_k;
 };
+
+// Presence filter: one 64-bit word per k-mer hash, two bits per k-mer inside that word (a blocked Bloom filter:
+// one memory access per query, false-positive rate ~ (2 * distinct k-mers / bits)^2).
+__host__ __device__ inline uint64_t kfilter_hash(uint64_t kmer) {
+    kmer ^= kmer >> 33;
+    kmer *= 0xff51afd7ed558ccdull;
+    kmer ^= kmer >> 33;
+    kmer *= 0xc4ceb9fe1a85ec53ull;
+    kmer ^= kmer >> 33;
+    return kmer;
+}
+__host__ __device__ inline uint64_t kfilter_bits(uint64_t h) { return (1ull << ((h >> 52) & 63u)) | (1ull << ((h >> 58) & 63u)); }
 
 // Raw record written by the search kernel before the per-block compaction (K9).
 struct RawKey { uint32_t block; uint32_t k; };

@@ -205,6 +205,25 @@ __global__ void __launch_bounds__(256) k_rank_samples(const uint4* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// K1b: k-mer presence filter (not in the reference: lets the search skip strands that share no k-mer with the
+// text, e.g. the wrong strand of every read).  One lane per text position; windows containing N are not entered
+// (a query window with N is treated as present, so N == N matches are never filtered out).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
+                                                       uint32_t log2_words, unsigned long long* __restrict__ filter) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + k > n) return;
+    uint64_t km = 0;
+    for (uint32_t d = 0; d < k; d++) {
+        uint32_t c = nibble_at(pk, i + d);
+        if (c < 2u) return;  // N inside the window
+        km = (km << 2) | (uint64_t)(c - 2u);
+    }
+    uint64_t h = kfilter_hash(km);
+    atomicOr(&filter[h & ((1ull << log2_words) - 1ull)], (unsigned long long)kfilter_bits(h));
+}
+
+// ------------------------------------------------------------------------------------------
 // K5: exact LCP in text order (Kasai): one thread per chunk of text positions, the match length
 // carried from position i to i+1 never drops by more than one.  Stores LCP+1 (0 = "-1" sentinel).
 // ------------------------------------------------------------------------------------------
@@ -413,6 +432,9 @@ void make_view(slamem_index* idx) {
     idx->view.fm = reinterpret_cast<const FMBlock*>(base + h.off_fm);
     idx->view.rec = reinterpret_cast<const RowRec*>(base + h.off_rec);
     idx->view.nrows = reinterpret_cast<const uint32_t*>(base + h.off_nrows);
+    idx->view.kfilter = h.off_kfilter ? reinterpret_cast<const uint64_t*>(base + h.off_kfilter) : nullptr;
+    idx->view.kfilter_log2 = h.kfilter_log2;
+    idx->view.kfilter_k = h.kfilter_k;
     idx->view.n = h.n;
     idx->view.nblocks = h.nblocks;
     idx->view.dollar_row = h.dollar_row;
@@ -470,6 +492,18 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     hdr.off_fm = off;    off = align_up(off + (uint64_t)nblocks * sizeof(FMBlock), 256);
     hdr.off_rec = off;   off = align_up(off + (R + 1) * sizeof(RowRec), 256);
     hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
+    {   // k-mer presence filter: 64 bits per text character (rounded up to a power of two of words), n >= k only
+        const char* kf = getenv("SLAMEM_KFILTER");
+        bool want = !(kf && atoi(kf) == 0) && n >= kFilterK;
+        if (want) {
+            uint32_t lg = 10;
+            while ((1ull << lg) < (uint64_t)n && lg < 32) lg++;
+            hdr.off_kfilter = off;
+            hdr.kfilter_log2 = lg;
+            hdr.kfilter_k = kFilterK;
+            off = align_up(off + (8ull << lg), 256);
+        }
+    }
     hdr.total_bytes = off;
 
     // ---- K2: suffix sort ----------------------------------------------------------------------
@@ -565,6 +599,13 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     RowRec* d_rec = reinterpret_cast<RowRec*>(base + hdr.off_rec);
     uint32_t* d_nrows = reinterpret_cast<uint32_t*>(base + hdr.off_nrows);
     SLAMEM_HIP(hipMemsetAsync(base, 0, kHeaderBytes, stream));
+    if (hdr.off_kfilter) {
+        unsigned long long* d_filter = reinterpret_cast<unsigned long long*>(base + hdr.off_kfilter);
+        SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));
+        hipLaunchKernelGGL(k_kfilter_build, dim3(grid_for((uint64_t)n - kFilterK + 1)), dim3(256), 0, stream, pk.as<uint64_t>(),
+                           n, kFilterK, hdr.kfilter_log2, d_filter);
+        SLAMEM_HIP(hipGetLastError());
+    }
 
 
     // ---- K3: BWT planes + rank samples ------------------------------------------------------------

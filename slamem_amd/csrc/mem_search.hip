@@ -169,6 +169,9 @@ struct SearchArgs {
     const struct ItemDesc* items; // v3: work items in emission order
     uint64_t num_items;
     uint8_t* item_attempt;      // v3: attempt whose records are the valid ones
+    const uint8_t* item_alive;  // v3: nullptr, or 0 for items the k-mer presence filter proved empty
+    const uint32_t* work_ids;   // v3: nullptr (work = all items), or the ids of the items that survived the prefilter
+    const uint32_t* work_count; // v3: device word holding their number
 };
 
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
@@ -392,7 +395,9 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     const IndexView& ix = A.ix;
     const int L = (int)A.min_len;
     const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
-    const uint64_t nitems = A.num_items;
+    __shared__ uint32_t lds_id[4][kChunkMax];
+    // the work list: every item, or only those that survived the prefilter (dense, so no lane idles on dead items)
+    const uint64_t nitems = A.work_ids ? (uint64_t)*A.work_count : A.num_items;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * A.chunk;  // wave-uniform: first unassigned work item of this wave's chunk
@@ -400,7 +405,11 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     const uint64_t chunk_first = next;
     const uint64_t chunk_end = next + A.chunk < nitems ? next + A.chunk : nitems;
     // item descriptors of the chunk -> LDS (one coalesced read per wave instead of a round trip per item)
-    for (uint64_t i = chunk_first + lane; i < chunk_end; i += 64u) lds_item[wv][i - chunk_first] = A.items[i];
+    for (uint64_t i = chunk_first + lane; i < chunk_end; i += 64u) {
+        uint32_t id = A.work_ids ? A.work_ids[i] : (uint32_t)i;
+        lds_id[wv][i - chunk_first] = id;
+        lds_item[wv][i - chunk_first] = A.items[id];
+    }
     __syncthreads();
 
     bool active = false, st_rec = false, st_flush = false, pend = false;
@@ -422,7 +431,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             uint64_t cand = next + rank;
             if (!active && cand < chunk_end) {
-                g = (uint32_t)cand;
+                g = lds_id[wv][cand - chunk_first];
                 ItemDesc d = lds_item[wv][cand - chunk_first];
                 qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
                 uint32_t sl = d.slice_rev & 0x7FFFFFFFu;
@@ -431,8 +440,10 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 attempt = 0;
                 j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
                 top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st_rec = false; st_flush = false; k = 0;
-                if (d.len == 0) { A.block_counts[g] = 0; A.item_attempt[g] = 0; }  // empty record: nothing to scan
-                else active = true;
+                if (d.len == 0) {  // empty record: nothing to scan
+                    A.block_counts[g] = 0;
+                    A.item_attempt[g] = 0;
+                } else active = true;
             }
             next += (uint64_t)__popcll(idle);
         }
@@ -575,6 +586,52 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     }
 }
 
+// K8a: presence prefilter.  A MEM of length >= L that starts in the item's slice [a,b) contains a k-mer window
+// starting at a multiple of s = L-k+1 inside [a, b+s-2]; if none of those windows occurs in the text (filter says
+// "absent": no false negatives) the item cannot emit anything and K8 skips it.  Windows holding an N count as
+// present.  One lane per item, early exit at the first present window (the matching strand of a read exits after
+// a few probes; the other strand pays ~ len/s probes instead of a full scan).
+__global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __restrict__ alive) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.num_items) return;
+    const IndexView& ix = A.ix;
+    ItemDesc d = A.items[g];
+    const uint32_t k = ix.kfilter_k, L = A.min_len;
+    const uint32_t s = L - k + 1u;
+    uint32_t sl = d.slice_rev & 0x7FFFFFFFu;
+    uint32_t a = sl * kSliceLen;
+    uint32_t b = d.len - a < kSliceLen ? d.len : a + kSliceLen;
+    uint8_t res = 0;
+    if (d.len >= k && d.len - a >= 1u) {
+        uint64_t p0 = ((uint64_t)a + s - 1) / s * s;            // first sampled window start >= a
+        uint64_t pmax = (uint64_t)b + s - 2;                     // last window start that can serve this slice
+        if (pmax > d.len - k) pmax = d.len - k;
+        if (p0 <= pmax) {
+            QueryCursor qc;
+            qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
+            const uint64_t mask = (1ull << (2u * k)) - 1ull, wmask = (1ull << ix.kfilter_log2) - 1ull;
+            uint64_t km = 0;
+            uint32_t run = 0;
+            for (uint64_t x = p0; x <= pmax + k - 1 && !res; x++) {
+                uint32_t c = qc.at((uint32_t)x);
+                if (c >= 2u) { km = ((km << 2) | (uint64_t)(c - 2u)) & mask; run++; }
+                else { km = 0; run = 0; }
+                if (x + 1 >= p0 + k) {
+                    uint64_t p = x + 1 - k;                     // window [p, p+k)
+                    if (p % s == 0) {
+                        if (run < k) res = 1;                   // holds an N: cannot be ruled out
+                        else {
+                            uint64_t h = kfilter_hash(km), bits = kfilter_bits(h);
+                            if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    alive[g] = res;
+}
+
 // K9 for v3: inline slots and overflow records -> grouped output, BWT rows resolved to text positions here
 __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__ inl, const uint32_t* __restrict__ counts,
                                                       const uint64_t* __restrict__ item_off, uint64_t nitems,
@@ -709,7 +766,7 @@ inline unsigned grid_for(uint64_t items, unsigned block = 256) { return (unsigne
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_itemoff, off_rawkey,
+    uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_alive, off_workids, off_select, select_bytes, off_itemoff, off_rawkey,
         off_rawmem, off_inline, off_scan, scan_bytes, max_items, bytes;
 };
 
@@ -725,6 +782,15 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     w.off_items = off;    off = align_up(off + w.max_items * sizeof(ItemDesc), 256);
     w.off_counts = off;   off = align_up(off + (w.max_items + 1) * 4, 256);
     w.off_attempt = off;  off = align_up(off + w.max_items, 256);
+    w.off_alive = off;    off = align_up(off + w.max_items, 256);
+    w.off_workids = off;  off = align_up(off + w.max_items * 4, 256);
+    {
+        size_t need2 = 0;
+        (void)select_indices_u32(nullptr, need2, nullptr, nullptr, nullptr, w.max_items, 0);
+        w.select_bytes = need2;
+        w.off_select = off;
+        off = align_up(off + need2, 256);
+    }
     w.off_itemoff = off;  off = align_up(off + (w.max_items + 1) * 8, 256);
     w.off_rawkey = off;   off = align_up(off + capacity * sizeof(RawKey), 256);
     w.off_rawmem = off;   off = align_up(off + capacity * sizeof(slamem_mem), 256);
@@ -833,6 +899,22 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first,
                                num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items));
             STEP(hipGetLastError(), "k_item_fill");
+            static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
+            if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
+                uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
+                hipLaunchKernelGGL(k_prefilter, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
+                STEP(hipGetLastError(), "k_prefilter");
+                A.item_alive = d_alive;
+                // dead items emit nothing: their counts are zero; the survivors become a dense work list
+                STEP(hipMemsetAsync(d_counts, 0, nitems * 4, stream), "memset");
+                STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
+                uint32_t* d_ids = reinterpret_cast<uint32_t*>(ws + w.off_workids);
+                uint32_t* d_nwork = reinterpret_cast<uint32_t*>(d_total) + 8;  // a word of the zeroed scalar block
+                size_t need2 = w.select_bytes;
+                STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
+                A.work_ids = d_ids;
+                A.work_count = d_nwork;
+            }
             uint64_t waves = (nitems + A.chunk - 1) / A.chunk;
             hipLaunchKernelGGL(k_find_mems_v3, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             STEP(hipGetLastError(), "k_find_mems_v3");
