@@ -11,7 +11,7 @@ already resident in HBM.  Reads shard across ranks with no data-path collective 
 matches its own 10 M reads); the index is built once on rank 0 and broadcast over RCCL/xGMI, and per-rank
 MEM counts are gathered every step.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_find_mems_v3) by the fixed
+Rank 0 prints ONE JSON line.  `roofline` prices the hot path's kernels (k_prefilter + k_find_mems_v3, timed together) by the fixed
 reference-layout byte formula of SURVEY.md 8(d); `cpu_baseline` times the oracle (our CPU restatement of
 the reference algorithm, single thread) on a bounded sample of the same reads on this box's host cores.
 """
@@ -180,7 +180,7 @@ def main():
             "index_build_ms": build_t,
             "index_bytes": arena_bytes,
             "index_broadcast_s": bcast_s,
-            "kernel": "k_find_mems_v3",
+            "kernel": "k_prefilter + k_find_mems_v3 (K8a + K8, timed together with HIP events)",
             "kernel_ms": kernel_ms,
         }
         bytes_per_base = FIXED_BYTES_PER_BASE
