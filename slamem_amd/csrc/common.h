@@ -16,7 +16,6 @@ namespace slamem {
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
 constexpr uint32_t kArenaVersion = 3;
-constexpr uint32_t kFilterK = 18;  // letters per k-mer of the presence filter
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;

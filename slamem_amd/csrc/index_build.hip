@@ -494,13 +494,19 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
     {   // k-mer presence filter: 64 bits per text character (rounded up to a power of two of words), n >= k only
         const char* kf = getenv("SLAMEM_KFILTER");
-        bool want = !(kf && atoi(kf) == 0) && n >= kFilterK;
+        // k grows with the text: a random k-mer occurs with probability ~ n / 4^k, which must stay well below
+        // 1 / (probes per strand) for the filter to discriminate; k = ceil(log4 n) + 4 keeps it near 0.2 %
+        uint32_t kf_k = 4;
+        for (uint64_t v = 1; v < (uint64_t)n; v <<= 2) kf_k++;
+        if (kf_k < 12) kf_k = 12;
+        if (kf_k > 31) kf_k = 31;
+        bool want = !(kf && atoi(kf) == 0) && n >= kf_k;
         if (want) {
             uint32_t lg = 10;
             while ((1ull << lg) < (uint64_t)n && lg < 32) lg++;
             hdr.off_kfilter = off;
             hdr.kfilter_log2 = lg;
-            hdr.kfilter_k = kFilterK;
+            hdr.kfilter_k = kf_k;
             off = align_up(off + (8ull << lg), 256);
         }
     }
@@ -602,8 +608,8 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     if (hdr.off_kfilter) {
         unsigned long long* d_filter = reinterpret_cast<unsigned long long*>(base + hdr.off_kfilter);
         SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));
-        hipLaunchKernelGGL(k_kfilter_build, dim3(grid_for((uint64_t)n - kFilterK + 1)), dim3(256), 0, stream, pk.as<uint64_t>(),
-                           n, kFilterK, hdr.kfilter_log2, d_filter);
+        hipLaunchKernelGGL(k_kfilter_build, dim3(grid_for((uint64_t)n - hdr.kfilter_k + 1)), dim3(256), 0, stream,
+                           pk.as<uint64_t>(), n, hdr.kfilter_k, hdr.kfilter_log2, d_filter);
         SLAMEM_HIP(hipGetLastError());
     }
 
