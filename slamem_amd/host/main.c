@@ -15,6 +15,8 @@
 #include <string.h>
 #include <time.h>
 
+#include <pthread.h>
+
 #include "../../include/slamem_hip.h"
 #include "slamem_host.h"
 
@@ -35,6 +37,33 @@ static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* formatting of a range of strand blocks of one batch, one range per thread */
+typedef struct {
+    const slh_seqset *q;
+    const slh_seqset *ref;
+    const slamem_mem *mems;
+    const uint64_t *boff;
+    int first_rec, strands;
+    uint64_t b0, b1; /* strand blocks [b0,b1) of the batch */
+    slh_buffer buf;
+    long long matches, sum;
+    int failed;
+} fmt_job;
+
+static void *fmt_run(void *arg) {
+    fmt_job *j = (fmt_job *)arg;
+    uint64_t b;
+    for (b = j->b0; b < j->b1; b++) {
+        int i = j->first_rec + (int)(b / (uint64_t)j->strands), s = (int)(b % (uint64_t)j->strands);
+        uint64_t cnt = j->boff[b + 1] - j->boff[b], sum = 0;
+        if (slh_format_block(&j->buf, j->q->recs[i].name, s, (const uint32_t *)(j->mems + j->boff[b]), cnt, j->ref->recs,
+                             j->ref->merged_start, j->ref->num, &sum)) { j->failed = 1; return NULL; }
+        j->matches += (long long)cnt;
+        j->sum += (long long)sum;
+    }
+    return NULL;
 }
 
 static void usage(const char *prog) { /* slamem.c:533-553 */
@@ -178,29 +207,63 @@ int main(int argc, char **argv) {
                 if (rc != SLAMEM_OK) gpu_fail("MEM search on the GPU", rc);
                 t_gpu += now_s() - tg;
                 tg = now_s();
-                for (i = first; i < last; i++) {
-                    int s;
-                    for (s = 0; s < strands; s++) {
-                        uint64_t b = (uint64_t)(i - first) * strands + s, cnt = boff[b + 1] - boff[b], sum = 0;
-                        if (slh_format_block(&buf, q->recs[i].name, s, (const uint32_t *)(mems + boff[b]), cnt, ref.recs,
+                {
+                    /* the first strand blocks get their ':: "name" ....' line (slamem.c:97,101,203) and are formatted here;
+                       the rest of the batch is formatted by all host threads and written in order */
+                    uint64_t nblk = (uint64_t)(last - first) * strands, bseq = 0, b;
+                    int nthr = slh_thread_count(), t;
+                    if (log_limit == 0) bseq = nblk;
+                    else if (printed < log_limit) bseq = (uint64_t)(log_limit - printed) < nblk ? (uint64_t)(log_limit - printed) : nblk;
+                    for (b = 0; b < bseq; b++) {
+                        int ri = first + (int)(b / strands), s = (int)(b % strands), d, dots;
+                        uint64_t cnt = boff[b + 1] - boff[b], sum = 0;
+                        if (slh_format_block(&buf, q->recs[ri].name, s, (const uint32_t *)(mems + boff[b]), cnt, ref.recs,
                                              ref.merged_start, ref.num, &sum))
                             exit_message("Out of memory");
                         total_matches += (long long)cnt;
                         total_sum += (long long)sum;
-                        if (log_limit == 0 || printed < log_limit) { /* slamem.c:97,101,203 */
-                            int d, dots = slh_progress_dots(q->recs[i].size);
-                            printf(":: \"%s%s\" ", q->recs[i].name, s ? " Reverse" : "");
-                            for (d = 0; d < dots; d++) putchar('.');
-                            printf(" (%d M%cMs ; avg size = %d bp)\n", (int)cnt, MATCH_TYPE_CHAR[o.match_type],
-                                   (int)(cnt ? sum / cnt : 0));
-                            printed++;
-                        }
+                        dots = slh_progress_dots(q->recs[ri].size);
+                        printf(":: \"%s%s\" ", q->recs[ri].name, s ? " Reverse" : "");
+                        for (d = 0; d < dots; d++) putchar('.');
+                        printf(" (%d M%cMs ; avg size = %d bp)\n", (int)cnt, MATCH_TYPE_CHAR[o.match_type], (int)(cnt ? sum / cnt : 0));
+                        printed++;
                     }
-                    if (buf.len > (64u << 20)) {
+                    if (buf.len) {
                         double tw = now_s();
                         if (fwrite(buf.data, 1, buf.len, out) != buf.len) exit_message("Cannot write output file");
                         buf.len = 0;
                         t_write += now_s() - tw;
+                    }
+                    if (bseq < nblk) {
+                        fmt_job *jobs;
+                        pthread_t *tid;
+                        uint64_t per;
+                        if ((nblk - bseq) < 4096 || nthr < 1) nthr = 1;
+                        jobs = (fmt_job *)calloc((size_t)nthr, sizeof(fmt_job));
+                        tid = (pthread_t *)calloc((size_t)nthr, sizeof(pthread_t));
+                        if (!jobs || !tid) exit_message("Out of memory");
+                        per = (nblk - bseq + (uint64_t)nthr - 1) / (uint64_t)nthr;
+                        for (t = 0; t < nthr; t++) {
+                            jobs[t].q = q; jobs[t].ref = &ref; jobs[t].mems = mems; jobs[t].boff = boff;
+                            jobs[t].first_rec = first; jobs[t].strands = strands;
+                            jobs[t].b0 = bseq + per * (uint64_t)t < nblk ? bseq + per * (uint64_t)t : nblk;
+                            jobs[t].b1 = jobs[t].b0 + per < nblk ? jobs[t].b0 + per : nblk;
+                            if (t == nthr - 1 || pthread_create(&tid[t], NULL, fmt_run, &jobs[t]) != 0) { fmt_run(&jobs[t]); tid[t] = 0; }
+                        }
+                        for (t = 0; t < nthr; t++) {
+                            double tw;
+                            if (tid[t]) pthread_join(tid[t], NULL);
+                            if (jobs[t].failed) exit_message("Out of memory");
+                            total_matches += jobs[t].matches;
+                            total_sum += jobs[t].sum;
+                            tw = now_s();
+                            if (jobs[t].buf.len && fwrite(jobs[t].buf.data, 1, jobs[t].buf.len, out) != jobs[t].buf.len)
+                                exit_message("Cannot write output file");
+                            t_write += now_s() - tw;
+                            slh_buffer_free(&jobs[t].buf);
+                        }
+                        free(jobs);
+                        free(tid);
                     }
                 }
                 t_format += now_s() - tg;
@@ -210,7 +273,6 @@ int main(int argc, char **argv) {
                 first = last;
             }
         }
-        if (buf.len && fwrite(buf.data, 1, buf.len, out) != buf.len) exit_message("Cannot write output file");
         if (log_limit != 0 && (long)total_queries * strands > log_limit)
             printf(":: ... (%ld more strand blocks matched; set SLAMEM_VERBOSE=1 for a line each)\n",
                    (long)total_queries * strands - log_limit);

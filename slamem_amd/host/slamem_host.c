@@ -79,11 +79,9 @@ void slh_free_seqset(slh_seqset *s) {
     memset(s, 0, sizeof(*s));
 }
 
-int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, const char *name_filter,
-                  int first_number, long log_limit, slh_seqset *out, FILE *log) {
-    FILE *f;
-    unsigned char *data = NULL;
-    long fsize;
+/* the records of one memory range that starts with '>' */
+static int load_mem(const unsigned char *data, long fsize, int merge, int acgt_only, uint32_t min_len,
+                    const char *name_filter, int first_number, long log_limit, slh_seqset *out, FILE *log) {
     char table[256];
     reader r;
     int c, k, numseqs = 0, reccap = 0, matchpos, desclen;
@@ -93,31 +91,12 @@ int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, 
     char *chars = NULL;
 
     memset(out, 0, sizeof(*out));
-    if (log) fprintf(log, "> Loading sequences from file <%s> ... ", path);
-    f = fopen(path, "rb");
-    if (!f) {
-        if (log) fprintf(log, "\n> WARNING: Sequence file not found\n");
-        return 0;
-    }
-    fseek(f, 0L, SEEK_END);
-    fsize = ftell(f);
-    rewind(f);
-    if (log) fprintf(log, "(%ld bytes)\n", fsize);
-    data = (unsigned char *)malloc(fsize > 0 ? (size_t)fsize : 1);
-    if (!data || (fsize > 0 && fread(data, 1, (size_t)fsize, f) != (size_t)fsize)) {
-        if (log) fprintf(log, "> WARNING: Cannot read file\n");
-        free(data);
-        fclose(f);
-        return 0;
-    }
-    fclose(f);
     out->file_bytes = fsize;
     r.p = data;
     r.end = data + fsize;
     c = rd(&r);
     if (c != '>') {
         if (log) fprintf(log, "> WARNING: Invalid FASTA file\n");
-        free(data);
         return 0;
     }
     init_table(table, !acgt_only);
@@ -235,8 +214,6 @@ int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, 
             }
         }
     }
-    free(data);
-    data = NULL;
     if (numseqs == 0) {
         free(chars);
         slh_free_seqset(out);
@@ -256,12 +233,157 @@ int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, 
     }
     return numseqs;
 oom:
-    if (log) fprintf(log, "\n> ERROR: Out of memory while loading <%s>\n", path);
+    if (log) fprintf(log, "\n> ERROR: Out of memory while loading sequences\n");
 fail:
-    free(data);
     if (chars != out->chars) free(chars);
     slh_free_seqset(out);
     return 0;
+}
+
+
+/* ---- parallel loading of large query files ------------------------------------------------------- */
+#include <pthread.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+typedef struct {
+    const unsigned char *data;
+    long size;
+    int acgt_only;
+    uint32_t min_len;
+    int first_number;
+    long log_limit;
+    FILE *log;
+    slh_seqset set;
+    int n;
+} load_job;
+
+static void *load_job_run(void *arg) {
+    load_job *j = (load_job *)arg;
+    j->n = j->size > 0 ? load_mem(j->data, j->size, 0, j->acgt_only, j->min_len, NULL, j->first_number, j->log_limit, &j->set, j->log) : 0;
+    return NULL;
+}
+
+int slh_thread_count(void) {
+    const char *e = getenv("SLAMEM_THREADS");
+    long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    if (n > 32) n = 32;
+    return (int)n;
+}
+
+/* Query files above 64 MB are cut at "newline + '>'" positions (always a true record start: header lines are single
+ * lines, and in sequence context any '>' starts a record, sequence.c:157) and parsed by several threads; the
+ * pieces are concatenated in order, so the result equals the sequential parse.  The per-record log lines come from
+ * the first piece only (they are limited to the first log_limit records anyway). */
+static int load_parallel(const unsigned char *data, long fsize, int acgt_only, uint32_t min_len, int first_number,
+                         long log_limit, slh_seqset *out, FILE *log, int threads) {
+    load_job *jobs = (load_job *)calloc((size_t)threads, sizeof(load_job));
+    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    long *cut = (long *)calloc((size_t)threads + 1, sizeof(long));
+    int t, total = 0, ok = 1;
+    uint64_t chars_total = 0;
+    if (!jobs || !tid || !cut) { free(jobs); free(tid); free(cut); return -1; }
+    cut[0] = 0;
+    cut[threads] = fsize;
+    for (t = 1; t < threads; t++) {
+        long p = fsize / threads * t;
+        if (p < cut[t - 1]) p = cut[t - 1];
+        while (p < fsize && !(data[p] == '>' && p > 0 && (data[p - 1] == '\n' || data[p - 1] == '\r'))) p++;
+        cut[t] = p;
+    }
+    for (t = 0; t < threads; t++) {
+        jobs[t].data = data + cut[t];
+        jobs[t].size = cut[t + 1] - cut[t];
+        jobs[t].acgt_only = acgt_only;
+        jobs[t].min_len = min_len;
+        jobs[t].first_number = first_number;
+        jobs[t].log_limit = log_limit;
+        jobs[t].log = t == 0 ? log : NULL;
+        if (pthread_create(&tid[t], NULL, load_job_run, &jobs[t]) != 0) { load_job_run(&jobs[t]); tid[t] = 0; }
+    }
+    for (t = 0; t < threads; t++) if (tid[t]) pthread_join(tid[t], NULL);
+    for (t = 0; t < threads; t++) { total += jobs[t].n; chars_total += jobs[t].set.total; }
+    memset(out, 0, sizeof(*out));
+    out->file_bytes = fsize;
+    if (total > 0) {
+        out->recs = (slh_record *)malloc((size_t)total * sizeof(slh_record));
+        out->offsets = (uint64_t *)malloc(((size_t)total + 1) * sizeof(uint64_t));
+        out->chars = (char *)malloc(chars_total + 16);
+        if (!out->recs || !out->offsets || !out->chars) ok = 0;
+        else {
+            uint64_t cpos = 0;
+            int rpos = 0, i;
+            for (t = 0; t < threads; t++) {
+                slh_seqset *s = &jobs[t].set;
+                if (jobs[t].n == 0) continue;
+                memcpy(out->chars + cpos, s->chars, s->total);
+                memcpy(out->recs + rpos, s->recs, (size_t)s->num * sizeof(slh_record));
+                for (i = 0; i < s->num; i++) out->offsets[rpos + i] = s->offsets[i] + cpos;
+                cpos += s->total;
+                rpos += s->num;
+                if (s->name_arena) { /* the names stay where they are: chain the arenas */
+                    name_chunk *last = (name_chunk *)s->name_arena;
+                    while (last->next) last = last->next;
+                    last->next = (name_chunk *)out->name_arena;
+                    out->name_arena = s->name_arena;
+                    s->name_arena = NULL;
+                }
+            }
+            out->offsets[total] = cpos;
+            memset(out->chars + cpos, 0, 16);
+            out->total = cpos;
+            out->num = total;
+        }
+    }
+    for (t = 0; t < threads; t++) slh_free_seqset(&jobs[t].set);
+    free(jobs); free(tid); free(cut);
+    if (!ok) { slh_free_seqset(out); return -1; }
+    return total;
+}
+
+int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, const char *name_filter,
+                  int first_number, long log_limit, slh_seqset *out, FILE *log) {
+    FILE *f;
+    unsigned char *data = NULL;
+    long fsize;
+    int n, threads, mapped = 0;
+    memset(out, 0, sizeof(*out));
+    if (log) fprintf(log, "> Loading sequences from file <%s> ... ", path);
+    f = fopen(path, "rb");
+    if (!f) {
+        if (log) fprintf(log, "\n> WARNING: Sequence file not found\n");
+        return 0;
+    }
+    fseek(f, 0L, SEEK_END);
+    fsize = ftell(f);
+    rewind(f);
+    if (log) fprintf(log, "(%ld bytes)\n", fsize);
+    /* map the file instead of copying it: the parser threads fault its pages in parallel */
+    if (fsize > 0) {
+        void *m = mmap(NULL, (size_t)fsize, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+        if (m != MAP_FAILED) { data = (unsigned char *)m; mapped = 1; }
+    }
+    if (!mapped) {
+        data = (unsigned char *)malloc(fsize > 0 ? (size_t)fsize : 1);
+        if (!data || (fsize > 0 && fread(data, 1, (size_t)fsize, f) != (size_t)fsize)) {
+            if (log) fprintf(log, "> WARNING: Cannot read file\n");
+            free(data);
+            fclose(f);
+            return 0;
+        }
+    }
+    fclose(f);
+    threads = slh_thread_count();
+    if (!merge && threads > 1 && fsize > (64L << 20) && log_limit > 0 && data[0] == '>') {
+        n = load_parallel(data, fsize, acgt_only, min_len, first_number, log_limit, out, log, threads);
+        if (n < 0) n = load_mem(data, fsize, merge, acgt_only, min_len, name_filter, first_number, log_limit, out, log);
+    } else {
+        n = load_mem(data, fsize, merge, acgt_only, min_len, name_filter, first_number, log_limit, out, log);
+    }
+    if (mapped) munmap(data, (size_t)fsize);
+    else free(data);
+    return n;
 }
 
 int slh_seq_id_from_merged_pos(const uint32_t *starts, int num, uint32_t *pos) {

@@ -40,6 +40,8 @@ typedef struct {
 int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, const char *name_filter,
                   int first_number, long log_limit, slh_seqset *out, FILE *log);
 void slh_free_seqset(slh_seqset *s);
+/* host threads used for loading / formatting: SLAMEM_THREADS or the online CPUs, at most 32 */
+int slh_thread_count(void);
 
 /* GetSeqIdFromMergedSeqsPos (sequence.c:309-320). */
 int slh_seq_id_from_merged_pos(const uint32_t *starts, int num, uint32_t *pos);

@@ -68,10 +68,10 @@ def parse_options(args):
 
 
 class Loaded:
-    def __init__(self, path, merge, acgt_only=0, min_len=0, name_filter=None):
+    def __init__(self, path, merge, acgt_only=0, min_len=0, name_filter=None, log_limit=100):
         self.s = SeqSet()
         self.n = lib().slh_load_file(path.encode(), merge, acgt_only, min_len,
-                                     name_filter.encode() if name_filter is not None else None, 1, 0, C.byref(self.s), None)
+                                     name_filter.encode() if name_filter is not None else None, 1, log_limit, C.byref(self.s), None)
         s = self.s
         self.names = [s.recs[i].name for i in range(s.num)]
         self.sizes = [s.recs[i].size for i in range(s.num)]

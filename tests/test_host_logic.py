@@ -113,3 +113,33 @@ def test_cli_fails_loudly_without_gpu(tmp_path):
     ref_fa, q_fa, _, _ = case_paths("acgt_l20_fwd")
     r = subprocess.run([exe, "-o", str(tmp_path / "o.txt"), ref_fa, q_fa], stdout=subprocess.PIPE)
     assert r.returncode == 255 and b"no CPU" in r.stdout
+
+
+def test_parallel_loader_equals_sequential(tmp_path):
+    """Query files above 64 MB are parsed by several threads; the result must equal the one-thread parse,
+    including records whose '>' is not at a line start and headers that contain '>'."""
+    rng = np.random.default_rng(4)
+    p = tmp_path / "big.fa"
+    alpha = np.frombuffer(b"ACGTNacgtn", dtype=np.uint8)
+    with open(p, "wb") as f:
+        size = 0
+        k = 0
+        while size < (70 << 20):
+            L = int(rng.integers(1, 400))
+            seq = rng.choice(alpha, size=L).tobytes()
+            if k % 1000 == 7:
+                rec = b">r%d has > inside\r\n" % k + seq[: L // 2] + b"\n" + seq[L // 2:] + b">glued%d\n" % k + seq + b"\n"
+            elif k % 1000 == 9:
+                rec = b">empty%d\n\n" % k
+            else:
+                rec = b">r%d desc\n" % k + seq + b"\n"
+            f.write(rec)
+            size += len(rec)
+            k += 1
+    os.environ["SLAMEM_THREADS"] = "1"
+    a = hostlib.Loaded(str(p), 0, 0, 30)
+    os.environ["SLAMEM_THREADS"] = "7"
+    b = hostlib.Loaded(str(p), 0, 0, 30)
+    del os.environ["SLAMEM_THREADS"]
+    assert a.n == b.n > 100000 and a.names == b.names and a.sizes == b.sizes
+    assert a.offsets == b.offsets and a.chars == b.chars
