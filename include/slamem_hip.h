@@ -109,6 +109,8 @@ int slamem_index_export(const slamem_index *idx, void *dst_dev, uint64_t dst_byt
 /* Borrow an arena that a peer built (after ncclBroadcast / torch.distributed.broadcast).
  * The caller keeps the memory alive until slamem_index_free(). */
 int slamem_index_attach(void *arena_dev, uint64_t bytes, int device, slamem_index **out);
+/* Hand the attached arena over to the handle: slamem_index_free() will hipFree it (it must come from hipMalloc). */
+int slamem_index_adopt_arena(slamem_index *idx);
 int slamem_index_save(const slamem_index *idx, const char *path);
 int slamem_index_load(const char *path, int device, slamem_index **out);
 

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "slamem_abi_version", "slamem_strerror", "slamem_last_error_message", "slamem_device_count",
     "slamem_get_timings", "slamem_reset_timings",
     "slamem_index_build", "slamem_index_build_device", "slamem_index_free", "slamem_index_get_info",
-    "slamem_index_arena", "slamem_index_export", "slamem_index_attach", "slamem_index_save", "slamem_index_load",
+    "slamem_index_arena", "slamem_index_export", "slamem_index_attach", "slamem_index_adopt_arena", "slamem_index_save", "slamem_index_load",
     "slamem_index_download", "slamem_index_sampled_lcp_stats",
     "slamem_follow_letter_batch", "slamem_enclosing_interval_batch", "slamem_position_in_text_batch",
     "slamem_char_at_bwt_pos_batch",
@@ -83,6 +83,7 @@ def _declare(L):
     L.slamem_index_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.slamem_index_export.argtypes = [vp, vp, u64, vp]
     L.slamem_index_attach.argtypes = [vp, u64, i32, C.POINTER(vp)]
+    L.slamem_index_adopt_arena.argtypes = [vp]
     L.slamem_index_save.argtypes = [vp, C.c_char_p]
     L.slamem_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.slamem_index_download.argtypes = [vp, i32, vp, u64]

@@ -188,6 +188,12 @@ int slamem_index_attach(void* arena_dev, uint64_t bytes, int device, slamem_inde
     return SLAMEM_OK;
 }
 
+int slamem_index_adopt_arena(slamem_index* idx) {
+    if (!idx) return SLAMEM_ERR_ARG;
+    idx->owns_arena = 1;
+    return SLAMEM_OK;
+}
+
 int slamem_index_save(const slamem_index* idx, const char* path) {
     if (!idx || !path) return SLAMEM_ERR_ARG;
     SLAMEM_HIP(hipSetDevice(idx->device));

@@ -157,8 +157,8 @@ struct SearchArgs {
     uint32_t num_queries;
     uint32_t strands;          // 1 or 2
     uint32_t min_len;
-    int32_t spec_depth;        // v2: at or below this match length the parent records are fetched with the FM blocks
-    uint32_t chunk;            // v2: strand blocks owned by one wave
+    int32_t spec_depth;        // v3: at or below this match length the parent records are fetched with the FM blocks
+    uint32_t chunk;            // v3: work items owned by one wave
     uint32_t pad;
     uint64_t capacity;         // raw records that fit
     unsigned long long* total; // running number of MEMs

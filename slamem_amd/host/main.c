@@ -18,6 +18,7 @@
 #include <pthread.h>
 
 #include "../../include/slamem_hip.h"
+#include "../../include/slamem_rccl.h"
 #include "slamem_host.h"
 
 #define VERSION "0.8.2"
@@ -66,6 +67,28 @@ static void *fmt_run(void *arg) {
     return NULL;
 }
 
+/* one contiguous share of a batch's records, searched on one GPU by one host thread */
+typedef struct {
+    slamem_index *idx;
+    const char *chars;
+    uint64_t *offs;
+    int first, last; /* records [first,last) of the query set */
+    uint32_t min_len;
+    int both;
+    slamem_mem *mems;
+    uint64_t *boff, total;
+    int rc;
+    char err[512];
+} gpu_part;
+
+static void *gpu_part_run(void *arg) {
+    gpu_part *g = (gpu_part *)arg;
+    g->rc = slamem_find_mems_host(g->idx, g->chars, g->offs, (uint32_t)(g->last - g->first), g->min_len, g->both, &g->mems,
+                                  &g->boff, &g->total);
+    if (g->rc != SLAMEM_OK) snprintf(g->err, sizeof(g->err), "%s", slamem_last_error_message()); /* the message is per thread */
+    return NULL;
+}
+
 static void usage(const char *prog) { /* slamem.c:533-553 */
     printf("Usage:\n");
     printf("\t%s (<options>) <reference_file> <query_file(s)>\n", prog);
@@ -91,8 +114,8 @@ int main(int argc, char **argv) {
     const char *env;
     char *out_name;
     FILE *out;
-    slamem_index *idx = NULL;
-    int rc;
+    slamem_index *idx = NULL, *gpus[16];
+    int rc, ngpu = 1;
     double t0;
     long long total_matches = 0, total_sum = 0;
     slh_buffer buf = {0, 0, 0};
@@ -180,6 +203,26 @@ int main(int argc, char **argv) {
                    (long long)st.max_link_distance);
         }
     }
+    /* SLAMEM_GPUS=N: replicate the index to N GPUs (device, device+1, ...) with one RCCL broadcast of its arena over
+       xGMI; every batch is then split by bases into N contiguous shares, one per GPU (no data-path collective). */
+    gpus[0] = idx;
+    if ((env = getenv("SLAMEM_GPUS")) != NULL) {
+        int avail = 0;
+        slamem_device_count(&avail);
+        ngpu = atoi(env) <= 0 ? avail - device : atoi(env);
+        if (ngpu < 1) ngpu = 1;
+        if (ngpu > 16) ngpu = 16;
+        if (device + ngpu > avail) exit_message("SLAMEM_GPUS asks for more GPUs than are visible");
+    }
+    if (ngpu > 1 || getenv("SLAMEM_REPLICATE_SELFTEST") != NULL) {
+        int devs[16], g;
+        double tr = now_s();
+        for (g = 0; g < ngpu; g++) devs[g] = device + g;
+        rc = slamem_index_replicate(idx, devs, ngpu, ngpu == 1, gpus);
+        if (rc != SLAMEM_OK) gpu_fail("index replication over RCCL", rc);
+        if (ngpu == 1) { slamem_index_free(idx); idx = gpus[0]; } /* self-test: search on the broadcast copy */
+        printf("> Index replicated to %d GPU%s by RCCL broadcast ... OK (%.3f s)\n", ngpu, ngpu == 1 ? " (self-test copy)" : "s", now_s() - tr);
+    }
     t_build = now_s() - t0;
     free(ref.chars); /* the reference frees the text here too (slamem.c:75-77) */
     ref.chars = NULL;
@@ -193,21 +236,50 @@ int main(int argc, char **argv) {
             slh_seqset *q = &qsets[f];
             int first = 0;
             while (first < q->num) { /* batches of records */
-                int last = first;
+                int last = first, part;
                 uint64_t base = q->offsets[first];
-                slamem_mem *mems = NULL;
-                uint64_t *boff = NULL, total = 0, *offs;
-                while (last < q->num && (last == first || q->offsets[last + 1] - base <= batch_bytes)) last++;
-                offs = (uint64_t *)malloc(((size_t)(last - first) + 1) * sizeof(uint64_t));
-                if (!offs) exit_message("Out of memory");
-                for (i = first; i <= last; i++) offs[i - first] = q->offsets[i] - base;
+                gpu_part parts[16];
+                pthread_t ptid[16];
                 double tg = now_s();
-                rc = slamem_find_mems_host(idx, q->chars + base, offs, (uint32_t)(last - first), (uint32_t)o.min_mem_len,
-                                           o.both_strands, &mems, &boff, &total);
-                if (rc != SLAMEM_OK) gpu_fail("MEM search on the GPU", rc);
+                while (last < q->num && (last == first || q->offsets[last + 1] - base <= batch_bytes * (uint64_t)ngpu)) last++;
+                memset(parts, 0, sizeof(parts));
+                {   /* contiguous shares with (almost) equal numbers of bases, one per GPU, searched concurrently */
+                    uint64_t tot = q->offsets[last] - base;
+                    int r0 = first;
+                    for (part = 0; part < ngpu; part++) {
+                        uint64_t target = base + tot * (uint64_t)(part + 1) / (uint64_t)ngpu;
+                        int r1 = r0;
+                        if (part == ngpu - 1) r1 = last;
+                        else while (r1 < last && q->offsets[r1 + 1] <= target) r1++;
+                        parts[part].idx = gpus[part];
+                        parts[part].first = r0;
+                        parts[part].last = r1;
+                        parts[part].chars = q->chars + q->offsets[r0];
+                        parts[part].offs = (uint64_t *)malloc(((size_t)(r1 - r0) + 1) * sizeof(uint64_t));
+                        if (!parts[part].offs) exit_message("Out of memory");
+                        for (i = r0; i <= r1; i++) parts[part].offs[i - r0] = q->offsets[i] - q->offsets[r0];
+                        parts[part].min_len = (uint32_t)o.min_mem_len;
+                        parts[part].both = o.both_strands;
+                        r0 = r1;
+                    }
+                    for (part = 0; part < ngpu; part++)
+                        if (part == ngpu - 1 || pthread_create(&ptid[part], NULL, gpu_part_run, &parts[part]) != 0) { gpu_part_run(&parts[part]); ptid[part] = 0; }
+                    for (part = 0; part < ngpu; part++) {
+                        if (ptid[part]) pthread_join(ptid[part], NULL);
+                        if (parts[part].rc != SLAMEM_OK) {
+                            printf("\n> ERROR: MEM search on GPU %d failed: %s (%s)\n", device + part, slamem_strerror(parts[part].rc), parts[part].err);
+                            exit(-1);
+                        }
+                    }
+                }
                 t_gpu += now_s() - tg;
                 tg = now_s();
-                {
+                for (part = 0; part < ngpu; part++) {
+                    const int pfirst = parts[part].first, plast = parts[part].last;
+                    slamem_mem *mems = parts[part].mems;
+                    uint64_t *boff = parts[part].boff;
+#define first pfirst
+#define last plast
                     /* the first strand blocks get their ':: "name" ....' line (slamem.c:97,101,203) and are formatted here;
                        the rest of the batch is formatted by all host threads and written in order */
                     uint64_t nblk = (uint64_t)(last - first) * strands, bseq = 0, b;
@@ -265,11 +337,13 @@ int main(int argc, char **argv) {
                         free(jobs);
                         free(tid);
                     }
+#undef first
+#undef last
+                    slamem_host_free(mems);
+                    slamem_host_free(boff);
+                    free(parts[part].offs);
                 }
                 t_format += now_s() - tg;
-                slamem_host_free(mems);
-                slamem_host_free(boff);
-                free(offs);
                 first = last;
             }
         }
@@ -277,7 +351,7 @@ int main(int argc, char **argv) {
             printf(":: ... (%ld more strand blocks matched; set SLAMEM_VERBOSE=1 for a line each)\n",
                    (long)total_queries * strands - log_limit);
     }
-    slamem_index_free(idx);
+    for (i = 0; i < ngpu; i++) slamem_index_free(gpus[i]);
     if (total_queries != 1) /* slamem.c:210-212 (the reference divides by zero when nothing matched) */
         printf(":: Average %d M%cMs found per query sequence (total = %lld, avg size = %d bp)\n",
                (int)(total_matches / total_queries), MATCH_TYPE_CHAR[o.match_type], total_matches,

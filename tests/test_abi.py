@@ -52,3 +52,15 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"(from|import)\s+oracle|oracle\.h|liboracle|pyoracle", s):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_rccl_companion_library_exports_replicate():
+    """libslamem_rccl.so (include/slamem_rccl.h): the C front end's multi-GPU step; separate from libslamem_hip.so so
+    that torch's own RCCL is never doubled in the Python harness."""
+    so = os.path.join(ROOT, "slamem_amd", "csrc", "libslamem_rccl.so")
+    assert os.path.exists(so), "run __graft_entry__.build()"
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], stdout=subprocess.PIPE).stdout.decode()
+    assert " T slamem_index_replicate" in syms
+    text = open(os.path.join(ROOT, "include", "slamem_rccl.h")).read()
+    assert "slamem_index_replicate" in text

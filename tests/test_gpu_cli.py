@@ -90,3 +90,25 @@ def test_cli_config2_full_size_output_hash(tmp_path):
             h.update(chunk)
     assert os.path.getsize(os.path.join(d, "out.txt")) == 44_723_866
     assert h.hexdigest().startswith("8f711ed6cd088ee1")
+
+
+def test_cli_rccl_replication_selftest(tmp_path):
+    """The multi-GPU step of the C front end on a one-GPU box: the index arena goes through a real RCCL communicator
+    (ncclCommInitAll + ncclBroadcast into a second arena), the search then runs on the broadcast copy."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    ref_fa, q_fa, exp_mems, _ = case_paths("acgt_l20_both")
+    out = str(tmp_path / "o.txt")
+    env = dict(os.environ, SLAMEM_REPLICATE_SELFTEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "-b", "-l", "20", "-o", out, ref_fa, q_fa], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    assert b"replicated to 1 GPU (self-test copy) by RCCL broadcast ... OK" in r.stdout
+    assert open(out, "rb").read() == open(exp_mems, "rb").read()
+    # SLAMEM_GPUS=1 takes the sharding code path with one share
+    r = subprocess.run([exe, "-b", "-l", "20", "-o", out, ref_fa, q_fa], stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_GPUS="1"))
+    assert r.returncode == 0 and open(out, "rb").read() == open(exp_mems, "rb").read()
+    # asking for more GPUs than exist fails loudly
+    r = subprocess.run([exe, "-o", out, ref_fa, q_fa], stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_GPUS="64"))
+    assert r.returncode == 255
