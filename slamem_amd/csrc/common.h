@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 3;
+constexpr uint32_t kArenaVersion = 4;
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -54,6 +54,9 @@ struct ArenaHeader {
     uint64_t off_rec;     // RowRec[n+2]    per-row {LCP+1, PSV, NSV, SA}
     uint64_t off_nrows;   // uint32[num_n]  sorted BWT rows holding N
     uint64_t off_kfilter; // uint64[1 << kfilter_log2]  k-mer presence filter (0 = absent)
+    uint64_t off_ptext;   // uint64[]  the text, 4-bit letter ids, 16 per word, first letter in the top nibble (0 = absent)
+    uint64_t off_isa;     // uint32[n+1]  inverse suffix array: BWT row of the suffix that starts at text position s
+    uint64_t off_pd;      // uint8[n+1]   text-ordered parent depth: min(255, max(LCP[row], LCP[row+1])), row = ISA[s]
     uint32_t kfilter_log2;
     uint32_t kfilter_k;
     uint32_t nblocks;
@@ -72,6 +75,9 @@ struct IndexView {
     const RowRec* rec;
     const uint32_t* nrows;
     const uint64_t* kfilter;  // nullptr when the index has no presence filter
+    const uint64_t* ptext;    // nullptr when the index has no text-ordered sections (direct extension off)
+    const uint32_t* isa;
+    const uint8_t* pd;
     uint32_t n;
     uint32_t nblocks;
     uint32_t dollar_row;

@@ -172,6 +172,9 @@ struct SearchArgs {
     const uint8_t* item_alive;  // v3: nullptr, or 0 for items the k-mer presence filter proved empty
     const uint32_t* work_ids;   // v3: nullptr (work = all items), or the ids of the items that survived the prefilter
     const uint32_t* work_count; // v3: device word holding their number
+    int32_t direct_min_depth;   // v3: unique matches at least this long are extended by direct text comparison (<0: off)
+    uint32_t pad2;
+    uint64_t query_words;       // v3: 8-byte words of the query buffer that may be read
 };
 
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
@@ -387,9 +390,28 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
     return k;
 }
 
+// ---- direct extension of a unique match ---------------------------------------------------------------------
+// Once the interval is a single row, the matched string occurs exactly once in the text, at r = SA[row]; extending it
+// to the left is then a comparison of the query with the text itself -- sequential memory, 32 letters per trip --
+// instead of one random FM-block line per letter.  Nothing can be emitted on the way as long as the letters agree
+// (the single row's BWT letter IS the left letter) and the parent of the single-row interval stays shallower than
+// min_len, which the text-ordered parent-depth bytes tell without touching the row records.  The run ends at the
+// first disagreeing letter, at a position whose parent may qualify, or at the slice / text boundary; ISA gives the
+// row back and the normal machinery (parent step, enumeration) takes over.  The reference walks these positions
+// one FMI_FollowLetter at a time (slamem.c:121).
+__device__ __forceinline__ uint64_t sel3(uint64_t a0, uint64_t a1, uint64_t a2, uint32_t i) {
+    return i == 0u ? a0 : i == 1u ? a1 : a2;
+}
+__device__ __forceinline__ uint64_t sel5(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, uint64_t a4, uint32_t i) {
+    return i == 0u ? a0 : i == 1u ? a1 : i == 2u ? a2 : i == 3u ? a3 : a4;
+}
+
+enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DISA = 5 };
+
 #ifndef SLAMEM_V3_WAVES
 #define SLAMEM_V3_WAVES 1
 #endif
+template <bool kDirect>
 __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
     __shared__ ItemDesc lds_item[4][kChunkMax];
     const IndexView& ix = A.ix;
@@ -412,7 +434,8 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     }
     __syncthreads();
 
-    bool active = false, st_rec = false, st_flush = false, pend = false;
+    bool active = false, pend = false, dir_moved = false;
+    uint32_t st = ST_EXT, dir_r = 0;  // state; text position where the current (unique) match starts
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
     uint32_t a_pos = 0, b_pos = 0, attempt = 0;  // emitted slice [a_pos, b_pos) of the strand, warm-up attempt
     int depth = 0, pub = -1;
@@ -439,7 +462,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 b_pos = d.len - a_pos < kSliceLen ? d.len : a_pos + kSliceLen;
                 attempt = 0;
                 j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
-                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st_rec = false; st_flush = false; k = 0;
+                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; dir_moved = false; k = 0;
                 if (d.len == 0) {  // empty record: nothing to scan
                     A.block_counts[g] = 0;
                     A.item_attempt[g] = 0;
@@ -460,37 +483,116 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
         if (active) {
             // ---- memory phase: every load of this trip, no use in between -------------------------------------
             uint4 rt = make_uint4(0, 0, 0, 0), rb = rt;
-            const bool rec_only = st_rec || st_flush;
-            bool want_rec = rec_only;
-            uint32_t c = 0;
+            bool want_rec = st == ST_REC || st == ST_FLUSH;
+            uint32_t c = 0, isa_row = 0, W = 0, lo = 0;
+            uint64_t tw0 = 0, tw1 = 0, tw2 = 0, pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0, pw4 = 0;
+            uint64_t qw0 = 0, qw1 = 0, qw2 = 0, qw3 = 0, qw4 = 0, qb = 0;
             Blk kb;  // block of bot+1 when it differs from top's (wide intervals only: not kept across trips)
             kb.a = kb.b = kb.c = kb.d = make_uint4(0, 0, 0, 0);
-            if (!rec_only) {
+            if (st == ST_EXT) {
                 uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
                 if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
                 if (bb != bt) kb = load_blk(ix.fm, bb);
                 // records together with the blocks: when a pending position's parent may still be >= min_len deep
                 // (its depth is needed now), or speculatively while the match is short (off by default)
                 want_rec = depth <= A.spec_depth || (pend && pub >= L);
+            } else if (kDirect && st == ST_DSA) {
+                rt = R[top];  // SA of the single row
+            } else if (kDirect && st == ST_DISA) {
+                isa_row = ix.isa[dir_r];
+            } else if (kDirect && st == ST_DIR) {
+                W = j - a_pos;  // positions that may still be consumed by this item
+                if (W > dir_r) W = dir_r;  // letters of the text to the left of the match
+                if (W > 32u) W = 32u;
+                lo = dir_r - W;
+                const uint64_t* tp = ix.ptext + (lo >> 4);
+                tw0 = tp[0]; tw1 = tp[1]; tw2 = tp[2];
+                const uint64_t* pp = reinterpret_cast<const uint64_t*>(ix.pd) + (lo >> 3);
+                pw0 = pp[0]; pw1 = pp[1]; pw2 = pp[2]; pw3 = pp[3]; pw4 = pp[4];
+                // the W query letters below position j are contiguous in memory on either strand
+                uint64_t qs = qc.base + (qc.rev ? (uint64_t)(qc.len - j) : (uint64_t)(j - W));
+                qb = qs >> 3;
+                const uint64_t nw = A.query_words;
+                qw0 = qb < nw ? qc.words[qb] : 0ull;
+                qw1 = qb + 1 < nw ? qc.words[qb + 1] : 0ull;
+                qw2 = qb + 2 < nw ? qc.words[qb + 2] : 0ull;
+                qw3 = qb + 3 < nw ? qc.words[qb + 3] : 0ull;
+                qw4 = qb + 4 < nw ? qc.words[qb + 4] : 0ull;
             }
             if (want_rec) { rt = R[top]; rb = R[bot + 1u]; }
-            if (!rec_only) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
+            if (st == ST_EXT) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
 
             // ---- compute phase -------------------------------------------------------------------------------
-            if (st_flush) {  // the strand ended on a match whose parent may qualify too: its depth has arrived
-                st_flush = false;
+            bool strand_end = false;  // position 0 has been consumed: flush what is pending, finish
+            if (st == ST_FLUSH) {  // the strand ended on a match whose parent may qualify too: its depth has arrived
+                st = ST_EXT;
                 uint32_t t2 = top, b2 = bot;
                 pub = parent_from(rt, rb, t2, b2);
                 if (pub < L && top == bot) { emit3_at(A, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; }
                 else { e_on = true; e_level0 = true; e_up = pub >= L; e_pos = 0u; e_left = 0xFFu; }
                 pend = false;
                 finished = true;
-            } else if (st_rec) {  // a deep match ended at this letter: widen, retry next trip
-                st_rec = false;
+            } else if (st == ST_REC) {  // a deep match ended at this letter: widen, retry next trip
+                st = ST_EXT;
                 int d = parent_from(rt, rb, top, bot);
                 if (d < 0) { depth = 0; pub = -1; consumed = true; }
                 else { depth = d; pub = d - 1; }
-            } else {
+            } else if (kDirect && st == ST_DSA) {
+                dir_r = rt.w;
+                dir_moved = false;
+                st = ST_DIR;
+            } else if (kDirect && st == ST_DISA) {
+                top = bot = isa_row;
+                dir_moved = false;
+                st = ST_EXT;
+                if (j == 0u) strand_end = true;
+            } else if (kDirect && st == ST_DIR) {
+                uint32_t kc = 0, last_pd = 0;
+                bool special = false;
+                for (uint32_t i = 0; i < W; i++) {
+                    uint32_t tpos = dir_r - 1u - i;
+                    uint64_t tword = sel3(tw0, tw1, tw2, (tpos >> 4) - (lo >> 4));
+                    uint32_t tn = (uint32_t)(tword >> (60u - 4u * (tpos & 15u))) & 15u;
+                    uint32_t p = j - 1u - i;
+                    uint64_t m = qc.base + (qc.rev ? (uint64_t)(qc.len - 1u - p) : (uint64_t)p);
+                    uint64_t qword = sel5(qw0, qw1, qw2, qw3, qw4, (uint32_t)((m >> 3) - qb));
+                    uint32_t qn = ascii_code_q((uint32_t)(qword >> ((m & 7u) * 8u)) & 0xFFu);
+                    if (qc.rev && qn >= 2u) qn = 7u - qn;
+                    if (qn != tn) break;  // the extension by this letter does not occur
+                    kc++;
+                    uint64_t pword = sel5(pw0, pw1, pw2, pw3, pw4, (tpos >> 3) - (lo >> 3));
+                    last_pd = (uint32_t)(pword >> ((tpos & 7u) * 8u)) & 0xFFu;
+                    if (last_pd == 255u || (int)last_pd >= L) { special = true; break; }  // an ancestor may qualify here
+                }
+                if (kc != 0u) {
+                    const uint32_t j_old = j;
+                    depth += (int)kc;
+                    j -= kc;
+                    dir_r -= kc;
+                    dir_moved = true;
+                    pub = last_pd == 255u ? 0x3FFFFFFF : (int)last_pd;  // exact parent depth of the new single-row interval
+                    const bool in_slice = j >= a_pos && j < b_pos;
+                    pend = depth >= L && depth > 0 && in_slice;
+                    uint32_t e = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
+                                                                                                       : b_pos + (kWarmUp << (2u * attempt));
+                    const bool touched = j < b_pos && j_old - 1u >= a_pos;
+                    if (touched && e < qc.len && (uint32_t)depth == e - j) {  // the match reaches the scan start: redo
+                        attempt++;
+                        j = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
+                                                                                                : b_pos + (kWarmUp << (2u * attempt));
+                        top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; k = 0;
+                        qc.widx = ~0ull; qc.wnidx = ~0ull;
+                        st = ST_EXT;
+                        dir_moved = false;
+                    } else if (kc == W && !special && j > a_pos && dir_r != 0u) {
+                        st = ST_DIR;   // the whole window agreed: keep going
+                    } else {
+                        st = ST_DISA;  // hand back: the row of the new match start
+                    }
+                } else {
+                    st = dir_moved ? ST_DISA : ST_EXT;  // first letter disagrees (or nothing left): the normal step decides
+                }
+            } else {  // ST_EXT
                 uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
                 uint32_t nt, nb1;
                 if (c >= 2u) {
@@ -535,7 +637,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                         if (d < 0) { depth = 0; pub = -1; consumed = true; }  // root, letter absent (slamem.c:125)
                         else { depth = d; pub = d - 1; }                      // widened; retry the letter next trip
                     } else {
-                        st_rec = true;  // fetch the records in the next trip
+                        st = ST_REC;  // fetch the records in the next trip
                     }
                 }
             }
@@ -552,12 +654,18 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                                                                                             : b_pos + (kWarmUp << (2u * attempt));
                     top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; k = 0;
                     qc.widx = ~0ull; qc.wnidx = ~0ull;
-                } else if (j == 0u) {  // strand finished; rows still pending have nothing to their left (slamem.c:138)
-                    finished = true;
-                    if (pend && pub >= L) { st_flush = true; finished = false; }  // parent depth needed: next trip
-                    else if (pend && top == bot) { emit3_at(A, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; pend = false; }
-                    else if (pend) { e_on = true; e_level0 = true; e_up = false; e_pos = 0u; e_left = 0xFFu; }
+                } else if (j == 0u) {
+                    strand_end = true;
+                } else if (kDirect && st == ST_EXT && top == bot && depth >= A.direct_min_depth && A.direct_min_depth >= 0 &&
+                           j > a_pos && !(pend && pub >= L)) {
+                    st = ST_DSA;  // a unique match that is long enough: extend it by comparing with the text
                 }
+            }
+            if (strand_end) {  // strand finished; rows still pending have nothing to their left (slamem.c:138)
+                finished = true;
+                if (pend && pub >= L) { st = ST_FLUSH; finished = false; }  // parent depth needed: next trip
+                else if (pend && top == bot) { emit3_at(A, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; pend = false; }
+                else if (pend) { e_on = true; e_level0 = true; e_up = false; e_pos = 0u; e_left = 0xFFu; }
             }
         }
 
@@ -885,6 +993,15 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         A.items = reinterpret_cast<const ItemDesc*>(ws + w.off_items);
         A.num_items = nitems;
         A.item_attempt = reinterpret_cast<uint8_t*>(ws + w.off_attempt);
+        A.query_words = (query_bytes + 7) / 8;
+        {   // direct extension: on when the index has the text-ordered sections; threshold = where random matches stop
+            static const bool use_direct = [] { const char* v = getenv("SLAMEM_DIRECT"); return v && atoi(v) != 0; }();
+            int lg = 0;
+            for (uint64_t v = idx->hdr.n; v > 1; v >>= 2) lg++;
+            A.direct_min_depth = (use_direct && idx->view.ptext) ? lg + 5 : -1;
+            const char* e3 = getenv("SLAMEM_DIRECT_DEPTH");
+            if (e3 && A.direct_min_depth >= 0) A.direct_min_depth = atoi(e3);
+        }
         {
             A.spec_depth = -1;  // measured: fetching the records speculatively costs more lines than the trips it saves
             const char* e1 = getenv("SLAMEM_SPEC_DEPTH");
@@ -916,7 +1033,8 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                 A.work_count = d_nwork;
             }
             uint64_t waves = (nitems + A.chunk - 1) / A.chunk;
-            hipLaunchKernelGGL(k_find_mems_v3, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
+            if (A.direct_min_depth >= 0) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL(k_find_mems_v3<false>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             STEP(hipGetLastError(), "k_find_mems_v3");
         } else if (nitems) {
             hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
