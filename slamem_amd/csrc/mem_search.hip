@@ -399,11 +399,41 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
 // first disagreeing letter, at a position whose parent may qualify, or at the slice / text boundary; ISA gives the
 // row back and the normal machinery (parent step, enumeration) takes over.  The reference walks these positions
 // one FMI_FollowLetter at a time (slamem.c:121).
-__device__ __forceinline__ uint64_t sel3(uint64_t a0, uint64_t a1, uint64_t a2, uint32_t i) {
-    return i == 0u ? a0 : i == 1u ? a1 : a2;
+// 8 query bytes -> 8 letter ids (A=2 C=3 G=4 T=5, anything else 1), one id in the low bits of every byte (SWAR).
+__device__ __forceinline__ uint64_t letter_ids8(uint64_t x, bool complement) {
+    const uint64_t k01 = 0x0101010101010101ull, k7f = 0x7F7F7F7F7F7F7F7Full;
+    uint64_t b = x & 0xDFDFDFDFDFDFDFDFull;                  // upper case
+    uint64_t v0 = (b >> 1) & k01, v1 = (b >> 2) & k01;        // A:00 C:01 T:10 G:11 (v1 v0)
+    uint64_t t = v1 & ~v0 & k01;                              // T
+    uint64_t expect = (0x41ull * k01) ^ t ^ (t << 4);         // the other six bits an A/C/G/T byte must have
+    uint64_t y = (b & 0xF9F9F9F9F9F9F9F9ull) ^ expect;        // zero byte <=> really one of A,C,G,T
+    uint64_t nz = ((y & k7f) + k7f) | y;                      // bit 7 of a byte set <=> byte != 0
+    uint64_t ok = (~nz >> 7) & k01;                           // 1 per valid byte
+    uint64_t code = v0 ^ v1;                                  // low bit of the 2-bit order value: A0 C1 G0 T1 ...
+    code = (v1 << 1) | (v0 ^ v1);                             // A:0 C:1 G:2 T:3
+    if (complement) code ^= 3ull * k01;                       // A<->T, C<->G
+    uint64_t id = code + 2ull * k01;                          // 2..5
+    return (id & (ok * 0xFFull)) | ((ok ^ k01));              // invalid bytes -> 1 (N)
 }
-__device__ __forceinline__ uint64_t sel5(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, uint64_t a4, uint32_t i) {
-    return i == 0u ? a0 : i == 1u ? a1 : i == 2u ? a2 : i == 3u ? a3 : a4;
+// 8 bytes (ids in their low nibbles) -> 8 nibbles; byte 0 becomes the LOWEST nibble
+__device__ __forceinline__ uint32_t pack_nibbles8(uint64_t c) {
+    c &= 0x0F0F0F0F0F0F0F0Full;
+    c = (c | (c >> 4)) & 0x00FF00FF00FF00FFull;
+    c = (c | (c >> 8)) & 0x0000FFFF0000FFFFull;
+    c = (c | (c >> 16));
+    return (uint32_t)c;
+}
+__device__ __forceinline__ uint32_t reverse_nibbles32(uint32_t v) {
+    v = __builtin_bswap32(v);
+    return ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
+}
+// bytes of a 128-bit value that are >= lim (lim <= 128) or 255: bit 7 of each such byte
+__device__ __forceinline__ uint64_t bytes_ge(uint64_t p, uint32_t lim) {
+    const uint64_t k7f = 0x7F7F7F7F7F7F7F7Full;
+    return (((p & k7f) + (uint64_t)(0x80u - lim) * 0x0101010101010101ull) | p) & 0x8080808080808080ull;
+}
+__device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t byte_shift) {  // bytes [s, s+8) of hi:lo
+    return byte_shift ? (lo >> (8u * byte_shift)) | (hi << (64u - 8u * byte_shift)) : lo;
 }
 
 enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DISA = 5 };
@@ -485,8 +515,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             uint4 rt = make_uint4(0, 0, 0, 0), rb = rt;
             bool want_rec = st == ST_REC || st == ST_FLUSH;
             uint32_t c = 0, isa_row = 0, W = 0, lo = 0;
-            uint64_t tw0 = 0, tw1 = 0, tw2 = 0, pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0, pw4 = 0;
-            uint64_t qw0 = 0, qw1 = 0, qw2 = 0, qw3 = 0, qw4 = 0, qb = 0;
+            uint64_t tw0 = 0, tw1 = 0, pw0 = 0, pw1 = 0, pw2 = 0, qw0 = 0, qw1 = 0, qw2 = 0, qb = 0;
             Blk kb;  // block of bot+1 when it differs from top's (wide intervals only: not kept across trips)
             kb.a = kb.b = kb.c = kb.d = make_uint4(0, 0, 0, 0);
             if (st == ST_EXT) {
@@ -501,23 +530,20 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             } else if (kDirect && st == ST_DISA) {
                 isa_row = ix.isa[dir_r];
             } else if (kDirect && st == ST_DIR) {
-                W = j - a_pos;  // positions that may still be consumed by this item
-                if (W > dir_r) W = dir_r;  // letters of the text to the left of the match
-                if (W > 32u) W = 32u;
-                lo = dir_r - W;
+                // 16 letters per trip: text [dir_r-16, dir_r), their parent-depth bytes, the 16 query letters below j
+                lo = dir_r - 16u;
                 const uint64_t* tp = ix.ptext + (lo >> 4);
-                tw0 = tp[0]; tw1 = tp[1]; tw2 = tp[2];
+                tw0 = tp[0]; tw1 = tp[1];
                 const uint64_t* pp = reinterpret_cast<const uint64_t*>(ix.pd) + (lo >> 3);
-                pw0 = pp[0]; pw1 = pp[1]; pw2 = pp[2]; pw3 = pp[3]; pw4 = pp[4];
-                // the W query letters below position j are contiguous in memory on either strand
-                uint64_t qs = qc.base + (qc.rev ? (uint64_t)(qc.len - j) : (uint64_t)(j - W));
+                pw0 = pp[0]; pw1 = pp[1]; pw2 = pp[2];
+                uint64_t qs = qc.base + (qc.rev ? (uint64_t)(qc.len - j) : (uint64_t)j - 16u);
                 qb = qs >> 3;
                 const uint64_t nw = A.query_words;
                 qw0 = qb < nw ? qc.words[qb] : 0ull;
                 qw1 = qb + 1 < nw ? qc.words[qb + 1] : 0ull;
                 qw2 = qb + 2 < nw ? qc.words[qb + 2] : 0ull;
-                qw3 = qb + 3 < nw ? qc.words[qb + 3] : 0ull;
-                qw4 = qb + 4 < nw ? qc.words[qb + 4] : 0ull;
+                W = j - a_pos;  // positions that may still be consumed by this item
+                if (W > 16u) W = 16u;
             }
             if (want_rec) { rt = R[top]; rb = R[bot + 1u]; }
             if (st == ST_EXT) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
@@ -540,7 +566,9 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             } else if (kDirect && st == ST_DSA) {
                 dir_r = rt.w;
                 dir_moved = false;
-                st = ST_DIR;
+                // the 16-letter windows must lie inside the text and the query buffer; the few positions at their
+                // very beginning go the normal way
+                st = (dir_r >= 16u && qc.base + j >= 16u) ? ST_DIR : ST_EXT;
             } else if (kDirect && st == ST_DISA) {
                 top = bot = isa_row;
                 dir_moved = false;
@@ -549,20 +577,44 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             } else if (kDirect && st == ST_DIR) {
                 uint32_t kc = 0, last_pd = 0;
                 bool special = false;
-                for (uint32_t i = 0; i < W; i++) {
-                    uint32_t tpos = dir_r - 1u - i;
-                    uint64_t tword = sel3(tw0, tw1, tw2, (tpos >> 4) - (lo >> 4));
-                    uint32_t tn = (uint32_t)(tword >> (60u - 4u * (tpos & 15u))) & 15u;
-                    uint32_t p = j - 1u - i;
-                    uint64_t m = qc.base + (qc.rev ? (uint64_t)(qc.len - 1u - p) : (uint64_t)p);
-                    uint64_t qword = sel5(qw0, qw1, qw2, qw3, qw4, (uint32_t)((m >> 3) - qb));
-                    uint32_t qn = ascii_code_q((uint32_t)(qword >> ((m & 7u) * 8u)) & 0xFFu);
-                    if (qc.rev && qn >= 2u) qn = 7u - qn;
-                    if (qn != tn) break;  // the extension by this letter does not occur
-                    kc++;
-                    uint64_t pword = sel5(pw0, pw1, pw2, pw3, pw4, (tpos >> 3) - (lo >> 3));
-                    last_pd = (uint32_t)(pword >> ((tpos & 7u) * 8u)) & 0xFFu;
-                    if (last_pd == 255u || (int)last_pd >= L) { special = true; break; }  // an ancestor may qualify here
+                {
+                    // text window: letter of position dir_r-1 in the lowest nibble
+                    uint32_t sh = (lo & 15u) * 4u;
+                    uint64_t T = sh ? (tw0 << sh) | (tw1 >> (64u - sh)) : tw0;
+                    // query window in the same layout
+                    uint64_t qs = qc.base + (qc.rev ? (uint64_t)(qc.len - j) : (uint64_t)j - 16u);
+                    uint32_t bs = (uint32_t)(qs & 7u);
+                    uint64_t q0 = funnel64(qw0, qw1, bs), q1 = funnel64(qw1, qw2, bs);  // memory bytes 0..7, 8..15
+                    uint32_t n0 = pack_nibbles8(letter_ids8(q0, qc.rev != 0u)), n1 = pack_nibbles8(letter_ids8(q1, qc.rev != 0u));
+                    uint64_t Q;
+                    if (qc.rev) Q = ((uint64_t)n1 << 32) | n0;  // memory byte 0 is position j-1: already "last letter lowest"
+                    else Q = ((uint64_t)reverse_nibbles32(n0) << 32) | reverse_nibbles32(n1);  // byte 15 is position j-1
+                    uint64_t x = T ^ Q;
+                    uint32_t km = x ? (uint32_t)__builtin_ctzll(x) >> 2 : 16u;
+                    if (km > W) km = W;
+                    if (km != 0u) {
+                        // parent-depth bytes of positions lo..lo+15 (byte k of P0 / P1 = position lo+k / lo+8+k)
+                        uint32_t ps = lo & 7u;
+                        uint64_t P0 = funnel64(pw0, pw1, ps), P1 = funnel64(pw1, pw2, ps);
+                        uint64_t s1 = bytes_ge(P1, (uint32_t)L), s0 = bytes_ge(P0, (uint32_t)L);
+                        uint64_t m1 = km >= 8u ? s1 : s1 & (~0ull << (8u * (8u - km)));
+                        uint64_t m0 = km > 8u ? s0 & (~0ull << (8u * (16u - km))) : 0ull;
+                        if (m1) {          // the special position closest to the match start wins
+                            uint32_t bidx = (63u - (uint32_t)__builtin_clzll(m1)) >> 3;
+                            kc = 8u - bidx;
+                            last_pd = (uint32_t)(P1 >> (8u * bidx)) & 0xFFu;
+                            special = true;
+                        } else if (m0) {
+                            uint32_t bidx = (63u - (uint32_t)__builtin_clzll(m0)) >> 3;
+                            kc = 16u - bidx;
+                            last_pd = (uint32_t)(P0 >> (8u * bidx)) & 0xFFu;
+                            special = true;
+                        } else {
+                            kc = km;
+                            uint32_t bi = 16u - kc;  // byte index of position dir_r - kc in the 16-byte window
+                            last_pd = bi >= 8u ? (uint32_t)(P1 >> (8u * (bi - 8u))) & 0xFFu : (uint32_t)(P0 >> (8u * bi)) & 0xFFu;
+                        }
+                    }
                 }
                 if (kc != 0u) {
                     const uint32_t j_old = j;
@@ -584,7 +636,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                         qc.widx = ~0ull; qc.wnidx = ~0ull;
                         st = ST_EXT;
                         dir_moved = false;
-                    } else if (kc == W && !special && j > a_pos && dir_r != 0u) {
+                    } else if (kc == 16u && !special && j > a_pos && dir_r >= 16u && qc.base + j >= 16u) {
                         st = ST_DIR;   // the whole window agreed: keep going
                     } else {
                         st = ST_DISA;  // hand back: the row of the new match start
@@ -996,9 +1048,10 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         A.query_words = (query_bytes + 7) / 8;
         {   // direct extension: on when the index has the text-ordered sections; threshold = where random matches stop
             static const bool use_direct = [] { const char* v = getenv("SLAMEM_DIRECT"); return v && atoi(v) != 0; }();
+            if (min_len > 128) { /* the SWAR parent-depth test handles limits up to 128 */ }
             int lg = 0;
             for (uint64_t v = idx->hdr.n; v > 1; v >>= 2) lg++;
-            A.direct_min_depth = (use_direct && idx->view.ptext) ? lg + 5 : -1;
+            A.direct_min_depth = (use_direct && idx->view.ptext && min_len <= 128) ? lg + 5 : -1;
             const char* e3 = getenv("SLAMEM_DIRECT_DEPTH");
             if (e3 && A.direct_min_depth >= 0) A.direct_min_depth = atoi(e3);
         }
