@@ -186,10 +186,23 @@ int slamem_find_mems_device(const slamem_index *idx, const void *queries_dev, co
                             slamem_mem *mems_dev, uint64_t mems_capacity, uint64_t *block_offsets_dev,
                             void *workspace_dev, uint64_t workspace_bytes, void *stream, uint64_t *total_out);
 
+/* The same batch in MAM mode (option -mam: matchType 1, slamem.c:131,657): only positions whose match is a single
+ * BWT row are reported.  The reference skips the other positions with a `continue` that also skips its interval
+ * bookkeeping (slamem.c:197-198), which makes later fall-backs start from a stale interval; the
+ * result is defined by that behaviour and is reproduced exactly.  Same arguments, layout and errors as
+ * slamem_find_mems_device; strands are scanned whole (one lane per strand). */
+int slamem_find_mams_device(const slamem_index *idx, const void *queries_dev, const uint64_t *offsets_dev,
+                            uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands,
+                            slamem_mem *mems_dev, uint64_t mems_capacity, uint64_t *block_offsets_dev,
+                            void *workspace_dev, uint64_t workspace_bytes, void *stream, uint64_t *total_out);
+
 /* Host-buffer convenience used by the C front end: uploads the batch, runs
  * slamem_find_mems_device (growing the output buffer if needed) and returns
  * malloc()ed arrays the caller frees with slamem_host_free(). */
 int slamem_find_mems_host(const slamem_index *idx, const char *queries, const uint64_t *offsets,
+                          uint32_t num_queries, uint32_t min_len, int both_strands,
+                          slamem_mem **mems_out, uint64_t **block_offsets_out, uint64_t *total_out);
+int slamem_find_mams_host(const slamem_index *idx, const char *queries, const uint64_t *offsets,
                           uint32_t num_queries, uint32_t min_len, int both_strands,
                           slamem_mem **mems_out, uint64_t **block_offsets_out, uint64_t *total_out);
 void slamem_host_free(void *p);

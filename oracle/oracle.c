@@ -366,6 +366,14 @@ static int push_mem(oracle_mem **out, size_t *cap, size_t *have, uint32_t r, uin
 /* hot body of GetMatches, slamem.c:105-199 (MEM mode) */
 size_t oracle_get_matches(const oracle_index *x, const char *q, uint32_t len, int min_len,
                           oracle_mem **out, size_t *cap, size_t have, oracle_counts *cnt) {
+    return oracle_get_matches_mode(x, q, len, min_len, 0, out, cap, have, cnt);
+}
+
+/* match_type 0 = MEM (default), 1 = MAM (-mam, slamem.c:657): positions whose interval is not a single row are
+ * skipped by the `continue` at slamem.c:131 -- which also skips the bookkeeping at :197-198, so the interval that a
+ * later failed extension falls back to (:122-123) is a stale one.  Restated as is. */
+size_t oracle_get_matches_mode(const oracle_index *x, const char *q, uint32_t len, int min_len, int match_type,
+                               oracle_mem **out, size_t *cap, size_t have, oracle_counts *cnt) {
     oracle_counts local;
     uint32_t top = 0, bottom = x->n; /* slamem.c:110-111; n+1 there, n here */
     uint32_t prev_top = top, prev_bottom = bottom, saved_top, saved_bottom, row, j, n;
@@ -389,6 +397,7 @@ size_t oracle_get_matches(const oracle_index *x, const char *q, uint32_t len, in
         }
         depth++; /* :129 */
         if (depth >= min_len) { /* :130 */
+            if (match_type == 1 && n != 1) continue; /* :131 */
             saved_top = top;
             saved_bottom = bottom;
             prev_top = bottom + 1; /* :134 */
@@ -490,6 +499,12 @@ size_t oracle_brute_force_mems(const char *text, uint32_t n, const char *query, 
 size_t oracle_match_batch(const oracle_index *x, const char *queries, const uint64_t *offsets,
                           uint32_t num, int min_len, int both, oracle_mem **out, size_t *cap,
                           uint64_t *block_counts, oracle_counts *cnt) {
+    return oracle_match_batch_mode(x, queries, offsets, num, min_len, both, 0, out, cap, block_counts, cnt);
+}
+
+size_t oracle_match_batch_mode(const oracle_index *x, const char *queries, const uint64_t *offsets,
+                               uint32_t num, int min_len, int both, int match_type, oracle_mem **out, size_t *cap,
+                               uint64_t *block_counts, oracle_counts *cnt) {
     size_t have = 0, before;
     uint32_t i;
     char *buf = NULL;
@@ -497,7 +512,7 @@ size_t oracle_match_batch(const oracle_index *x, const char *queries, const uint
     for (i = 0; i < num; i++) {
         uint64_t len = offsets[i + 1] - offsets[i];
         before = have;
-        have = oracle_get_matches(x, queries + offsets[i], (uint32_t)len, min_len, out, cap, have, cnt);
+        have = oracle_get_matches_mode(x, queries + offsets[i], (uint32_t)len, min_len, match_type, out, cap, have, cnt);
         if (have == (size_t)-1) { free(buf); return have; }
         if (block_counts) block_counts[(size_t)i * (both ? 2 : 1)] = have - before;
         if (both) {
@@ -511,7 +526,7 @@ size_t oracle_match_batch(const oracle_index *x, const char *queries, const uint
             buf[len] = 0;
             oracle_reverse_complement(buf, (int)len);
             before = have;
-            have = oracle_get_matches(x, buf, (uint32_t)len, min_len, out, cap, have, cnt);
+            have = oracle_get_matches_mode(x, buf, (uint32_t)len, min_len, match_type, out, cap, have, cnt);
             if (have == (size_t)-1) { free(buf); return have; }
             if (block_counts) block_counts[(size_t)i * 2 + 1] = have - before;
         }

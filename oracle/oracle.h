@@ -80,6 +80,9 @@ char oracle_char_at_bwt_pos(const oracle_index *idx, uint32_t row);
  * number of stored elements, or (size_t)-1 on allocation failure.  counts may be NULL. */
 size_t oracle_get_matches(const oracle_index *idx, const char *query, uint32_t len, int min_len,
                           oracle_mem **out, size_t *cap, size_t have, oracle_counts *counts);
+/* same with the match type of slamem.c:131,657: 0 = MEM, 1 = MAM (-mam), stale-interval quirk included */
+size_t oracle_get_matches_mode(const oracle_index *idx, const char *query, uint32_t len, int min_len, int match_type,
+                               oracle_mem **out, size_t *cap, size_t have, oracle_counts *counts);
 
 /* ReverseComplementSequence (sequence.c:413-430), in place; N unchanged. */
 void oracle_reverse_complement(char *text, int len);
@@ -100,6 +103,9 @@ size_t oracle_brute_force_mems(const char *text, uint32_t n, const char *query, 
 size_t oracle_match_batch(const oracle_index *idx, const char *queries, const uint64_t *offsets,
                           uint32_t num, int min_len, int both_strands,
                           oracle_mem **out, size_t *cap, uint64_t *block_counts, oracle_counts *counts);
+size_t oracle_match_batch_mode(const oracle_index *idx, const char *queries, const uint64_t *offsets,
+                               uint32_t num, int min_len, int both_strands, int match_type,
+                               oracle_mem **out, size_t *cap, uint64_t *block_counts, oracle_counts *counts);
 
 void oracle_free_mems(oracle_mem *p);
 

@@ -69,6 +69,14 @@ def lib():
         L.oracle_get_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int,
                                          C.POINTER(C.POINTER(Mem)), C.POINTER(C.c_size_t), C.c_size_t,
                                          C.POINTER(Counts)]
+        L.oracle_get_matches_mode.restype = C.c_size_t
+        L.oracle_get_matches_mode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int, C.c_int,
+                                              C.POINTER(C.POINTER(Mem)), C.POINTER(C.c_size_t), C.c_size_t,
+                                              C.POINTER(Counts)]
+        L.oracle_match_batch_mode.restype = C.c_size_t
+        L.oracle_match_batch_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.POINTER(Mem)), C.POINTER(C.c_size_t), C.c_void_p,
+                                              C.POINTER(Counts)]
         L.oracle_brute_force_mems.restype = C.c_size_t
         L.oracle_brute_force_mems.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int,
                                               C.POINTER(C.POINTER(Mem)), C.POINTER(C.c_size_t), C.c_size_t]
@@ -141,15 +149,15 @@ class OracleIndex:
     def char_at_bwt_pos(self, row: int) -> str:
         return self.L.oracle_char_at_bwt_pos(self.h, row).decode()
 
-    def get_matches(self, query: bytes, min_len: int, counts: Counts | None = None) -> np.ndarray:
+    def get_matches(self, query: bytes, min_len: int, counts: Counts | None = None, mam: bool = False) -> np.ndarray:
         out = C.POINTER(Mem)()
         cap = C.c_size_t(0)
-        n = self.L.oracle_get_matches(self.h, bytes(query), len(query), min_len, C.byref(out), C.byref(cap), 0,
-                                      C.byref(counts) if counts is not None else None)
+        n = self.L.oracle_get_matches_mode(self.h, bytes(query), len(query), min_len, int(mam), C.byref(out),
+                                           C.byref(cap), 0, C.byref(counts) if counts is not None else None)
         return _take(self.L, out, n)
 
     def match_batch(self, queries: np.ndarray, offsets: np.ndarray, min_len: int, both: bool,
-                    counts: Counts | None = None):
+                    counts: Counts | None = None, mam: bool = False):
         """queries: uint8 concatenation; offsets: uint64[num+1].  Returns (mems, block_counts)."""
         queries = np.ascontiguousarray(queries, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -157,9 +165,9 @@ class OracleIndex:
         bc = np.zeros(num * (2 if both else 1), dtype=np.uint64)
         out = C.POINTER(Mem)()
         cap = C.c_size_t(0)
-        n = self.L.oracle_match_batch(self.h, queries.ctypes.data, offsets.ctypes.data, num, min_len, int(both),
-                                      C.byref(out), C.byref(cap), bc.ctypes.data,
-                                      C.byref(counts) if counts is not None else None)
+        n = self.L.oracle_match_batch_mode(self.h, queries.ctypes.data, offsets.ctypes.data, num, min_len, int(both),
+                                           int(mam), C.byref(out), C.byref(cap), bc.ctypes.data,
+                                           C.byref(counts) if counts is not None else None)
         return _take(self.L, out, n), bc
 
 

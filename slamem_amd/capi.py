@@ -29,6 +29,7 @@ ABI_SYMBOLS = (
     "slamem_follow_letter_batch", "slamem_enclosing_interval_batch", "slamem_position_in_text_batch",
     "slamem_char_at_bwt_pos_batch",
     "slamem_find_mems_workspace_bytes", "slamem_find_mems_device", "slamem_find_mems_host", "slamem_host_free",
+    "slamem_find_mams_device", "slamem_find_mams_host",
 )
 
 
@@ -96,6 +97,8 @@ def _declare(L):
     L.slamem_find_mems_device.argtypes = [vp, vp, vp, u32, u64, u32, i32, vp, u64, vp, vp, u64, vp, C.POINTER(u64)]
     L.slamem_find_mems_host.argtypes = [vp, C.c_char_p, vp, u32, u32, i32, C.POINTER(C.POINTER(Mem)),
                                         C.POINTER(C.POINTER(u64)), C.POINTER(u64)]
+    L.slamem_find_mams_device.argtypes = L.slamem_find_mems_device.argtypes
+    L.slamem_find_mams_host.argtypes = L.slamem_find_mems_host.argtypes
     L.slamem_host_free.argtypes = [vp]
     L.slamem_host_free.restype = None
     for name in ABI_SYMBOLS:

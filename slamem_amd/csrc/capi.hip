@@ -298,16 +298,41 @@ int slamem_find_mems_device(const slamem_index* idx, const void* queries_dev, co
                             uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands,
                             slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
                             uint64_t workspace_bytes, void* stream, uint64_t* total_out) {
-    return find_mems_device(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, mems_dev,
+    return find_mems_device(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, 0, mems_dev,
+                            mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes, static_cast<hipStream_t>(stream),
+                            total_out);
+}
+
+int slamem_find_mams_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
+                            uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands,
+                            slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
+                            uint64_t workspace_bytes, void* stream, uint64_t* total_out) {
+    return find_mems_device(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, 1, mems_dev,
                             mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes, static_cast<hipStream_t>(stream),
                             total_out);
 }
 
 void slamem_host_free(void* p) { free(p); }
 
+static int find_matches_host(const slamem_index* idx, const char* queries, const uint64_t* offsets, uint32_t num_queries,
+                             uint32_t min_len, int both_strands, int match_type, slamem_mem** mems_out,
+                             uint64_t** block_offsets_out, uint64_t* total_out);
+
 int slamem_find_mems_host(const slamem_index* idx, const char* queries, const uint64_t* offsets, uint32_t num_queries,
                           uint32_t min_len, int both_strands, slamem_mem** mems_out, uint64_t** block_offsets_out,
                           uint64_t* total_out) {
+    return find_matches_host(idx, queries, offsets, num_queries, min_len, both_strands, 0, mems_out, block_offsets_out, total_out);
+}
+
+int slamem_find_mams_host(const slamem_index* idx, const char* queries, const uint64_t* offsets, uint32_t num_queries,
+                          uint32_t min_len, int both_strands, slamem_mem** mems_out, uint64_t** block_offsets_out,
+                          uint64_t* total_out) {
+    return find_matches_host(idx, queries, offsets, num_queries, min_len, both_strands, 1, mems_out, block_offsets_out, total_out);
+}
+
+static int find_matches_host(const slamem_index* idx, const char* queries, const uint64_t* offsets, uint32_t num_queries,
+                             uint32_t min_len, int both_strands, int match_type, slamem_mem** mems_out,
+                             uint64_t** block_offsets_out, uint64_t* total_out) {
     if (!idx || !offsets || !mems_out || !block_offsets_out || !total_out || (num_queries && !queries)) {
         set_error("slamem_find_mems_host: null argument");
         return SLAMEM_ERR_ARG;
@@ -332,7 +357,7 @@ int slamem_find_mems_host(const slamem_index* idx, const char* queries, const ui
         HOST_TRY(hipMalloc(&d_mems, cap * sizeof(slamem_mem) + 16));
         HOST_TRY(hipMalloc(&d_ws, ws_bytes));
         rc = find_mems_device(idx, d_q, static_cast<const uint64_t*>(d_off), num_queries, qbytes, min_len, both_strands,
-                              static_cast<slamem_mem*>(d_mems), cap, static_cast<uint64_t*>(d_boff), d_ws, ws_bytes,
+                              match_type, static_cast<slamem_mem*>(d_mems), cap, static_cast<uint64_t*>(d_boff), d_ws, ws_bytes,
                               nullptr, total_out);
         if (rc != SLAMEM_ERR_CAPACITY) break;
         (void)hipFree(d_mems); d_mems = nullptr;

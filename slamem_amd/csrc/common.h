@@ -131,7 +131,7 @@ namespace slamem {
 void make_view(slamem_index* idx);
 int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t stream, slamem_index** out);
 int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
-                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands,
+                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
                      slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
                      uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out);
 uint64_t find_mems_workspace_bytes(uint64_t num_queries, int both_strands, uint64_t query_bytes, uint64_t mems_capacity);

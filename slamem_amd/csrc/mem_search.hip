@@ -316,6 +316,52 @@ __global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
     A.block_counts[g] = k;
 }
 
+// -mam (slamem.c:131,657): the reference's scan with its MAM test -- a position whose interval is not a single row is
+// skipped by a `continue` that also skips the bookkeeping of slamem.c:197-198, so the interval that a later failed
+// extension falls back to (:122-123) is the one saved at an EARLIER position.  Output is defined by that
+// behaviour, so the scan is kept in the reference's shape: emission at the position itself, explicit fall-back
+// interval; one lane per strand, whole strands (the stale interval makes slices of a strand depend on their past).
+__global__ void __launch_bounds__(256) k_find_mams(SearchArgs A) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t nblocks = (uint64_t)A.num_queries * A.strands;
+    if (g >= nblocks) return;
+    uint32_t qi = (uint32_t)(A.strands == 2 ? g >> 1 : g);
+    uint32_t rev = A.strands == 2 ? (uint32_t)(g & 1u) : 0u;
+    uint64_t o0 = A.offsets[qi], o1 = A.offsets[qi + 1];
+    uint32_t len = (uint32_t)(o1 - o0);
+    const IndexView& ix = A.ix;
+    const int L = (int)A.min_len;
+    QueryCursor qc;
+    qc.init(A.qwords, o0, len, rev);
+    uint32_t top = 0, bot = ix.n, prev_top = 0, prev_bot = ix.n;  // slamem.c:110-113
+    int depth = 0;
+    uint32_t k = 0;
+    for (uint32_t j = len; j-- > 0u;) {
+        uint32_t c = qc.at(j);
+        uint32_t size = 0;
+        for (;;) {  // slamem.c:121-128
+            uint32_t t = top, b = bot;
+            if (follow(ix, c, t, b)) { top = t; bot = b; size = b - t + 1u; break; }
+            top = prev_top;
+            bot = prev_bot;
+            depth = parent(ix, top, bot);
+            if (depth < 0) break;
+            prev_top = top;
+            prev_bot = bot;
+        }
+        depth++;
+        if (depth >= L) {
+            if (size != 1u) continue;  // slamem.c:131 (prev_top / prev_bot keep their old values)
+            uint32_t left = j ? qc.at(j - 1u) : 0xFFu;  // slamem.c:137-138
+            int pub = 0x3FFFFFFF;
+            emit_levels(A, (uint32_t)g, k, top, bot, depth, j, left, bwt_code(ix, top) == left ? 1u : 0u, pub);
+        }
+        prev_top = top;  // slamem.c:197-198
+        prev_bot = bot;
+    }
+    A.block_counts[g] = k;
+}
+
 // ------------------------------------------------------------------------------------------
 // K8 v3: the same scan as a persistent, desynchronised state machine with ONE memory phase per trip.
 //
@@ -969,7 +1015,7 @@ uint64_t find_mems_workspace_bytes(uint64_t num_queries, int both_strands, uint6
 }
 
 int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
-                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands,
+                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
                      slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
                      uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out) {
     if (!idx || !offsets_dev || !block_offsets_dev || !workspace_dev || !total_out || (!mems_dev && mems_capacity) ||
@@ -1004,7 +1050,9 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     uint32_t* d_first = reinterpret_cast<uint32_t*>(ws + w.off_first);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
     uint64_t* d_itemoff = reinterpret_cast<uint64_t*>(ws + w.off_itemoff);
-    static const int kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
+    static const int env_kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
+    // MAM mode scans whole strands with k_find_mams and shares the v1 output path (atomic list + scatter)
+    const int kernel_version = match_type == 1 ? 1 : env_kernel_version;
 
     Timings& tm = thread_timings();
     hipEvent_t e0, e1, e2;
@@ -1089,6 +1137,9 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             if (A.direct_min_depth >= 0) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             else hipLaunchKernelGGL(k_find_mems_v3<false>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             STEP(hipGetLastError(), "k_find_mems_v3");
+        } else if (nitems && match_type == 1) {
+            hipLaunchKernelGGL(k_find_mams, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
+            STEP(hipGetLastError(), "k_find_mams");
         } else if (nitems) {
             hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
             STEP(hipGetLastError(), "k_find_mems");

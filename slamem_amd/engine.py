@@ -172,11 +172,13 @@ class Index:
         return o.cpu().numpy().tobytes()
 
     # ---- GetMatches (slamem.c:90-207) for a batch ---------------------------------------------------------
-    def matcher(self, num_queries: int, both_strands: bool, mems_capacity: int, query_bytes: int) -> "Matcher":
-        return Matcher(self, num_queries, both_strands, mems_capacity, query_bytes)
+    def matcher(self, num_queries: int, both_strands: bool, mems_capacity: int, query_bytes: int,
+                mam: bool = False) -> "Matcher":
+        return Matcher(self, num_queries, both_strands, mems_capacity, query_bytes, mam)
 
-    def find_mems(self, queries, offsets, min_len: int = 20, both_strands: bool = False):
-        """Convenience: host arrays in, (mems structured array, block_offsets) out."""
+    def find_mems(self, queries, offsets, min_len: int = 20, both_strands: bool = False, mam: bool = False):
+        """Convenience: host arrays in, (mems structured array, block_offsets) out.  mam=True: -mam mode
+        (slamem_find_mams_device; slamem.c:131,657)."""
         dev = self.device
         q = np.ascontiguousarray(np.frombuffer(queries, dtype=np.uint8) if isinstance(queries, (bytes, bytearray))
                                  else queries, dtype=np.uint8)
@@ -188,7 +190,7 @@ class Index:
         od = torch.from_numpy(offsets.view(np.int64)).to(dev)
         cap = max(1024, q.shape[0] // 8 + 4 * num)
         while True:
-            m = self.matcher(num, both_strands, cap, int(offsets[-1]) if num else 0)
+            m = self.matcher(num, both_strands, cap, int(offsets[-1]) if num else 0, mam)
             try:
                 total = m.run(qd, od, min_len)
                 break
@@ -205,8 +207,10 @@ class Index:
 class Matcher:
     """Pre-allocated output + workspace buffers for repeated slamem_find_mems_device calls (bench loop)."""
 
-    def __init__(self, index: Index, num_queries: int, both_strands: bool, mems_capacity: int, query_bytes: int):
+    def __init__(self, index: Index, num_queries: int, both_strands: bool, mems_capacity: int, query_bytes: int,
+                 mam: bool = False):
         self.index = index
+        self.mam = bool(mam)
         self.num_queries = int(num_queries)
         self.both = bool(both_strands)
         self.capacity = int(mems_capacity)
@@ -224,7 +228,8 @@ class Matcher:
     def run(self, queries_dev: torch.Tensor, offsets_dev: torch.Tensor, min_len: int) -> int:
         dev = self.index.device
         total = C.c_uint64()
-        rc = capi.lib().slamem_find_mems_device(
+        fn = capi.lib().slamem_find_mams_device if self.mam else capi.lib().slamem_find_mems_device
+        rc = fn(
             self.index._h, _ptr(queries_dev), _ptr(offsets_dev), self.num_queries, self.query_bytes, int(min_len),
             int(self.both),
             _ptr(self.mems), self.capacity, _ptr(self.block_offsets), _ptr(self.workspace), self.workspace.numel(),

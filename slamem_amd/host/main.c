@@ -74,7 +74,7 @@ typedef struct {
     uint64_t *offs;
     int first, last; /* records [first,last) of the query set */
     uint32_t min_len;
-    int both;
+    int both, mam;
     slamem_mem *mems;
     uint64_t *boff, total;
     int rc;
@@ -83,8 +83,8 @@ typedef struct {
 
 static void *gpu_part_run(void *arg) {
     gpu_part *g = (gpu_part *)arg;
-    g->rc = slamem_find_mems_host(g->idx, g->chars, g->offs, (uint32_t)(g->last - g->first), g->min_len, g->both, &g->mems,
-                                  &g->boff, &g->total);
+    g->rc = (g->mam ? slamem_find_mams_host : slamem_find_mems_host)(g->idx, g->chars, g->offs, (uint32_t)(g->last - g->first),
+                                                                     g->min_len, g->both, &g->mems, &g->boff, &g->total);
     if (g->rc != SLAMEM_OK) snprintf(g->err, sizeof(g->err), "%s", slamem_last_error_message()); /* the message is per thread */
     return NULL;
 }
@@ -127,7 +127,6 @@ int main(int argc, char **argv) {
     if (o.num_files < 2) exit_message("Not enough input sequence files provided");
     if (o.ref_name_given && o.ref_name_empty) exit_message("No reference name string provided");
     if (o.image_arg != -1) exit_message("The -v image tool is not part of this front end (use the reference's on the *-mems.txt output)");
-    if (o.match_type == 1) exit_message("MAM mode (-mam) is not implemented in this front end yet");
     if ((env = getenv("SLAMEM_DEVICE")) != NULL) device = atoi(env);
     if ((env = getenv("SLAMEM_VERBOSE")) != NULL && atoi(env) != 0) log_limit = 0;
     if ((env = getenv("SLAMEM_BATCH_MB")) != NULL && atoll(env) > 0) batch_bytes = (uint64_t)atoll(env) << 20;
@@ -260,6 +259,7 @@ int main(int argc, char **argv) {
                         for (i = r0; i <= r1; i++) parts[part].offs[i - r0] = q->offsets[i] - q->offsets[r0];
                         parts[part].min_len = (uint32_t)o.min_mem_len;
                         parts[part].both = o.both_strands;
+                        parts[part].mam = o.match_type == 1;
                         r0 = r1;
                     }
                     for (part = 0; part < ngpu; part++)

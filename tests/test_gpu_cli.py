@@ -20,11 +20,12 @@ def test_cli_output_file_is_byte_identical(case, tmp_path):
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     ref_fa, q_fa, exp_mems, _ = case_paths(case)
     out = str(tmp_path / "out-mems.txt")
-    r = subprocess.run([exe] + MANIFEST[case]["opts"] + ["-o", out, ref_fa, q_fa], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT)
+    r = subprocess.run([exe] + MANIFEST[case]["opts"] + ["-o", out, ref_fa, q_fa] + MANIFEST[case].get("tail", []),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode(errors="replace")
     assert open(out, "rb").read() == open(exp_mems, "rb").read()
-    assert b"> Done!" in r.stdout and b"> Saving MEMs to <" in r.stdout
+    kind = b"MAMs" if "-mam" in MANIFEST[case].get("tail", []) else b"MEMs"
+    assert b"> Done!" in r.stdout and b"> Saving " + kind + b" to <" in r.stdout
 
 
 def test_cli_default_output_name_and_batches(tmp_path):
@@ -51,7 +52,8 @@ def test_cli_prints_the_reference_structure_statistics(case, tmp_path):
         pytest.skip("needs an MI355X")
     exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
     ref_fa, q_fa, _, exp_stdout = case_paths(case)
-    r = subprocess.run([exe] + MANIFEST[case]["opts"] + ["-o", str(tmp_path / "o.txt"), ref_fa, q_fa], stdout=subprocess.PIPE)
+    r = subprocess.run([exe] + MANIFEST[case]["opts"] + ["-o", str(tmp_path / "o.txt"), ref_fa, q_fa] +
+                       MANIFEST[case].get("tail", []), stdout=subprocess.PIPE)
     assert r.returncode == 0
     ours = r.stdout.decode(errors="replace")
     exp = open(exp_stdout, encoding="latin1").read()

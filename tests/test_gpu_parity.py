@@ -96,6 +96,31 @@ def test_find_mems_matches_oracle_in_order(eng, alpha, n, repeats, nrun, l, both
     g.close()
 
 
+@pytest.mark.parametrize("alpha,n,repeats,l,both", [
+    ("ACGT", 3000, 8, 8, True), ("AC", 1500, 4, 12, False), ("ACG", 900, 3, 5, True), ("ACGT", 20000, 30, 15, True),
+    ("ACGTN", 2500, 4, 6, True), ("A", 300, 0, 4, True)])
+def test_find_mams_matches_oracle_in_order(eng, alpha, n, repeats, l, both):
+    """-mam (slamem_find_mams_device): same triples in the same order as the restated scan with matchType 1
+    (slamem.c:131), stale fall-back interval included; the restatement itself is pinned by the mam_* golden files."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(7 * n + l)
+    text = rand_text(rng, n, alpha, repeats, nrun=60 if "N" in alpha else 0)
+    qs = make_queries(rng, text, 40, alpha) + [b"", b"N" * 25, text[:30], text[-30:], text[: min(n, 6000)]]
+    q, off = pack(qs)
+    o = po.OracleIndex(text)
+    om, obc = o.match_batch(q, off, l, both, mam=True)
+    mm, _ = o.match_batch(q, off, l, both)
+    g = eng.Index.build(text)
+    gm, goff = g.find_mems(q, off, l, both, mam=True)
+    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+    assert len(gm) == len(om)
+    for f in ("ref_pos", "query_pos", "length"):
+        assert np.array_equal(gm[f], om[f]), f
+    if repeats:
+        assert len(om) != len(mm)  # the case does exercise the mode
+    g.close()
+
+
 def test_fine_grained_ops_match_oracle(eng):
     """FMI_FollowLetter / GetEnclosingLCPInterval / FMI_PositionInText / FMI_GetCharAtBWTPos, batched."""
     from oracle import pyoracle as po

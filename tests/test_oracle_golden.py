@@ -25,7 +25,8 @@ def test_oracle_reproduces_reference_output_file(case):
     assert ref.n > 0 and qs.n > 0
     idx = po.OracleIndex(ref.chars)
     off = np.array(qs.offsets, dtype=np.uint64)
-    mems, bc = idx.match_batch(np.frombuffer(qs.chars, dtype=np.uint8), off, l, both)
+    mam = "-mam" in MANIFEST[case].get("tail", [])
+    mems, bc = idx.match_batch(np.frombuffer(qs.chars, dtype=np.uint8), off, l, both, mam=mam)
     tri = np.stack([mems["ref_pos"], mems["query_pos"], mems["length"]], axis=1).astype(np.uint32) if len(mems) else \
         np.zeros((0, 3), dtype=np.uint32)
     out = []
