@@ -229,28 +229,129 @@ __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restric
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kLcpChunk = 32;
 
+// A lane of k_lcp_kasai starts its 32 positions without the carry of the position before them, so a repeat of
+// length R (a centromere's run of N, a tandem array, a long duplication) would cost every lane inside it up to R/16
+// steps: R^2/1024 in total.  Two sampled passes bound that: text positions that are multiples of kLcpCoarse2 are
+// compared from scratch (one wave each, 4096 letters per step), multiples of kLcpCoarse1 start from the sample
+// before them, and the lanes of k_lcp_kasai start from those -- all through  LCP(i+d) >= LCP(i) - d  (the Kasai
+// invariant).  And when the predecessor in suffix order moves along with the position (pred(i+d) = pred(i)+d, which is
+// what happens inside every long repeat) the value is EXACT without reading the text: LCP(i+d) = LCP(i) - d.  That
+// matters beyond the saved work: inside a repeat every position's comparison ends at the same text position, and
+// millions of loads of one cache line crawl (measured 23 ns each: 190 ms for an 8 Mbp run of N).
+constexpr uint32_t kLcpCoarse1 = 1024, kLcpCoarse2 = 32768;
+// The whole wave extends one comparison: suffixes at ii and jj agree on hh letters; returns their exact LCP.
+// 4096 letters per step (every lane 64 of them); reads up to 4096 letters behind the mismatch (kPackSlack).
+__device__ __forceinline__ uint32_t wave_extend_lcp(const uint64_t* __restrict__ pk, uint64_t ii, uint64_t jj, uint32_t hh,
+                                                    uint32_t lane) {
+    for (;;) {
+        const uint64_t a = ii + hh + lane * 64u, b = jj + hh + lane * 64u;
+        uint64_t x0 = window16(pk, a) ^ window16(pk, b);
+        uint64_t x1 = window16(pk, a + 16) ^ window16(pk, b + 16);
+        uint64_t x2 = window16(pk, a + 32) ^ window16(pk, b + 32);
+        uint64_t x3 = window16(pk, a + 48) ^ window16(pk, b + 48);
+        uint32_t mine = x0 ? (uint32_t)__clzll((long long)x0) >> 2
+                      : x1 ? 16u + ((uint32_t)__clzll((long long)x1) >> 2)
+                      : x2 ? 32u + ((uint32_t)__clzll((long long)x2) >> 2)
+                      : x3 ? 48u + ((uint32_t)__clzll((long long)x3) >> 2) : 64u;
+        uint64_t m = __ballot(mine != 64u);
+        if (m) {
+            const int first = __ffsll((unsigned long long)m) - 1;
+            return hh + (uint32_t)first * 64u + __shfl(mine, first);
+        }
+        hh += 4096u;
+    }
+}
+
+// one WAVE per sampled position; out_h[k] = LCP of the suffix at k*stride with its predecessor, out_j[k] = where that
+// predecessor starts
+__global__ void __launch_bounds__(256) k_lcp_sampled(const uint64_t* __restrict__ pk, const uint32_t* __restrict__ sa,
+                                                     const uint32_t* __restrict__ rank, uint32_t rows, uint32_t stride,
+                                                     const uint32_t* __restrict__ prev_h, const uint32_t* __restrict__ prev_j,
+                                                     uint32_t prev_stride, uint32_t* __restrict__ out_h,
+                                                     uint32_t* __restrict__ out_j) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t i = k * stride;
+    if (i >= rows) return;  // whole wave
+    const uint32_t r = rank[i];
+    if (r == 0u) { if (lane == 0u) { out_h[k] = 0u; out_j[k] = 0xFFFFFFFFu; } return; }
+    const uint64_t j = sa[r - 1];
+    uint32_t h = 0;
+    bool exact = false;
+    if (prev_h) {
+        uint32_t p = prev_h[i / prev_stride], d = (uint32_t)(i % prev_stride);
+        if (p > d) { h = p - d; exact = (uint64_t)prev_j[i / prev_stride] + d == j; }
+    }
+    if (!exact) h = wave_extend_lcp(pk, i, j, h, lane);
+    if (lane == 0u) { out_h[k] = h; out_j[k] = (uint32_t)j; }
+}
+
 __global__ void __launch_bounds__(256) k_lcp_kasai(const uint64_t* __restrict__ pk, const uint32_t* __restrict__ sa,
                                                    const uint32_t* __restrict__ rank, uint32_t rows,
+                                                   const uint32_t* __restrict__ coarse_h, const uint32_t* __restrict__ coarse_j,
                                                    uint32_t* __restrict__ l32, uint32_t* __restrict__ max_lcp) {
+    const uint32_t lane = threadIdx.x & 63u;
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t i0 = t * kLcpChunk;
-    if (i0 >= rows) return;
-    uint64_t i1 = i0 + kLcpChunk;
+    uint64_t i = t * kLcpChunk;
+    uint64_t i1 = i + kLcpChunk;
     if (i1 > rows) i1 = rows;
-    uint32_t h = 0, mx = 0;
-    for (uint64_t i = i0; i < i1; i++) {
-        uint32_t r = rank[i];
-        if (r == 0) { h = 0; continue; }  // the '$' suffix: row 0 keeps the sentinel
-        uint64_t j = sa[r - 1];
-        // extend: compare 16 characters per step; the unique '$' guarantees a mismatch before either suffix ends
-        for (;;) {
-            uint64_t x = window16(pk, i + h) ^ window16(pk, j + h);
-            if (x) { h += (uint32_t)__clzll((long long)x) >> 2; break; }
-            h += 16;
+    if (i > rows) i = i1 = rows;  // lanes behind the text idle, but stay for the wave-wide steps
+    uint32_t h = 0, mx = 0, r = 0;
+    // (h, pj): a lower bound of the next position's value, and -- if pj is not ~0 -- the predecessor start for which the
+    // bound is the exact value
+    uint64_t pj = ~0ull, j = 0;
+    if (i < i1) {
+        uint32_t p = coarse_h[i / kLcpCoarse1], d = (uint32_t)(i % kLcpCoarse1);
+        if (p > d) { h = p - d; pj = (uint64_t)coarse_j[i / kLcpCoarse1] + d; }
+    }
+    for (;;) {
+        // ---- every lane on its own: positions whose comparison ends within 256 letters ---------------------------
+        bool stuck = false;
+        while (i < i1) {
+            r = rank[i];
+            if (r == 0) { h = 0; pj = ~0ull; i++; continue; }  // the '$' suffix: row 0 keeps the sentinel
+            j = sa[r - 1];
+            if (j != pj) {
+                // extend: compare 16 characters per step; the unique '$' guarantees a mismatch before either suffix ends
+                for (uint32_t it = 0;; it++) {
+                    uint64_t x = window16(pk, i + h) ^ window16(pk, j + h);
+                    if (x) { h += (uint32_t)__clzll((long long)x) >> 2; break; }
+                    h += 16;
+                    if (it == 15u) { stuck = true; break; }
+                }
+                if (stuck) break;
+            }
+            l32[r] = h + 1;
+            mx = h > mx ? h : mx;
+            if (h) { h--; pj = j + 1; } else pj = ~0ull;
+            i++;
         }
-        l32[r] = h + 1;
-        mx = h > mx ? h : mx;
-        if (h) h--;
+        // ---- long comparisons (the first positions of a long repeat that no sample covers): the wave together,
+        //      4096 letters per step; a later one that runs parallel to an earlier one follows from it
+        uint64_t todo = __ballot(stuck);
+        if (!todo) break;
+        uint64_t last_i = 0, last_j = 0;
+        uint32_t last_h = 0;
+        bool have_last = false;
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint64_t ii = __shfl((unsigned long long)i, src), jj = __shfl((unsigned long long)j, src);
+            uint32_t hh = __shfl(h, src);
+            if (have_last && ii > last_i && ii - last_i < last_h && jj == last_j + (ii - last_i)) {
+                hh = last_h - (uint32_t)(ii - last_i);
+            } else {
+                hh = wave_extend_lcp(pk, ii, jj, hh, lane);
+            }
+            last_i = ii; last_j = jj; last_h = hh; have_last = true;
+            if ((int)lane == src) h = hh;
+        }
+        if (stuck) {  // finish the position that was stuck, then go on
+            l32[r] = h + 1;
+            mx = h > mx ? h : mx;
+            if (h) { h--; pj = j + 1; } else pj = ~0ull;
+            i++;
+        }
     }
     if (mx) atomicMax(max_lcp, mx);
 }
@@ -467,7 +568,8 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     SLAMEM_HIP(hipSetDevice(device));
     const uint32_t rows = n + 1;
     const uint64_t R = rows;
-    const uint64_t nwords = (R + 15) / 16 + 2;  // two zero words of slack for window16()
+    constexpr uint64_t kPackSlack = 264;  // zero words behind the text: window16() reads one word ahead, wave_extend_lcp up to 4096 letters more
+    const uint64_t nwords = (R + 15) / 16 + kPackSlack;
     const uint32_t nblocks = (uint32_t)((R + 1 + kFmRows - 1) >> kFmRowsLog2);  // occ(c, <= n) reads offset n+1
 
     Timings& tm = thread_timings();
@@ -484,8 +586,8 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     SLAMEM_HIP(hipMemsetAsync(pk.p, 0, nwords * 8, stream));
     SLAMEM_HIP(hipMemsetAsync(d_scal, 0, 64 * 4, stream));
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
-    hipLaunchKernelGGL(k_pack_text, dim3(grid_for(nwords - 2)), dim3(256), 0, stream,
-                       static_cast<const uint8_t*>(text_dev), n, pk.as<uint64_t>(), nwords - 2, d_scal);
+    hipLaunchKernelGGL(k_pack_text, dim3(grid_for(nwords - kPackSlack)), dim3(256), 0, stream,
+                       static_cast<const uint8_t*>(text_dev), n, pk.as<uint64_t>(), nwords - kPackSlack, d_scal);
     SLAMEM_HIP(hipGetLastError());
     SLAMEM_HIP(hipEventRecord(ev.b, stream));
     uint32_t h_scal[64];
@@ -683,9 +785,20 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     uint32_t* d_l32 = l32buf.as<uint32_t>();
     uint32_t* d_psv = psvbuf.as<uint32_t>();
     uint32_t* d_nsv = nsvbuf.as<uint32_t>();
+    {   // sampled passes (scratch: the PSV / NSV buffers, free until K7)
+        uint64_t n2 = (R + kLcpCoarse2 - 1) / kLcpCoarse2, n1 = (R + kLcpCoarse1 - 1) / kLcpCoarse1;
+        hipLaunchKernelGGL(k_lcp_sampled, dim3(grid_for(n2 * 64)), dim3(256), 0, stream, pk.as<uint64_t>(), d_sa,
+                           rank.as<uint32_t>(), rows, kLcpCoarse2, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u,
+                           d_psv, d_psv + n2);
+        hipLaunchKernelGGL(k_lcp_sampled, dim3(grid_for(n1 * 64)), dim3(256), 0, stream, pk.as<uint64_t>(), d_sa,
+                           rank.as<uint32_t>(), rows, kLcpCoarse1, (const uint32_t*)d_psv, (const uint32_t*)(d_psv + n2),
+                           kLcpCoarse2, d_nsv, d_nsv + n1);
+        hipLaunchKernelGGL(k_lcp_kasai, dim3(grid_for((R + kLcpChunk - 1) / kLcpChunk)), dim3(256), 0, stream,
+                           pk.as<uint64_t>(), d_sa, rank.as<uint32_t>(), rows, (const uint32_t*)d_nsv,
+                           (const uint32_t*)(d_nsv + n1), d_l32, d_scal + 9);
+    }
+    // after the sampled passes: they use the PSV / NSV buffers as scratch
     hipLaunchKernelGGL(k_lcp_sentinels, dim3(1), dim3(64), 0, stream, rows, d_l32, d_psv, d_nsv);
-    hipLaunchKernelGGL(k_lcp_kasai, dim3(grid_for((R + kLcpChunk - 1) / kLcpChunk)), dim3(256), 0, stream,
-                       pk.as<uint64_t>(), d_sa, rank.as<uint32_t>(), rows, d_l32, d_scal + 9);
     SLAMEM_HIP(hipGetLastError());
     SLAMEM_HIP(hipEventRecord(ev.b, stream));
     SLAMEM_HIP(hipEventSynchronize(ev.b));
