@@ -210,6 +210,39 @@ def test_config2_known_answer_full_size(eng):
     idx.close()
 
 
+def test_config3_known_answer_full_size(eng):
+    """BASELINE.json configs[2] -- the workload bench.py times -- at full size: 100 Mbp reference, 10 M x 150 bp reads,
+    half of them reverse-complemented, -b -l 20.  The known answer (tests/golden/config3_known_answer.json) was
+    recorded from a run of the REAL reference on the same FASTA files (tools/gen_synth.py ... 42 50; ~35 minutes of
+    one core in the build container) and digested with tools/mems_digest.py: MEM count, sum / max of the lengths and
+    sha256 over the sorted (strand block, ref, query, length) rows."""
+    import json
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from mems_digest import digest_rows
+    known = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_known_answer.json")))
+    n, nreads, L = 100_000_000, 10_000_000, 150
+    ref = eng.synth_reference(n, 42, "cuda:0")
+    reads = eng.synth_reads(ref, 0, nreads, L, 0.02, 42, 50)
+    offsets = torch.arange(nreads + 1, dtype=torch.int64, device="cuda:0") * L
+    idx = eng.Index.build(ref, "cuda:0")
+    m = idx.matcher(nreads, True, 4 * nreads, nreads * L)
+    total = m.run(reads, offsets, 20)
+    assert total == known["mems"]
+    mems = m.mems[:total].cpu().numpy().view(np.uint32)
+    boff = m.block_offsets[: 2 * nreads + 1].cpu().numpy()
+    rows = np.empty((total, 4), dtype=np.uint32)
+    rows[:, 0] = np.repeat(np.arange(2 * nreads, dtype=np.uint32), np.diff(boff))
+    rows[:, 1] = mems[:, 0] + 1
+    rows[:, 2] = mems[:, 1] + 1
+    rows[:, 3] = mems[:, 2]
+    got = digest_rows(rows)
+    assert got == {k: known[k] for k in ("mems", "sum_len", "max_len", "sha256")}
+    idx.close()
+
+
 def test_capacity_error_reports_the_need_and_retry_succeeds(eng):
     """SLAMEM_ERR_CAPACITY contract: the call fails loudly, total_out holds the room to ask for, a retry works."""
     import torch
