@@ -123,7 +123,14 @@ int main(int argc, char **argv) {
     printf("[ slaMEM v%s ]\n\n", VERSION);
     if (slh_parse_options(argc, argv, &o) != 0) exit_message("Out of memory");
     if (o.usage) { usage(argv[0]); return -1; }
-    if (o.hidden_sort || o.hidden_clean) exit_message("The -s / -c utilities are not part of this front end");
+    if (o.hidden_sort) { /* slamem.c:555-562 */
+        if (argc != 3) { printf("Usage: %s -s <mems_file>\n\n", argv[0]); return -1; }
+        return slh_sort_mems_file(argv[2], stdout);
+    }
+    if (o.hidden_clean) { /* slamem.c:563-570 */
+        if (argc != 3) { printf("Usage: %s -c <fasta_file>\n\n", argv[0]); return -1; }
+        return slh_clean_fasta(argv[2], stdout);
+    }
     if (o.num_files < 2) exit_message("Not enough input sequence files provided");
     if (o.ref_name_given && o.ref_name_empty) exit_message("No reference name string provided");
     if (o.image_arg != -1) exit_message("The -v image tool is not part of this front end (use the reference's on the *-mems.txt output)");

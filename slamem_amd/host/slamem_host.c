@@ -596,3 +596,221 @@ int slh_progress_dots(uint32_t textsize) {
     uint32_t step = textsize / 10; /* slamem.c:94 */
     return (int)(textsize / (step + 1)); /* one dot each time the counter reaches the step (slamem.c:116-120) */
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * The two hidden utilities of the reference's command line (slamem.c:555-570).  Plain host text
+ * processing; kept so that every invocation of the reference has a counterpart here.
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    char ref_name[65]; /* first word of the reference name, at most 64 characters (slamem.c:221,330) */
+    int ref_pos, query_pos, size;
+    size_t order;      /* input order: ties keep it (glibc's qsort is a merge sort) */
+} sorted_mem;
+
+static int sorted_mem_cmp(const void *pa, const void *pb) { /* MEMInfoSortFunction, slamem.c:227-239 */
+    const sorted_mem *a = (const sorted_mem *)pa, *b = (const sorted_mem *)pb;
+    const char *ca = a->ref_name, *cb = b->ref_name;
+    int diff = 0;
+    while ((diff = (int)(*ca) - (int)(*cb)) == 0 && *ca != '\0') { ca++; cb++; }
+    if (diff == 0) {
+        diff = a->ref_pos - b->ref_pos;
+        if (diff == 0) diff = a->query_pos - b->query_pos;
+    }
+    if (diff == 0) diff = a->order < b->order ? -1 : (a->order > b->order ? 1 : 0);
+    return diff;
+}
+
+/* a byte source with the reference's `char c = fgetc()` view: byte 0xFF reads as end of input */
+typedef struct { const unsigned char *p, *end; } byte_src;
+static int src_get(byte_src *s) {
+    if (s->p >= s->end) return -1;
+    if (*s->p == 0xFF) { s->p = s->end; return -1; }
+    return *s->p++;
+}
+static int is_space_c(int c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; }
+static void skip_space(byte_src *s) { while (s->p < s->end && is_space_c(*s->p)) s->p++; }
+/* scanf("%d"): optional sign, digits; returns 0 when no number starts here */
+static int scan_int(byte_src *s, int *out) {
+    const unsigned char *q;
+    long long v = 0;
+    int neg = 0, digits = 0;
+    skip_space(s);
+    q = s->p;
+    if (q < s->end && (*q == '+' || *q == '-')) { neg = *q == '-'; q++; }
+    while (q < s->end && *q >= '0' && *q <= '9') { if (v < (1LL << 40)) v = v * 10 + (*q - '0'); q++; digits++; }
+    if (!digits) return 0;
+    s->p = q;
+    *out = (int)(neg ? -v : v);
+    return 1;
+}
+
+static char *read_whole_file(const char *path, size_t *size_out) {
+    FILE *f = fopen(path, "rb");
+    char *buf;
+    long sz;
+    if (!f) return NULL;
+    if (fseek(f, 0, SEEK_END) != 0 || (sz = ftell(f)) < 0) { fclose(f); return NULL; }
+    rewind(f);
+    buf = (char *)malloc((size_t)sz + 1);
+    if (!buf) { fclose(f); return NULL; }
+    if (sz && fread(buf, 1, (size_t)sz, f) != (size_t)sz) { free(buf); fclose(f); return NULL; }
+    fclose(f);
+    *size_out = (size_t)sz;
+    return buf;
+}
+
+/* SortMEMsFile (slamem.c:244-352): every block of the MEMs file sorted by (reference name, reference position, query
+ * position) and written in DESCENDING order (the reference walks its sorted array from the end, :310-317) to
+ * <basename>-sorted.txt.  Returns the process status: 0, or 255 after an error message. */
+int slh_sort_mems_file(const char *path, FILE *log) {
+    size_t size = 0, cap = 0, num = 0, seqs = 0, k;
+    char *data, *out_name, seqname[256];
+    sorted_mem *arr = NULL;
+    byte_src s;
+    FILE *out;
+    int c, fields = 0;
+    fprintf(log, "> Sorting MEMs from <%s> ", path);
+    fflush(log);
+    data = read_whole_file(path, &size);
+    if (!data) { fprintf(log, "\n> ERROR: Cannot read input file\n"); return 255; }
+    s.p = (const unsigned char *)data;
+    s.end = s.p + size;
+    c = src_get(&s);
+    if (c != '>') { fprintf(log, "\n> ERROR: Invalid MEMs file\n"); free(data); return 255; }
+    while (c == '>') { /* :261-265: skip the header lines in front of the first MEM */
+        c = src_get(&s);
+        while (c != '\n' && c != -1) c = src_get(&s);
+        c = src_get(&s);
+    }
+    if (c == -1) { fprintf(log, "\n> ERROR: No MEMs inside file\n"); free(data); return 255; }
+    for (;;) { /* :271-278: number of fields of that line */
+        while (c == ' ' || c == '\t') c = src_get(&s);
+        if (c != '\n') {
+            fields++;
+            while (c != ' ' && c != '\t' && c != '\n' && c != -1) c = src_get(&s);
+        }
+        if (c == '\n' || c == -1) break;
+    }
+    if (fields != 3 && fields != 4) { fprintf(log, "\n> ERROR: Invalid MEMs file format\n"); free(data); return 255; }
+    s.p = (const unsigned char *)data;
+    s.end = s.p + size;
+    if (fields == 4) fprintf(log, "(multiple references) ");
+    fprintf(log, "...\n");
+    out_name = slh_append_to_basename(path, "-sorted.txt");
+    if (!out_name || (out = fopen(out_name, "w")) == NULL) {
+        fprintf(log, "> ERROR: Cannot write output file\n");
+        free(out_name); free(data);
+        return 255;
+    }
+    seqname[0] = '\0';
+    for (;;) {
+        c = src_get(&s);
+        if (c == '>' || c == -1) {
+            if (seqs != 0) { /* :304-318 */
+                fprintf(log, "(%d MEMs)\n", (int)num);
+                fflush(log);
+                qsort(arr, num, sizeof(sorted_mem), sorted_mem_cmp);
+                fprintf(out, ">%s\n", seqname);
+                for (k = num; k-- > 0;) {
+                    if (fields == 4) fprintf(out, " %s\t", arr[k].ref_name);
+                    fprintf(out, "%d\t%d\t%d\n", arr[k].ref_pos, arr[k].query_pos, arr[k].size);
+                }
+            }
+            if (c == -1) break;
+            num = 0;
+            { /* fscanf(" %255[^\n]\n") :322 */
+                size_t n = 0;
+                skip_space(&s);
+                while (s.p < s.end && *s.p != '\n' && n < 255) seqname[n++] = (char)*s.p++;
+                seqname[n] = '\0';
+                skip_space(&s);
+            }
+            fprintf(log, ":: '%s' ... ", seqname);
+            fflush(log);
+            seqs++;
+            continue;
+        }
+        s.p--; /* ungetc */
+        if (num == cap) {
+            sorted_mem *na = (sorted_mem *)realloc(arr, (cap + 1024) * sizeof(sorted_mem));
+            if (!na) { fprintf(log, "\n> ERROR: Not enough memory\n"); fclose(out); free(out_name); free(arr); free(data); return 255; }
+            arr = na;
+            cap += 1024;
+        }
+        if (fields == 4) { /* fscanf(" %64[^\t ]") :330 */
+            size_t n = 0;
+            skip_space(&s);
+            while (s.p < s.end && *s.p != '\t' && *s.p != ' ' && n < 64) arr[num].ref_name[n++] = (char)*s.p++;
+            arr[num].ref_name[n] = '\0';
+        } else arr[num].ref_name[0] = '\0';
+        if (!scan_int(&s, &arr[num].ref_pos) || !scan_int(&s, &arr[num].query_pos) || !scan_int(&s, &arr[num].size)) {
+            fprintf(log, "\n> ERROR: Invalid format\n"); /* :333-337 (the reference also waits for a key here) */
+            fclose(out); free(out_name); free(arr); free(data);
+            return 255;
+        }
+        skip_space(&s);
+        arr[num].order = num;
+        num++;
+    }
+    fprintf(log, "> Saving sorted MEMs to <%s> ...\n", out_name);
+    fflush(log);
+    fclose(out);
+    free(out_name);
+    free(arr);
+    free(data);
+    fprintf(log, "> Done!\n");
+    return 0;
+}
+
+/* CleanFasta (slamem.c:455-523): one record named after the file, holding the A/C/G/T letters (upper-cased) of all
+ * records of the input, 100 per line, written to <basename>-clean.fasta. */
+int slh_clean_fasta(const char *path, FILE *log) {
+    size_t size = 0;
+    char *data, *out_name;
+    byte_src s;
+    FILE *out;
+    unsigned int chars = 0, invalid = 0, seqs = 0, line = 0;
+    int c;
+    fprintf(log, "> Opening FASTA file <%s> ... ", path);
+    fflush(log);
+    data = read_whole_file(path, &size);
+    if (!data) { fprintf(log, "\n> ERROR: FASTA file not found\n"); return 255; }
+    s.p = (const unsigned char *)data;
+    s.end = s.p + size;
+    c = src_get(&s);
+    if (c != '>') { fprintf(log, "\n> ERROR: Invalid FASTA file\n"); free(data); return 255; }
+    fprintf(log, "OK\n");
+    out_name = slh_append_to_basename(path, "-clean.fasta");
+    fprintf(log, "> Creating clean FASTA file <%s> ... ", out_name ? out_name : "");
+    fflush(log);
+    if (!out_name || (out = fopen(out_name, "w")) == NULL) {
+        fprintf(log, "\n> ERROR: Can't write clean FASTA file\n");
+        free(out_name); free(data);
+        return 255;
+    }
+    fprintf(out, ">%s\n", path); /* the file name is the label (:479) */
+    while (c != -1) {
+        int up = (c == 'a' || c == 'c' || c == 'g' || c == 't') ? c - 32 : c;
+        if (up == 'A' || up == 'C' || up == 'G' || up == 'T') {
+            fputc(up, out);
+            chars++;
+            if (++line == 100) { fputc('\n', out); line = 0; }
+        } else if (c == '>') {
+            while (c != '\n' && c != -1) c = src_get(&s); /* skip the description */
+            seqs++;
+        } else if (c > 32 && c < 127) invalid++;
+        c = src_get(&s);
+    }
+    if (line != 0) fputc('\n', out);
+    fclose(out);
+    free(out_name);
+    free(data);
+    fprintf(log, " OK\n");
+    fprintf(log, ":: %u total chars", chars);
+    if (invalid != 0) fprintf(log, " (%u non ACGT chars removed)", invalid);
+    if (seqs > 1) fprintf(log, " ; %u sequences merged", seqs);
+    fprintf(log, "\n");
+    fprintf(log, "> Done!\n");
+    return 0;
+}

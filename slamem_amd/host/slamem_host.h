@@ -83,6 +83,11 @@ int slh_format_block(slh_buffer *buf, const char *query_name, int reverse, const
                      const slh_record *refs, const uint32_t *merged_start, int num_refs, uint64_t *sum_len_out);
 void slh_buffer_free(slh_buffer *b);
 
+/* The hidden utilities of the reference's command line: "-s <mems_file>" (SortMEMsFile, slamem.c:244-352) and
+ * "-c <fasta_file>" (CleanFasta, slamem.c:455-523).  Messages go to log; the return value is the process status. */
+int slh_sort_mems_file(const char *path, FILE *log);
+int slh_clean_fasta(const char *path, FILE *log);
+
 /* number of progress dots the reference prints for a strand of this length (slamem.c:94,116-120) */
 int slh_progress_dots(uint32_t textsize);
 

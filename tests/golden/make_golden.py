@@ -188,6 +188,23 @@ def sane_vs_bruteforce(case, out_path, refs_text, queries):
     return True
 
 
+def utilities(d):
+    """The hidden -s (sort a MEMs file) and -c (clean a FASTA file) tools of the reference, run on this case's files
+    under fixed relative names (the names appear in the messages and in the cleaned file's header)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as t:
+        shutil.copy(os.path.join(d, "expected-mems.txt"), os.path.join(t, "x-mems.txt"))
+        shutil.copy(os.path.join(d, "ref.fa"), os.path.join(t, "r.fa"))
+        r = subprocess.run([REF_BIN, "-s", "x-mems.txt"], cwd=t, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           stdin=subprocess.DEVNULL)
+        open(os.path.join(d, "sort-stdout.txt"), "wb").write(r.stdout + b"status %d\n" % r.returncode)
+        if os.path.exists(os.path.join(t, "x-mems-sorted.txt")):
+            shutil.copy(os.path.join(t, "x-mems-sorted.txt"), os.path.join(d, "sorted.txt"))
+        r = subprocess.run([REF_BIN, "-c", "r.fa"], cwd=t, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        open(os.path.join(d, "clean-stdout.txt"), "wb").write(r.stdout + b"status %d\n" % r.returncode)
+        shutil.copy(os.path.join(t, "r-clean.fasta"), os.path.join(d, "clean.fasta"))
+
+
 def main():
     if not os.path.exists(REF_BIN):
         sys.exit("build the reference first: make -C oracle ref")
@@ -218,6 +235,7 @@ def main():
                 shutil.rmtree(d)
                 continue
         open(os.path.join(d, "expected-stdout.txt"), "wb").write(r.stdout)
+        utilities(d)
         nm = sum(len(b[1]) for b in parse_blocks(os.path.join(d, "expected-mems.txt")))
         manifest[name] = {"opts": case["opts"], "ref": "ref.fa", "queries": ["q.fa"], "mems": nm}
         if "tail" in case:

@@ -143,3 +143,27 @@ def test_parallel_loader_equals_sequential(tmp_path):
     del os.environ["SLAMEM_THREADS"]
     assert a.n == b.n > 100000 and a.names == b.names and a.sizes == b.sizes
     assert a.offsets == b.offsets and a.chars == b.chars
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_hidden_sort_and_clean_utilities_match_the_reference(case, tmp_path):
+    """`slaMEM -s <mems_file>` (SortMEMsFile, slamem.c:244-352) and `slaMEM -c <fasta_file>` (CleanFasta,
+    slamem.c:455-523): output files, messages and exit status equal what the real reference produced for the same
+    files (tests/golden/<case>/sorted.txt, sort-stdout.txt, clean.fasta, clean-stdout.txt).  No GPU involved."""
+    import shutil
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", hostlib.HOST_DIR], stdout=subprocess.DEVNULL)
+    ref_fa, _, exp_mems, _ = case_paths(case)
+    d = os.path.dirname(exp_mems)
+    shutil.copy(exp_mems, tmp_path / "x-mems.txt")
+    shutil.copy(ref_fa, tmp_path / "r.fa")
+    r = subprocess.run([exe, "-s", "x-mems.txt"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.stdout + b"status %d\n" % r.returncode == open(os.path.join(d, "sort-stdout.txt"), "rb").read()
+    if os.path.exists(os.path.join(d, "sorted.txt")):
+        assert open(tmp_path / "x-mems-sorted.txt", "rb").read() == open(os.path.join(d, "sorted.txt"), "rb").read()
+    else:
+        assert not os.path.exists(tmp_path / "x-mems-sorted.txt")
+    r = subprocess.run([exe, "-c", "r.fa"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.stdout + b"status %d\n" % r.returncode == open(os.path.join(d, "clean-stdout.txt"), "rb").read()
+    assert open(tmp_path / "r-clean.fasta", "rb").read() == open(os.path.join(d, "clean.fasta"), "rb").read()
