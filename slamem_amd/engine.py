@@ -186,7 +186,7 @@ class Index:
         num = offsets.shape[0] - 1
         qd = torch.zeros((q.shape[0] + 15) // 8 * 8, dtype=torch.uint8, device=dev)
         if q.shape[0]:
-            qd[: q.shape[0]] = torch.from_numpy(q).to(dev)
+            qd[: q.shape[0]] = torch.from_numpy(q if q.flags.writeable else q.copy()).to(dev)
         od = torch.from_numpy(offsets.view(np.int64)).to(dev)
         cap = max(1024, q.shape[0] // 8 + 4 * num)
         while True:

@@ -42,10 +42,11 @@ def shard_bounds(offsets: np.ndarray, world_size: int) -> np.ndarray:
     return bounds
 
 
-def broadcast_arena(arena: torch.Tensor | None, device, src: int = 0) -> torch.Tensor:
-    """Replicate the index arena (uint8 tensor) from rank `src` to every rank: size first, then the bytes."""
+def broadcast_arena(arena: torch.Tensor | None, device, src: int = 0, force: bool = False) -> torch.Tensor:
+    """Replicate the index arena (uint8 tensor) from rank `src` to every rank: size first, then the bytes.
+    force: issue the collectives even in a one-rank group (rehearsal of the RCCL calls on a one-GPU box)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_initialized()):
         assert arena is not None
         return arena
     size = torch.zeros(1, dtype=torch.int64, device=device)
@@ -58,11 +59,11 @@ def broadcast_arena(arena: torch.Tensor | None, device, src: int = 0) -> torch.T
     return arena
 
 
-def gather_counts(count: int, device) -> torch.Tensor:
+def gather_counts(count: int, device, force: bool = False) -> torch.Tensor:
     """All ranks learn every rank's MEM count (int64[world])."""
     rank, ws = world()
     mine = torch.tensor([count], dtype=torch.int64, device=device)
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_initialized()):
         return mine
     out = torch.zeros(ws, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, mine) if device.type == "cuda" else dist.all_gather(list(out.split(1)), mine)
