@@ -34,6 +34,11 @@ static void gpu_fail(const char *what, int rc) {
     exit(-1);
 }
 
+static void gpu_fail_msg(const char *what, int rc, const char *detail) { /* the detail was captured on another thread */
+    printf("\n> ERROR: %s failed: %s (%s)\n", what, slamem_strerror(rc), detail);
+    exit(-1);
+}
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -89,6 +94,35 @@ static void *gpu_part_run(void *arg) {
     return NULL;
 }
 
+/* The index is built on the GPU by its own host thread while the main thread parses the query files: the two do not
+ * depend on each other (the reference does them one after the other, slamem.c:635-651 then :73-74). */
+typedef struct {
+    const char *text;
+    uint32_t n;
+    int device;
+    slamem_index *idx;
+    slamem_index_info info;
+    slamem_timings tm;
+    slamem_sslcp_stats st;
+    int rc, rc_stats;
+    double seconds;
+    char err[512];
+} build_job;
+
+static void *build_run(void *arg) {
+    build_job *b = (build_job *)arg;
+    double t0 = now_s();
+    b->rc = slamem_index_build(b->text, b->n, b->device, &b->idx);
+    if (b->rc == SLAMEM_OK) {
+        slamem_index_get_info(b->idx, &b->info);
+        slamem_get_timings(&b->tm); /* timings and error text are per thread: take them here */
+        b->rc_stats = slamem_index_sampled_lcp_stats(b->idx, &b->st);
+    }
+    if (b->rc != SLAMEM_OK || b->rc_stats != SLAMEM_OK) snprintf(b->err, sizeof(b->err), "%s", slamem_last_error_message());
+    b->seconds = now_s() - t0;
+    return NULL;
+}
+
 static void usage(const char *prog) { /* slamem.c:533-553 */
     printf("Usage:\n");
     printf("\t%s (<options>) <reference_file> <query_file(s)>\n", prog);
@@ -119,6 +153,9 @@ int main(int argc, char **argv) {
     double t0;
     long long total_matches = 0, total_sum = 0;
     slh_buffer buf = {0, 0, 0};
+    build_job bj;
+    pthread_t build_tid;
+    int build_async = 0;
 
     printf("[ slaMEM v%s ]\n\n", VERSION);
     if (slh_parse_options(argc, argv, &o) != 0) exit_message("Out of memory");
@@ -142,6 +179,7 @@ int main(int argc, char **argv) {
     int timing = getenv("SLAMEM_TIMING") != NULL;
     /* load everything (slamem.c:635-651) */
     memset(&ref, 0, sizeof(ref));
+    memset(&bj, 0, sizeof(bj));
     qsets = (slh_seqset *)calloc((size_t)o.num_files, sizeof(slh_seqset));
     if (!qsets) exit_message("Out of memory");
     {
@@ -154,14 +192,20 @@ int main(int argc, char **argv) {
                 have_ref = 1;
                 numbering += n;
                 o.file_args[0] = o.file_args[f]; /* remember which argument was the reference */
+                bj.text = ref.chars;
+                bj.n = (uint32_t)ref.total;
+                bj.device = device;
+                build_async = pthread_create(&build_tid, NULL, build_run, &bj) == 0;
             } else {
                 int n = slh_load_file(path, 0, o.no_ns, (uint32_t)o.min_seq_len, NULL, numbering, log_limit, &qsets[num_qsets], stdout);
                 if (n != 0) { numbering += n; total_queries += n; num_qsets++; }
             }
         }
     }
-    if (num_qsets == 0) exit_message("No query files provided"); /* slamem.c:648 */
     t_load = now_s() - t_start;
+    if (build_async) pthread_join(build_tid, NULL); /* before any exit: never leave the process with a build in flight */
+    else build_run(&bj);
+    if (num_qsets == 0) exit_message("No query files provided"); /* slamem.c:648 */
     printf("> %d reference%s and %d quer%s successfully loaded\n", ref.num, ref.num == 1 ? "" : "s", total_queries,
            total_queries == 1 ? "y" : "ies");
     if (o.min_mem_len < 1) exit_message("Minimum match length must be at least 1");
@@ -183,22 +227,19 @@ int main(int argc, char **argv) {
     printf(" (%u Mbp) ...\n", (unsigned)(ref.total / 1000000U));
     fflush(stdout);
     t0 = now_s();
-    rc = slamem_index_build(ref.chars, (uint32_t)ref.total, device, &idx);
-    if (rc != SLAMEM_OK) gpu_fail("index construction on the GPU", rc);
+    idx = bj.idx;
+    if (bj.rc != SLAMEM_OK) gpu_fail_msg("index construction on the GPU", bj.rc, bj.err);
     {
-        slamem_index_info info;
-        slamem_timings tm;
-        slamem_index_get_info(idx, &info);
-        slamem_get_timings(&tm);
-        printf("> Suffix sort + BWT + LCP + parent links on GPU %d ... OK (%.3f s; device %.1f ms: sort %.1f, BWT %.1f, LCP %.1f, links %.1f; %u doubling rounds)\n",
-               device, now_s() - t0, tm.build_total_ms, tm.build_sort_ms, tm.build_bwt_ms, tm.build_lcp_ms, tm.build_links_ms,
+        slamem_index_info info = bj.info;
+        slamem_timings tm = bj.tm;
+        printf("> Suffix sort + BWT + LCP + parent links on GPU %d ... OK (%.3f s, overlapped with the loading of the queries; device %.1f ms: sort %.1f, BWT %.1f, LCP %.1f, links %.1f; %u doubling rounds)\n",
+               device, bj.seconds, tm.build_total_ms, tm.build_sort_ms, tm.build_bwt_ms, tm.build_lcp_ms, tm.build_links_ms,
                info.sort_rounds);
         printf(":: Index size = %.1f MB in HBM (FM blocks + 16 B per row)\n", (double)info.arena_bytes / 1e6);
         {   /* the statistics lines of BuildSampledLCPArray (lcparray.c:709-711, 999-1000), from the per-row records */
-            slamem_sslcp_stats st;
+            slamem_sslcp_stats st = bj.st;
             unsigned bwt_len = info.bwt_size;
-            rc = slamem_index_sampled_lcp_stats(idx, &st);
-            if (rc != SLAMEM_OK) gpu_fail("LCP sampling statistics", rc);
+            if (bj.rc_stats != SLAMEM_OK) gpu_fail_msg("LCP sampling statistics", bj.rc_stats, bj.err);
             printf(":: %.2lf%% samples (%u of %u)\n", ((double)st.num_samples / (double)bwt_len) * 100.0, (unsigned)st.num_samples, bwt_len);
             printf(":: %.2lf%% oversized samples (%d of %u)\n", ((double)st.num_oversized_lcp / (double)st.num_samples) * 100.0,
                    (int)st.num_oversized_lcp, (unsigned)st.num_samples);
@@ -229,7 +270,7 @@ int main(int argc, char **argv) {
         if (ngpu == 1) { slamem_index_free(idx); idx = gpus[0]; } /* self-test: search on the broadcast copy */
         printf("> Index replicated to %d GPU%s by RCCL broadcast ... OK (%.3f s)\n", ngpu, ngpu == 1 ? " (self-test copy)" : "s", now_s() - tr);
     }
-    t_build = now_s() - t0;
+    t_build = bj.seconds + (now_s() - t0);
     free(ref.chars); /* the reference frees the text here too (slamem.c:75-77) */
     ref.chars = NULL;
     printf("> Matching query sequences against index ...\n");
@@ -358,6 +399,7 @@ int main(int argc, char **argv) {
             printf(":: ... (%ld more strand blocks matched; set SLAMEM_VERBOSE=1 for a line each)\n",
                    (long)total_queries * strands - log_limit);
     }
+    double t_end0 = now_s();
     for (i = 0; i < ngpu; i++) slamem_index_free(gpus[i]);
     if (total_queries != 1) /* slamem.c:210-212 (the reference divides by zero when nothing matched) */
         printf(":: Average %d M%cMs found per query sequence (total = %lld, avg size = %d bp)\n",
@@ -375,7 +417,7 @@ int main(int argc, char **argv) {
     slh_free_options(&o);
     printf("> Done!\n");
     if (timing)
-        fprintf(stderr, "[timing] load %.3f s, index build %.3f s, GPU search incl. transfers %.3f s, format %.3f s (of which write %.3f s), total %.3f s\n",
-                t_load, t_build, t_gpu, t_format - t_write, t_write, now_s() - t_start);
+        fprintf(stderr, "[timing] load %.3f s (index build of %.3f s overlapped), GPU search incl. transfers %.3f s, format %.3f s + write %.3f s, close/free %.3f s, total %.3f s\n",
+                t_load, t_build, t_gpu, t_format - t_write, t_write, now_s() - t_end0, now_s() - t_start);
     return 0;
 }
