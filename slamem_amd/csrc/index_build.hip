@@ -20,6 +20,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <chrono>
+#include <stdio.h>
 
 namespace slamem {
 
@@ -524,9 +526,11 @@ namespace {
 
 struct DevBuf {
     void* p = nullptr;
+    bool owned = true;
     ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; }
+    hipError_t alloc(size_t bytes) { owned = true; return hipMalloc(&p, bytes ? bytes : 16); }
+    void view(void* q) { release(); p = q; owned = false; }  // memory that belongs to somebody else (the arena)
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
@@ -573,6 +577,19 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     const uint32_t nblocks = (uint32_t)((R + 1 + kFmRows - 1) >> kFmRowsLog2);  // occ(c, <= n) reads offset n+1
 
     Timings& tm = thread_timings();
+    // SLAMEM_BUILD_TRACE=1: host wall clock of every phase (allocations included) on stderr
+    const bool trace = getenv("SLAMEM_BUILD_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_last = t_begin;
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(stream);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[build] %-28s %8.1f ms  (at %.1f ms)\n", what,
+                std::chrono::duration<double, std::milli>(now - t_last).count(),
+                std::chrono::duration<double, std::milli>(now - t_begin).count());
+        t_last = now;
+    };
     EventPair ev_all, ev;
     SLAMEM_HIP(ev_all.init());
     SLAMEM_HIP(ev.init());
@@ -595,6 +612,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     SLAMEM_HIP(hipStreamSynchronize(stream));
     SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_pack_ms, ev.a, ev.b));
     const uint32_t num_n = h_scal[1];
+    mark("K1 pack (+alloc)");
 
     // ---- arena ------------------------------------------------------------------------------
     ArenaHeader hdr;
@@ -640,15 +658,39 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
     hdr.total_bytes = off;
 
+    // ---- memory plan -------------------------------------------------------------------------------------------
+    // The arena is allocated FIRST and lends its row-record and filter regions to the suffix sort (they are written
+    // only after it), the LCP / PSV / NSV arrays reuse sort buffers, and nothing is freed before the end: the driver
+    // wipes freed VRAM in the background at ~33 GiB/s and an allocation that needs memory still waiting for its wipe
+    // blocks (measured at 3.1 Gbp: 9.3 of 10.7 s of the build were two such hipMalloc calls; tools/malloc_probe.hip).
+    // Peak = arena + 26.5 B per row (was: 50 B per row, then arena + 24 B per row after a free).
+    DevBuf arena;
+    if (arena.alloc(hdr.total_bytes) != hipSuccess) {
+        set_error("slamem_index_build: cannot allocate %llu bytes of HBM for the index", (unsigned long long)hdr.total_bytes);
+        return SLAMEM_ERR_NOMEM;
+    }
+    char* base = arena.as<char>();
+    struct Region { char* p; uint64_t left; };
+    Region lend[2] = {{base + hdr.off_rec, (R + 1) * sizeof(RowRec)},
+                      {hdr.off_kfilter ? base + hdr.off_kfilter : nullptr, hdr.off_kfilter ? (8ull << hdr.kfilter_log2) : 0ull}};
+    auto borrow = [&](DevBuf& b, uint64_t bytes) -> hipError_t {  // from the arena if it fits, else an own allocation
+        bytes = align_up(bytes, 16);
+        for (Region& r : lend)
+            if (r.p && r.left >= bytes) { b.view(r.p); r.p += bytes; r.left -= bytes; return hipSuccess; }
+        return b.alloc(bytes);
+    };
+
     // ---- K2: suffix sort ----------------------------------------------------------------------
     DevBuf keysA, keysB, valsA, valsB, rank, flagA, flagB, tmp32, gh, posA, posB, sorttmp, sabuf;
-    if (sabuf.alloc(R * 4) != hipSuccess || keysA.alloc(R * 8) != hipSuccess || keysB.alloc(R * 8) != hipSuccess || valsA.alloc(R * 4) != hipSuccess ||
-        valsB.alloc(R * 4) != hipSuccess || rank.alloc(R * 4) != hipSuccess || flagA.alloc(R) != hipSuccess ||
-        flagB.alloc(R) != hipSuccess || tmp32.alloc(R * 4) != hipSuccess || gh.alloc(R * 4) != hipSuccess ||
-        posA.alloc(R * 4) != hipSuccess || posB.alloc(R * 4) != hipSuccess) {
+    // keysA later holds LCP+1 and PSV, posA holds NSV (R+1 words each): sized for that, never borrowed
+    if (sabuf.alloc(R * 4) != hipSuccess || keysA.alloc((R + 1) * 8 + 64) != hipSuccess || rank.alloc(R * 4) != hipSuccess ||
+        flagA.alloc(R) != hipSuccess || flagB.alloc(R) != hipSuccess || posA.alloc((R + 1) * 4) != hipSuccess ||
+        borrow(keysB, R * 8) != hipSuccess || borrow(valsA, R * 4) != hipSuccess || borrow(valsB, R * 4) != hipSuccess ||
+        borrow(tmp32, R * 4) != hipSuccess || borrow(gh, R * 4) != hipSuccess || borrow(posB, R * 4) != hipSuccess) {
         set_error("slamem_index_build: cannot allocate suffix-sort scratch (%llu rows)", (unsigned long long)R);
         return SLAMEM_ERR_NOMEM;
     }
+    mark("arena + scratch hipMalloc");
     uint32_t* d_sa = sabuf.as<uint32_t>();
     size_t tmp_bytes = 0, need = 0;
     SLAMEM_HIP(sort_pairs_u64_u32(nullptr, need, keysA.as<uint64_t>(), keysB.as<uint64_t>(), valsA.as<uint32_t>(),
@@ -718,17 +760,8 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     SLAMEM_HIP(hipEventSynchronize(ev.b));
     SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_sort_ms, ev.a, ev.b));
     hdr.sort_rounds = rounds;
-    // rank[] is now the inverse suffix array.
-    // the sort's scratch is dead: free it before the arena and the LCP scratch are allocated (peak HBM at 3.1 Gbp:
-    // ~155 GB in the sort, ~145 GB afterwards)
-    keysB.release(); valsA.release(); valsB.release(); flagB.release(); tmp32.release(); gh.release();
-    posA.release(); posB.release();
-    DevBuf arena;
-    if (arena.alloc(hdr.total_bytes) != hipSuccess) {
-        set_error("slamem_index_build: cannot allocate %llu bytes of HBM for the index", (unsigned long long)hdr.total_bytes);
-        return SLAMEM_ERR_NOMEM;
-    }
-    char* base = arena.as<char>();
+    // rank[] is now the inverse suffix array; the borrowed regions of the arena are free again.
+    mark("K2 suffix sort");
     FMBlock* d_fm = reinterpret_cast<FMBlock*>(base + hdr.off_fm);
     RowRec* d_rec = reinterpret_cast<RowRec*>(base + hdr.off_rec);
     uint32_t* d_nrows = reinterpret_cast<uint32_t*>(base + hdr.off_nrows);
@@ -742,6 +775,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
 
 
+    mark("K1b k-mer filter");
     // ---- K3: BWT planes + rank samples ------------------------------------------------------------
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
     SLAMEM_HIP(hipMemsetAsync(d_fm, 0, (uint64_t)nblocks * sizeof(FMBlock), stream));
@@ -775,16 +809,11 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
 
     // ---- K5: LCP --------------------------------------------------------------------------------------
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
-    // scratch reuse: the sort buffers are free now
-    DevBuf l32buf, psvbuf, nsvbuf;  // R+1 words each
-    if (l32buf.alloc((R + 1) * 4) != hipSuccess || psvbuf.alloc((R + 1) * 4) != hipSuccess ||
-        nsvbuf.alloc((R + 1) * 4) != hipSuccess) {
-        set_error("slamem_index_build: cannot allocate LCP scratch");
-        return SLAMEM_ERR_NOMEM;
-    }
-    uint32_t* d_l32 = l32buf.as<uint32_t>();
-    uint32_t* d_psv = psvbuf.as<uint32_t>();
-    uint32_t* d_nsv = nsvbuf.as<uint32_t>();
+    // scratch reuse: LCP+1 and PSV in the first sort key buffer (its use as K3 scratch is over), NSV in posA
+    mark("K3 BWT");
+    uint32_t* d_l32 = keysA.as<uint32_t>();
+    uint32_t* d_psv = d_l32 + align_up(R + 1, 4);
+    uint32_t* d_nsv = posA.as<uint32_t>();
     {   // sampled passes (scratch: the PSV / NSV buffers, free until K7)
         uint64_t n2 = (R + kLcpCoarse2 - 1) / kLcpCoarse2, n1 = (R + kLcpCoarse1 - 1) / kLcpCoarse1;
         hipLaunchKernelGGL(k_lcp_sampled, dim3(grid_for(n2 * 64)), dim3(256), 0, stream, pk.as<uint64_t>(), d_sa,
@@ -812,8 +841,9 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     L.size[0] = R + 1;
     L.count = 1;
     {
-        uint32_t* lvbuf = keysA.as<uint32_t>();  // about (R+1)/31 words in total; keysA holds 2R words
-        uint64_t used = 0, cap = R * 2 - 1;       // in uint32 units (one word kept for the guard level)
+        uint32_t* lvbuf = valsA.as<uint32_t>();  // about (R+1)/31 words in total; valsA holds R words and is dead (if it
+                                                 // was borrowed from the record region: that is written last, below)
+        uint64_t used = 0, cap = R - 1;           // in uint32 units (one word kept for the guard level)
         uint64_t sz = R + 1;
         std::vector<uint64_t> sizes;
         uint64_t total = 0;
@@ -859,6 +889,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_links_ms, ev.a, ev.b));
     hdr.dollar_row = h_scal[8];
     hdr.max_lcp = h_scal[9];
+    mark("K5 LCP + K7 links + records");
 
     SLAMEM_HIP(hipMemcpyAsync(base, &hdr, sizeof(hdr), hipMemcpyHostToDevice, stream));
     SLAMEM_HIP(hipEventRecord(ev_all.b, stream));

@@ -3,7 +3,10 @@
 size-independent properties only -- every sampled MEM is a real match and maximal on both sides (checked
 against the text itself), MEMs per read and structure statistics stay where theory puts them.
 
-    tools/scale_check.py <n> [reads]        e.g. 1000000000, 2200000000 (> 2^31: 32-bit row arithmetic)
+    tools/scale_check.py <n> [reads] [min_len] [repeats]
+        e.g. 1000000000, 2200000000 (> 2^31: 32-bit row arithmetic)
+        repeats=1 plants the repeat model of SURVEY.md 8(d): 0.5 % of the text copied as 1-10 kbp segments with 1 %
+        divergence (BASELINE.json configs[3] = 248000000 6250000 50 1 per GPU, configs[4] = 3100000000 12500000 20 1)
 """
 import json
 import os
@@ -19,9 +22,23 @@ from slamem_amd import engine  # noqa: E402
 def main():
     n = int(sys.argv[1])
     nreads = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+    min_len = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    repeats = len(sys.argv) > 4 and sys.argv[4] != "0"
     L = 150
     dev = torch.device("cuda:0")
     ref = engine.synth_reference(n, 42, dev)
+    planted = 0
+    if repeats:
+        g = np.random.default_rng(7)
+        acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        while planted < n // 200:
+            ln = int(g.integers(1000, 10001))
+            src, dst = int(g.integers(0, n - ln)), int(g.integers(0, n - ln))
+            seg = ref[src:src + ln].clone()
+            mut = torch.rand(ln, device=dev) < 0.01
+            seg[mut] = acgt[torch.randint(0, 4, (int(mut.sum().item()),), device=dev)]
+            ref[dst:dst + ln] = seg
+            planted += ln
     torch.cuda.synchronize()
     t0 = time.time()
     idx = engine.Index.build(ref, dev)
@@ -32,9 +49,9 @@ def main():
     reads = engine.synth_reads(ref, 0, nreads, L, 0.02, 42, 50)
     offsets = torch.arange(nreads + 1, dtype=torch.int64, device=dev) * L
     m = idx.matcher(nreads, True, 8 * nreads, nreads * L)
-    m.run(reads, offsets, 20)
+    m.run(reads, offsets, min_len)
     engine.reset_timings()
-    total = m.run(reads, offsets, 20)
+    total = m.run(reads, offsets, min_len)
     kms = engine.timings()["search_kernel_ms"]
     mems = m.mems[:total].cpu().numpy().view(np.uint32).astype(np.int64)
     boff = m.block_offsets[: 2 * nreads + 1].cpu().numpy()
@@ -46,7 +63,7 @@ def main():
     for x, y in zip(b"ACGT", b"TGCA"):
         comp[x] = y
     r, q, ln = mems[:, 0], mems[:, 1], mems[:, 2]
-    assert (ln >= 20).all() and (q + ln <= L).all() and (r + ln <= n).all()
+    assert (ln >= min_len).all() and (q + ln <= L).all() and (r + ln <= n).all()
     bad = 0
     sel = np.random.default_rng(0).choice(total, size=min(total, 50_000), replace=False)
     for i in sel:
@@ -58,7 +75,7 @@ def main():
         ok = ok and (a == 0 or b == 0 or ref_h[a - 1] != rd[b - 1])
         ok = ok and (a + c == n or b + c == L or ref_h[a + c] != rd[b + c])
         bad += not ok
-    out = {"n": n, "reads": nreads, "build_wall_s": round(build_s, 3), "build_ms": tm, "sort_rounds": int(idx.info.sort_rounds),
+    out = {"n": n, "reads": nreads, "min_len": min_len, "planted_repeat_bp": planted, "build_wall_s": round(build_s, 3), "build_ms": tm, "sort_rounds": int(idx.info.sort_rounds),
            "max_lcp": int(idx.info.max_lcp), "index_GB": round(idx.info.arena_bytes / 1e9, 2),
            "samples_pct": round(100.0 * st["num_samples"] / (n + 1), 2), "mean_lcp": st["sum_lcp"] // (n + 1),
            "mems": int(total), "mems_per_read": round(total / nreads, 3), "checked": int(len(sel)), "bad": int(bad),
