@@ -84,6 +84,9 @@ int slamem_abi_version(void);
 const char *slamem_strerror(int code);
 const char *slamem_last_error_message(void);
 int slamem_device_count(int *count_out);
+/* Creates the HIP context of `device` (runtime start-up takes ~0.2 s): a front end calls this from a helper thread
+ * while it parses its input, so that the index build does not pay for it.  No reference counterpart. */
+int slamem_device_warmup(int device);
 int slamem_get_timings(slamem_timings *out);
 int slamem_reset_timings(void);
 

@@ -22,7 +22,7 @@ ARRAY_SA, ARRAY_BWT, ARRAY_LCP, ARRAY_PSV, ARRAY_NSV = range(5)
 # every symbol include/slamem_hip.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = (
     "slamem_abi_version", "slamem_strerror", "slamem_last_error_message", "slamem_device_count",
-    "slamem_get_timings", "slamem_reset_timings",
+    "slamem_get_timings", "slamem_reset_timings", "slamem_device_warmup",
     "slamem_index_build", "slamem_index_build_device", "slamem_index_free", "slamem_index_get_info",
     "slamem_index_arena", "slamem_index_export", "slamem_index_attach", "slamem_index_adopt_arena", "slamem_index_save", "slamem_index_load",
     "slamem_index_download", "slamem_index_sampled_lcp_stats",

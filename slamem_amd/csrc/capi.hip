@@ -96,6 +96,12 @@ int slamem_device_count(int* count_out) {
     return SLAMEM_OK;
 }
 
+int slamem_device_warmup(int device) {
+    SLAMEM_HIP(hipSetDevice(device));
+    SLAMEM_HIP(hipFree(nullptr));
+    return SLAMEM_OK;
+}
+
 int slamem_get_timings(slamem_timings* out) {
     if (!out) return SLAMEM_ERR_ARG;
     *out = g_tm.t;

@@ -11,6 +11,7 @@
  * SLAMEM_BATCH_MB bounds the query characters sent to the GPU per batch (default 1024).
  */
 #include <stdio.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -24,18 +25,28 @@
 #define VERSION "0.8.2"
 static const char MATCH_TYPE_CHAR[] = "EAU";
 
+/* the device warm-up thread (see main) is joined before the process ends, whichever way it ends */
+static pthread_t g_warm_tid;
+static int g_warm_started = 0;
+static void join_warmup(void) {
+    if (g_warm_started) { g_warm_started = 0; pthread_join(g_warm_tid, NULL); }
+}
+
 static void exit_message(const char *msg) { /* tools.c:21-25 */
     printf("> ERROR: %s\n", msg);
+    join_warmup();
     exit(-1);
 }
 
 static void gpu_fail(const char *what, int rc) {
     printf("\n> ERROR: %s failed: %s (%s)\n", what, slamem_strerror(rc), slamem_last_error_message());
+    join_warmup();
     exit(-1);
 }
 
 static void gpu_fail_msg(const char *what, int rc, const char *detail) { /* the detail was captured on another thread */
     printf("\n> ERROR: %s failed: %s (%s)\n", what, slamem_strerror(rc), detail);
+    join_warmup();
     exit(-1);
 }
 
@@ -61,6 +72,8 @@ typedef struct {
 static void *fmt_run(void *arg) {
     fmt_job *j = (fmt_job *)arg;
     uint64_t b;
+    /* about 36 characters per MEM line and a header per block: reserve once instead of doubling on the way */
+    (void)slh_buffer_reserve(&j->buf, (size_t)(j->boff[j->b1] - j->boff[j->b0]) * 36 + (size_t)(j->b1 - j->b0) * 48 + 4096);
     for (b = j->b0; b < j->b1; b++) {
         int i = j->first_rec + (int)(b / (uint64_t)j->strands), s = (int)(b % (uint64_t)j->strands);
         uint64_t cnt = j->boff[b + 1] - j->boff[b], sum = 0;
@@ -123,6 +136,67 @@ static void *build_run(void *arg) {
     return NULL;
 }
 
+/* One batch of query records: its shares are searched on the GPUs by their own host threads while the main thread
+ * formats and writes the batch before it (GPU(b+1) overlaps format(b)). */
+typedef struct {
+    const slh_seqset *q;
+    int first, last, nparts;
+    gpu_part parts[16];
+    pthread_t tid[16];
+    int threaded[16];
+} batch_t;
+
+static batch_t *batch_start(const slh_seqset *q, int first, int last, slamem_index **gpus, int ngpu, uint32_t min_len,
+                            int both, int mam) {
+    batch_t *b = (batch_t *)calloc(1, sizeof(batch_t));
+    uint64_t base = q->offsets[first], tot = q->offsets[last] - base;
+    int part, r0 = first, i;
+    if (!b) return NULL;
+    b->q = q; b->first = first; b->last = last; b->nparts = ngpu;
+    for (part = 0; part < ngpu; part++) { /* contiguous shares with (almost) equal numbers of bases, one per GPU */
+        uint64_t target = base + tot * (uint64_t)(part + 1) / (uint64_t)ngpu;
+        int r1 = r0;
+        gpu_part *g = &b->parts[part];
+        if (part == ngpu - 1) r1 = last;
+        else while (r1 < last && q->offsets[r1 + 1] <= target) r1++;
+        g->idx = gpus[part];
+        g->first = r0;
+        g->last = r1;
+        g->chars = q->chars + q->offsets[r0];
+        g->offs = (uint64_t *)malloc(((size_t)(r1 - r0) + 1) * sizeof(uint64_t));
+        if (!g->offs) return NULL;
+        for (i = r0; i <= r1; i++) g->offs[i - r0] = q->offsets[i] - q->offsets[r0];
+        g->min_len = min_len;
+        g->both = both;
+        g->mam = mam;
+        r0 = r1;
+    }
+    for (part = 0; part < ngpu; part++) {
+        b->threaded[part] = pthread_create(&b->tid[part], NULL, gpu_part_run, &b->parts[part]) == 0;
+        if (!b->threaded[part]) gpu_part_run(&b->parts[part]);
+    }
+    return b;
+}
+
+static void batch_join(batch_t *b, int device) {
+    int part;
+    for (part = 0; part < b->nparts; part++) {
+        if (b->threaded[part]) pthread_join(b->tid[part], NULL);
+        b->threaded[part] = 0;
+    }
+    for (part = 0; part < b->nparts; part++)
+        if (b->parts[part].rc != SLAMEM_OK) {
+            printf("\n> ERROR: MEM search on GPU %d failed: %s (%s)\n", device + part, slamem_strerror(b->parts[part].rc),
+                   b->parts[part].err);
+            exit(-1);
+        }
+}
+
+static void *warmup_run(void *arg) { /* HIP runtime + context start-up, hidden behind the parsing of the reference file */
+    (void)slamem_device_warmup(*(int *)arg);
+    return NULL;
+}
+
 static void usage(const char *prog) { /* slamem.c:533-553 */
     printf("Usage:\n");
     printf("\t%s (<options>) <reference_file> <query_file(s)>\n", prog);
@@ -144,7 +218,7 @@ int main(int argc, char **argv) {
     slh_seqset ref, *qsets;
     int i, f, num_qsets = 0, total_queries = 0, device = 0, numbering = 1;
     long log_limit = 100;
-    uint64_t batch_bytes = 1024ull << 20;
+    uint64_t batch_bytes = 256ull << 20; /* query characters per batch and GPU */
     const char *env;
     char *out_name;
     FILE *out;
@@ -175,6 +249,11 @@ int main(int argc, char **argv) {
     if ((env = getenv("SLAMEM_VERBOSE")) != NULL && atoi(env) != 0) log_limit = 0;
     if ((env = getenv("SLAMEM_BATCH_MB")) != NULL && atoll(env) > 0) batch_bytes = (uint64_t)atoll(env) << 20;
 
+    {
+        static int warm_device;
+        warm_device = device;
+        g_warm_started = pthread_create(&g_warm_tid, NULL, warmup_run, &warm_device) == 0;
+    }
     double t_start = now_s(), t_load = 0, t_build = 0, t_gpu = 0, t_format = 0, t_write = 0;
     int timing = getenv("SLAMEM_TIMING") != NULL;
     /* load everything (slamem.c:635-651) */
@@ -205,6 +284,7 @@ int main(int argc, char **argv) {
     t_load = now_s() - t_start;
     if (build_async) pthread_join(build_tid, NULL); /* before any exit: never leave the process with a build in flight */
     else build_run(&bj);
+    join_warmup();
     if (num_qsets == 0) exit_message("No query files provided"); /* slamem.c:648 */
     printf("> %d reference%s and %d quer%s successfully loaded\n", ref.num, ref.num == 1 ? "" : "s", total_queries,
            total_queries == 1 ? "y" : "ies");
@@ -279,48 +359,47 @@ int main(int argc, char **argv) {
     {
         int strands = o.both_strands ? 2 : 1;
         long printed = 0;
+        /* the list of batches (records [first,last) of one query file each), then a two-stage pipeline over it */
+        typedef struct { int f, first, last; } batch_range;
+        batch_range *ranges = NULL;
+        size_t nranges = 0, cap_ranges = 0, bi;
+        batch_t *cur = NULL, *nxt = NULL;
         for (f = 0; f < num_qsets; f++) {
             slh_seqset *q = &qsets[f];
             int first = 0;
-            while (first < q->num) { /* batches of records */
-                int last = first, part;
+            while (first < q->num) {
+                int last = first;
                 uint64_t base = q->offsets[first];
-                gpu_part parts[16];
-                pthread_t ptid[16];
-                double tg = now_s();
                 while (last < q->num && (last == first || q->offsets[last + 1] - base <= batch_bytes * (uint64_t)ngpu)) last++;
-                memset(parts, 0, sizeof(parts));
-                {   /* contiguous shares with (almost) equal numbers of bases, one per GPU, searched concurrently */
-                    uint64_t tot = q->offsets[last] - base;
-                    int r0 = first;
-                    for (part = 0; part < ngpu; part++) {
-                        uint64_t target = base + tot * (uint64_t)(part + 1) / (uint64_t)ngpu;
-                        int r1 = r0;
-                        if (part == ngpu - 1) r1 = last;
-                        else while (r1 < last && q->offsets[r1 + 1] <= target) r1++;
-                        parts[part].idx = gpus[part];
-                        parts[part].first = r0;
-                        parts[part].last = r1;
-                        parts[part].chars = q->chars + q->offsets[r0];
-                        parts[part].offs = (uint64_t *)malloc(((size_t)(r1 - r0) + 1) * sizeof(uint64_t));
-                        if (!parts[part].offs) exit_message("Out of memory");
-                        for (i = r0; i <= r1; i++) parts[part].offs[i - r0] = q->offsets[i] - q->offsets[r0];
-                        parts[part].min_len = (uint32_t)o.min_mem_len;
-                        parts[part].both = o.both_strands;
-                        parts[part].mam = o.match_type == 1;
-                        r0 = r1;
-                    }
-                    for (part = 0; part < ngpu; part++)
-                        if (part == ngpu - 1 || pthread_create(&ptid[part], NULL, gpu_part_run, &parts[part]) != 0) { gpu_part_run(&parts[part]); ptid[part] = 0; }
-                    for (part = 0; part < ngpu; part++) {
-                        if (ptid[part]) pthread_join(ptid[part], NULL);
-                        if (parts[part].rc != SLAMEM_OK) {
-                            printf("\n> ERROR: MEM search on GPU %d failed: %s (%s)\n", device + part, slamem_strerror(parts[part].rc), parts[part].err);
-                            exit(-1);
-                        }
-                    }
+                if (nranges == cap_ranges) {
+                    cap_ranges = cap_ranges ? cap_ranges * 2 : 16;
+                    ranges = (batch_range *)realloc(ranges, cap_ranges * sizeof(batch_range));
+                    if (!ranges) exit_message("Out of memory");
                 }
-                t_gpu += now_s() - tg;
+                ranges[nranges].f = f; ranges[nranges].first = first; ranges[nranges].last = last;
+                nranges++;
+                first = last;
+            }
+        }
+        if (nranges) {
+            cur = batch_start(&qsets[ranges[0].f], ranges[0].first, ranges[0].last, gpus, ngpu, (uint32_t)o.min_mem_len,
+                              o.both_strands, o.match_type == 1);
+            if (!cur) exit_message("Out of memory");
+        }
+        for (bi = 0; bi < nranges; bi++) {
+            slh_seqset *q = &qsets[ranges[bi].f];
+            gpu_part *parts;
+            int part;
+            double tg = now_s();
+            batch_join(cur, device);
+            if (bi + 1 < nranges) { /* the next batch goes to the GPUs while this one is formatted and written */
+                nxt = batch_start(&qsets[ranges[bi + 1].f], ranges[bi + 1].first, ranges[bi + 1].last, gpus, ngpu,
+                                  (uint32_t)o.min_mem_len, o.both_strands, o.match_type == 1);
+                if (!nxt) exit_message("Out of memory");
+            } else nxt = NULL;
+            parts = cur->parts;
+            {
+                t_gpu += now_s() - tg; /* time the main thread waited for the GPUs */
                 tg = now_s();
                 for (part = 0; part < ngpu; part++) {
                     const int pfirst = parts[part].first, plast = parts[part].last;
@@ -392,15 +471,18 @@ int main(int argc, char **argv) {
                     free(parts[part].offs);
                 }
                 t_format += now_s() - tg;
-                first = last;
             }
+            free(cur);
+            cur = nxt;
         }
+        free(ranges);
         if (log_limit != 0 && (long)total_queries * strands > log_limit)
             printf(":: ... (%ld more strand blocks matched; set SLAMEM_VERBOSE=1 for a line each)\n",
                    (long)total_queries * strands - log_limit);
     }
-    double t_end0 = now_s();
+    double t_end0 = now_s(), t_end1, t_end2;
     for (i = 0; i < ngpu; i++) slamem_index_free(gpus[i]);
+    t_end1 = now_s();
     if (total_queries != 1) /* slamem.c:210-212 (the reference divides by zero when nothing matched) */
         printf(":: Average %d M%cMs found per query sequence (total = %lld, avg size = %d bp)\n",
                (int)(total_matches / total_queries), MATCH_TYPE_CHAR[o.match_type], total_matches,
@@ -408,6 +490,7 @@ int main(int argc, char **argv) {
     fflush(stdout);
     printf("> Saving M%cMs to <%s> ... ", MATCH_TYPE_CHAR[o.match_type], out_name);
     if (fclose(out) != 0) exit_message("Cannot write output file");
+    t_end2 = now_s();
     printf("OK\n");
     if (o.out_arg == -1) free(out_name);
     slh_buffer_free(&buf);
@@ -417,7 +500,7 @@ int main(int argc, char **argv) {
     slh_free_options(&o);
     printf("> Done!\n");
     if (timing)
-        fprintf(stderr, "[timing] load %.3f s (index build of %.3f s overlapped), GPU search incl. transfers %.3f s, format %.3f s + write %.3f s, close/free %.3f s, total %.3f s\n",
-                t_load, t_build, t_gpu, t_format - t_write, t_write, now_s() - t_end0, now_s() - t_start);
+        fprintf(stderr, "[timing] load %.3f s (index build of %.3f s overlapped), waiting for the GPU (search + transfers, overlapped with formatting) %.3f s, format %.3f s + write %.3f s, index free %.3f s, close %.3f s, host free %.3f s, total %.3f s\n",
+                t_load, t_build, t_gpu, t_format - t_write, t_write, t_end1 - t_end0, t_end2 - t_end1, now_s() - t_end2, now_s() - t_start);
     return 0;
 }

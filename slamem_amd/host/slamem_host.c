@@ -5,6 +5,7 @@
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 /* ------------------------------------------------------------------------------------------------ */
 /* FASTA                                                                                             */
@@ -52,10 +53,30 @@ static char *name_alloc(void **arena, size_t len) {
 
 static int rd(reader *r) { return r->p < r->end ? (int)*r->p++ : EOF; }
 
+/* Buffers of tens of MB and more (sequence characters, record tables): 2 MB aligned and marked for transparent huge
+ * pages, which takes most of the page-fault and unmap time out of a 1.5 GB read set.  free() releases them. */
+void *slh_big_malloc(size_t bytes) {
+    void *p = NULL;
+    if (bytes < ((size_t)32 << 20)) return malloc(bytes ? bytes : 1);
+    bytes = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+    if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) return NULL;
+#ifdef MADV_HUGEPAGE
+    (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+    return p;
+}
+
 static int grow(char **buf, uint64_t *cap, uint64_t need) {
     if (need <= *cap) return 0;
     uint64_t nc = *cap ? *cap : (1u << 20);
     while (nc < need) nc += nc / 2 + (1u << 20);
+    if (*buf == NULL) { /* the loaders size their character buffer once, from the file size */
+        char *fb = (char *)slh_big_malloc(nc);
+        if (!fb) return -1;
+        *buf = fb;
+        *cap = nc;
+        return 0;
+    }
     char *nb = (char *)realloc(*buf, nc);
     if (!nb) return -1;
     *buf = nb;
@@ -256,11 +277,28 @@ typedef struct {
     FILE *log;
     slh_seqset set;
     int n;
+    slh_seqset *dst;   /* second phase: this piece is copied to characters dst_cpos.. / records dst_rpos.. of dst */
+    uint64_t dst_cpos;
+    int dst_rpos;
 } load_job;
 
 static void *load_job_run(void *arg) {
     load_job *j = (load_job *)arg;
     j->n = j->size > 0 ? load_mem(j->data, j->size, 0, j->acgt_only, j->min_len, NULL, j->first_number, j->log_limit, &j->set, j->log) : 0;
+    return NULL;
+}
+
+void slh_free_seqset(slh_seqset *s);
+
+static void *concat_job_run(void *arg) {
+    load_job *j = (load_job *)arg;
+    const slh_seqset *s = &j->set;
+    int i;
+    if (j->n == 0) return NULL;
+    memcpy(j->dst->chars + j->dst_cpos, s->chars, s->total);
+    memcpy(j->dst->recs + j->dst_rpos, s->recs, (size_t)s->num * sizeof(slh_record));
+    for (i = 0; i < s->num; i++) j->dst->offsets[j->dst_rpos + i] = s->offsets[i] + j->dst_cpos;
+    slh_free_seqset(&j->set); /* its names were handed over before; unmapping 100 MB pieces is worth doing in parallel too */
     return NULL;
 }
 
@@ -307,19 +345,19 @@ static int load_parallel(const unsigned char *data, long fsize, int acgt_only, u
     memset(out, 0, sizeof(*out));
     out->file_bytes = fsize;
     if (total > 0) {
-        out->recs = (slh_record *)malloc((size_t)total * sizeof(slh_record));
-        out->offsets = (uint64_t *)malloc(((size_t)total + 1) * sizeof(uint64_t));
-        out->chars = (char *)malloc(chars_total + 16);
+        out->recs = (slh_record *)slh_big_malloc((size_t)total * sizeof(slh_record));
+        out->offsets = (uint64_t *)slh_big_malloc(((size_t)total + 1) * sizeof(uint64_t));
+        out->chars = (char *)slh_big_malloc(chars_total + 16);
         if (!out->recs || !out->offsets || !out->chars) ok = 0;
         else {
             uint64_t cpos = 0;
-            int rpos = 0, i;
-            for (t = 0; t < threads; t++) {
+            int rpos = 0;
+            for (t = 0; t < threads; t++) { /* where every piece goes; then the pieces are copied by the threads again */
                 slh_seqset *s = &jobs[t].set;
+                jobs[t].dst = out;
+                jobs[t].dst_cpos = cpos;
+                jobs[t].dst_rpos = rpos;
                 if (jobs[t].n == 0) continue;
-                memcpy(out->chars + cpos, s->chars, s->total);
-                memcpy(out->recs + rpos, s->recs, (size_t)s->num * sizeof(slh_record));
-                for (i = 0; i < s->num; i++) out->offsets[rpos + i] = s->offsets[i] + cpos;
                 cpos += s->total;
                 rpos += s->num;
                 if (s->name_arena) { /* the names stay where they are: chain the arenas */
@@ -330,6 +368,9 @@ static int load_parallel(const unsigned char *data, long fsize, int acgt_only, u
                     s->name_arena = NULL;
                 }
             }
+            for (t = 0; t < threads; t++)
+                if (pthread_create(&tid[t], NULL, concat_job_run, &jobs[t]) != 0) { concat_job_run(&jobs[t]); tid[t] = 0; }
+            for (t = 0; t < threads; t++) if (tid[t]) pthread_join(tid[t], NULL);
             out->offsets[total] = cpos;
             memset(out->chars + cpos, 0, 16);
             out->total = cpos;
@@ -534,12 +575,21 @@ static int buf_reserve(slh_buffer *b, size_t extra) {
     if (b->len + extra <= b->cap) return 0;
     size_t nc = b->cap ? b->cap * 2 : (1u << 16);
     while (nc < b->len + extra) nc *= 2;
+    if (b->data == NULL) { /* first reservation: callers that know their size ask for all of it (huge pages if large) */
+        char *fd = (char *)slh_big_malloc(nc);
+        if (!fd) return -1;
+        b->data = fd;
+        b->cap = nc;
+        return 0;
+    }
     char *nd = (char *)realloc(b->data, nc);
     if (!nd) return -1;
     b->data = nd;
     b->cap = nc;
     return 0;
 }
+
+int slh_buffer_reserve(slh_buffer *b, size_t bytes) { return buf_reserve(b, bytes); }
 
 static inline char *put_u32(char *p, uint32_t v) {
     char tmp[10];

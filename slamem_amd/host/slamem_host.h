@@ -40,6 +40,8 @@ typedef struct {
 int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, const char *name_filter,
                   int first_number, long log_limit, slh_seqset *out, FILE *log);
 void slh_free_seqset(slh_seqset *s);
+/* malloc for buffers of tens of MB and more: 2 MB aligned, marked for transparent huge pages; release with free() */
+void *slh_big_malloc(size_t bytes);
 /* host threads used for loading / formatting: SLAMEM_THREADS or the online CPUs, at most 32 */
 int slh_thread_count(void);
 
@@ -82,6 +84,8 @@ typedef struct {
 int slh_format_block(slh_buffer *buf, const char *query_name, int reverse, const uint32_t *mems, uint64_t count,
                      const slh_record *refs, const uint32_t *merged_start, int num_refs, uint64_t *sum_len_out);
 void slh_buffer_free(slh_buffer *b);
+/* make room for `bytes` more characters in one step (slh_format_block grows the buffer by doubling otherwise) */
+int slh_buffer_reserve(slh_buffer *b, size_t bytes);
 
 /* The hidden utilities of the reference's command line: "-s <mems_file>" (SortMEMsFile, slamem.c:244-352) and
  * "-c <fasta_file>" (CleanFasta, slamem.c:455-523).  Messages go to log; the return value is the process status. */
