@@ -233,12 +233,14 @@ int main(int argc, char **argv) {
 
     printf("[ slaMEM v%s ]\n\n", VERSION);
     if (slh_parse_options(argc, argv, &o) != 0) exit_message("Out of memory");
-    if (o.usage) { usage(argv[0]); return -1; }
+    if (o.usage) { usage(argv[0]); slh_free_options(&o); return -1; }
     if (o.hidden_sort) { /* slamem.c:555-562 */
+        slh_free_options(&o);
         if (argc != 3) { printf("Usage: %s -s <mems_file>\n\n", argv[0]); return -1; }
         return slh_sort_mems_file(argv[2], stdout);
     }
     if (o.hidden_clean) { /* slamem.c:563-570 */
+        slh_free_options(&o);
         if (argc != 3) { printf("Usage: %s -c <fasta_file>\n\n", argv[0]); return -1; }
         return slh_clean_fasta(argv[2], stdout);
     }

@@ -760,7 +760,7 @@ int slh_sort_mems_file(const char *path, FILE *log) {
             if (seqs != 0) { /* :304-318 */
                 fprintf(log, "(%d MEMs)\n", (int)num);
                 fflush(log);
-                qsort(arr, num, sizeof(sorted_mem), sorted_mem_cmp);
+                if (num) qsort(arr, num, sizeof(sorted_mem), sorted_mem_cmp);
                 fprintf(out, ">%s\n", seqname);
                 for (k = num; k-- > 0;) {
                     if (fields == 4) fprintf(out, " %s\t", arr[k].ref_name);
