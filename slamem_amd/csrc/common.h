@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 4;
+constexpr uint32_t kArenaVersion = 5;  // 5: the presence filter also holds the (k-2)-mers (two-level prefilter)
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -96,6 +96,8 @@ __host__ __device__ inline uint64_t kfilter_hash(uint64_t kmer) {
     kmer ^= kmer >> 33;
     return kmer;
 }
+// the filter holds two k-mer lengths, k and k-2; the shorter ones are hashed with this salt
+constexpr uint64_t kFilterShortSalt = 0x9E3779B97F4A7C15ull;
 __host__ __device__ inline uint64_t kfilter_bits(uint64_t h) { return (1ull << ((h >> 52) & 63u)) | (1ull << ((h >> 58) & 63u)); }
 
 // Raw record written by the search kernel before the per-block compaction (K9).

@@ -214,15 +214,22 @@ __global__ void __launch_bounds__(256) k_rank_samples(const uint4* __restrict__ 
 __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
                                                        uint32_t log2_words, unsigned long long* __restrict__ filter) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i + k > n) return;
+    if (i + (k - 2u) > n) return;
+    const uint64_t wmask = (1ull << log2_words) - 1ull;
     uint64_t km = 0;
-    for (uint32_t d = 0; d < k; d++) {
+    for (uint32_t d = 0; d < k && i + d < n; d++) {
         uint32_t c = nibble_at(pk, i + d);
         if (c < 2u) return;  // N inside the window
         km = (km << 2) | (uint64_t)(c - 2u);
+        if (d + 1u == k - 2u) {  // the (k-2)-mer that starts here (first level of the prefilter)
+            uint64_t h = kfilter_hash(km ^ kFilterShortSalt);
+            atomicOr(&filter[h & wmask], (unsigned long long)kfilter_bits(h));
+        }
+        if (d + 1u == k) {
+            uint64_t h = kfilter_hash(km);
+            atomicOr(&filter[h & wmask], (unsigned long long)kfilter_bits(h));
+        }
     }
-    uint64_t h = kfilter_hash(km);
-    atomicOr(&filter[h & ((1ull << log2_words) - 1ull)], (unsigned long long)kfilter_bits(h));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -769,7 +776,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     if (hdr.off_kfilter) {
         unsigned long long* d_filter = reinterpret_cast<unsigned long long*>(base + hdr.off_kfilter);
         SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));
-        hipLaunchKernelGGL(k_kfilter_build, dim3(grid_for((uint64_t)n - hdr.kfilter_k + 1)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(k_kfilter_build, dim3(grid_for((uint64_t)n - hdr.kfilter_k + 3)), dim3(256), 0, stream,
                            pk.as<uint64_t>(), n, hdr.kfilter_k, hdr.kfilter_log2, d_filter);
         SLAMEM_HIP(hipGetLastError());
     }

@@ -808,14 +808,59 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
     uint32_t a = sl * kSliceLen;
     uint32_t b = d.len - a < kSliceLen ? d.len : a + kSliceLen;
     uint8_t res = 0;
-    if (d.len >= k && d.len - a >= 1u) {
+    const uint64_t wmask = (1ull << ix.kfilter_log2) - 1ull;
+    if (d.len >= k && d.len - a >= 1u && s <= 6u) {
+        // Two levels (short minimum lengths, where one level would probe almost every window): a MEM >= L that starts
+        // in [a,b) contains a (k-2)-mer window starting at a multiple of s1 = L-(k-2)+1 inside [a, b+s1-2], AND -- if m
+        // is where the MEM starts and p that window -- the k-mer starting at max(m, p-2), one of p-2, p-1, p.  So the
+        // k-mers are probed only behind a (k-2)-mer that is present: s1/s times fewer probes for an empty strand, and
+        // far fewer chance survivors (a random strand needs a (k-2)-mer hit and a k-mer hit next to it).
+        const uint32_t k1 = k - 2u, s1 = L - k1 + 1u;
+        uint64_t p0 = ((uint64_t)a + s1 - 1) / s1 * s1;
+        uint64_t pmax = (uint64_t)b + s1 - 2;
+        if (pmax > d.len - k1) pmax = d.len - k1;
+        if (p0 <= pmax) {
+            QueryCursor qc;
+            qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
+            const uint64_t mask = (1ull << (2u * k)) - 1ull, mask1 = (1ull << (2u * k1)) - 1ull;
+            uint64_t km = 0;
+            uint32_t run = 0, confirm = 0;
+            uint64_t x = p0 >= 2 ? p0 - 2 : 0, xend = pmax + k1 + 1;  // two letters more for the k-mers at p-1 and p
+            if (xend > (uint64_t)d.len - 1) xend = (uint64_t)d.len - 1;
+            for (; x <= xend && !res; x++) {
+                uint32_t c = qc.at((uint32_t)x);
+                if (c >= 2u) { km = ((km << 2) | (uint64_t)(c - 2u)) & mask; run++; }
+                else { km = 0; run = 0; }
+                if (x + 1 >= p0 + k1) {
+                    uint64_t p = x + 1 - k1;                    // short window [p, p+k1)
+                    if (p <= pmax && p % s1 == 0) {
+                        if (run < k1) res = 1;                  // holds an N: cannot be ruled out
+                        else {
+                            uint64_t h = kfilter_hash((km & mask1) ^ kFilterShortSalt), bits = kfilter_bits(h);
+                            if ((ix.kfilter[h & wmask] & bits) == bits) confirm = 3;  // k-mers ending at x, x+1, x+2
+                        }
+                    }
+                }
+                if (confirm && !res) {
+                    confirm--;
+                    if (x + 1 >= k) {                           // the k-mer [x+1-k, x+1) lies inside the strand
+                        if (run < k) res = 1;
+                        else {
+                            uint64_t h = kfilter_hash(km), bits = kfilter_bits(h);
+                            if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
+                        }
+                    }
+                }
+            }
+        }
+    } else if (d.len >= k && d.len - a >= 1u) {
         uint64_t p0 = ((uint64_t)a + s - 1) / s * s;            // first sampled window start >= a
         uint64_t pmax = (uint64_t)b + s - 2;                     // last window start that can serve this slice
         if (pmax > d.len - k) pmax = d.len - k;
         if (p0 <= pmax) {
             QueryCursor qc;
             qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
-            const uint64_t mask = (1ull << (2u * k)) - 1ull, wmask = (1ull << ix.kfilter_log2) - 1ull;
+            const uint64_t mask = (1ull << (2u * k)) - 1ull;
             uint64_t km = 0;
             uint32_t run = 0;
             for (uint64_t x = p0; x <= pmax + k - 1 && !res; x++) {
