@@ -62,6 +62,8 @@ typedef struct {
     uint64_t arena_bytes;  /* bytes of HBM the index occupies             */
     int32_t device;
     int32_t owns_arena;
+    uint32_t filter_k;     /* k of the k-mer presence filter (0 = the index has none); no reference counterpart */
+    uint32_t reserved;
 } slamem_index_info;
 
 /* Per-phase device times of the last build / search on this thread's most recent

@@ -154,6 +154,8 @@ int slamem_index_get_info(const slamem_index* idx, slamem_index_info* out) {
     out->arena_bytes = idx->arena_bytes;
     out->device = idx->device;
     out->owns_arena = idx->owns_arena;
+    out->filter_k = idx->hdr.off_kfilter ? idx->hdr.kfilter_k : 0u;
+    out->reserved = 0;
     return SLAMEM_OK;
 }
 

@@ -69,3 +69,52 @@ def test_random_case_matches_oracle_in_order(seed):
     for f in ("ref_pos", "query_pos", "length"):
         assert np.array_equal(gm[f], om[f]), (f, len(text), l, both)
     g.close()
+
+
+@pytest.mark.parametrize("l", [12, 13, 14, 15, 16, 17, 18, 19, 20, 25])
+def test_prefilter_never_drops_a_strand_with_a_barely_long_enough_mem(l):
+    """The presence prefilter (one- and two-level, K8a) on its worst case: strands whose ONLY match is l .. l+3 letters
+    long, placed at the strand's ends, in the middle and across the 4096-position slice borders of long records, on both
+    strands.  k = 12 for this text, so l = 12..17 takes the two-level path, l >= 18 the one-level path."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from oracle import pyoracle as po
+    from slamem_amd import engine
+    rng = np.random.default_rng(500 + l)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = 50_001
+    t = rng.choice(acgt, size=n)
+    comp = np.arange(256, dtype=np.uint8)
+    for u, v in zip(b"ACGT", b"TGCA"):
+        comp[u] = v
+    qs = []
+    for qlen, places in [(150, [0, 1, 2, 3, 4, 5, 60, 61, 62, 63, 64, None]),
+                         (9000, [0, 4090, 4092, 4094, 4096, 4097, 4100, 8180, 8190, None])]:
+        for d in range(4):
+            for at in places:
+                m = l + d
+                pos = qlen - m if at is None else at
+                if pos + m > qlen:
+                    continue
+                q = rng.choice(acgt, size=qlen)  # junk: random 12-mers rarely occur in a 50 kbp text
+                x = int(rng.integers(1, n - m - 1))
+                q[pos:pos + m] = t[x:x + m]
+                if pos > 0:  # make the copy maximal: the letters next to it differ from the text's
+                    q[pos - 1] = acgt[(int(np.searchsorted(acgt, t[x - 1])) + 1) % 4]
+                if pos + m < qlen:
+                    q[pos + m] = acgt[(int(np.searchsorted(acgt, t[x + m])) + 1) % 4]
+                qs.append(q if (len(qs) % 2 == 0) else comp[q[::-1]])
+    q = np.concatenate(qs)
+    off = np.zeros(len(qs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in qs])
+    o = po.OracleIndex(t.tobytes())
+    om, obc = o.match_batch(q, off, l, True)
+    g = engine.Index.build(t.tobytes())
+    assert g.info.filter_k == 12
+    gm, goff = g.find_mems(q, off, l, True)
+    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+    for f in ("ref_pos", "query_pos", "length"):
+        assert np.array_equal(gm[f], om[f]), f
+    assert len(om) >= len(qs)  # every record has its planted match (on one of the two strands)
+    g.close()
