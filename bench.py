@@ -220,7 +220,15 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_query_base": bytes_per_base,
-                           "query_bases_per_launch": bases_per_launch}
+                           "query_bases_per_launch": bases_per_launch,
+                           # `achieved` charges the REFERENCE's work (op counts of the restated algorithm
+                           # on these reads x reference-layout bytes); the engine skips part of that work (the presence
+                           # prefilter proves most wrong-strand scans empty), so the fraction can pass 1.  What the
+                           # kernels really move is `traffic`; they are bound by the rate of dependent random 64-B lines:
+                           "note": "algorithmic bytes of the reference's algorithm / time; real HBM bytes are in traffic",
+                           "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+                           "random_lines_per_s": (traffic / 64.0 / (kernel_ms * 1e-3)) if traffic else None,
+                           "random_line_ceiling_per_s": 55e9}
         out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
