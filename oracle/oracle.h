@@ -7,8 +7,10 @@
  *
  * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement
  * against outputs of the real reference (oracle/_ref/slaMEM, compiled from
- * /root/reference by oracle/Makefile) committed under tests/golden/, and
- * against the brute-force MEM definition (oracle_brute_force_mems).
+ * /root/reference by oracle/Makefile) committed under tests/golden/ (22 cases,
+ * five of them in -mam mode), and against the brute-force MEM definition
+ * (oracle_brute_force_mems).  The full-size known answers of the real reference
+ * (tests/golden/config3_known_answer.json) pin the GPU path directly.
  *
  * Every function cites the reference file:line whose behaviour it restates.
  */
