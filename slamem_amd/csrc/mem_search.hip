@@ -510,6 +510,10 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     }
     __syncthreads();
 
+#ifdef SLAMEM_K8_STATS
+    // diagnostic build: how many loads of each kind the lanes issue (reported per launch by find_mems_device)
+    uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_pos = 0, n_enum = 0;
+#endif
     bool active = false, pend = false, dir_moved = false;
     uint32_t st = ST_EXT, dir_r = 0;  // state; text position where the current (unique) match starts
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
@@ -566,6 +570,9 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             kb.a = kb.b = kb.c = kb.d = make_uint4(0, 0, 0, 0);
             if (st == ST_EXT) {
                 uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
+#ifdef SLAMEM_K8_STATS
+                n_kt += bt != tag_t; n_kb += bb != bt; n_rec_pend += (pend && pub >= L);
+#endif
                 if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
                 if (bb != bt) kb = load_blk(ix.fm, bb);
                 // records together with the blocks: when a pending position's parent may still be >= min_len deep
@@ -591,6 +598,9 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 W = j - a_pos;  // positions that may still be consumed by this item
                 if (W > 16u) W = 16u;
             }
+#ifdef SLAMEM_K8_STATS
+            n_trips++; n_rec_fail += st == ST_REC; n_rec_flush += st == ST_FLUSH;
+#endif
             if (want_rec) { rt = R[top]; rb = R[bot + 1u]; }
             if (st == ST_EXT) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
 
@@ -740,6 +750,9 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 }
             }
             if (consumed) {
+#ifdef SLAMEM_K8_STATS
+                n_pos++;
+#endif
                 j--;  // position j is done: it matched `depth` characters
                 bool in_slice = j >= a_pos && j < b_pos;
                 pend = depth >= L && depth > 0 && in_slice;  // slamem.c:130
@@ -789,7 +802,19 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             A.item_attempt[g] = (uint8_t)attempt;
             active = false;
         }
+#ifdef SLAMEM_K8_STATS
+        n_enum += e_on;
+#endif
     }
+#ifdef SLAMEM_K8_STATS
+    {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.total) + 1024;  // see find_mems_device
+        atomicAdd(dbg + 0, (unsigned long long)n_kt); atomicAdd(dbg + 1, (unsigned long long)n_kb);
+        atomicAdd(dbg + 2, (unsigned long long)n_rec_fail); atomicAdd(dbg + 3, (unsigned long long)n_rec_pend);
+        atomicAdd(dbg + 4, (unsigned long long)n_rec_flush); atomicAdd(dbg + 5, (unsigned long long)n_trips);
+        atomicAdd(dbg + 6, (unsigned long long)n_pos); atomicAdd(dbg + 7, (unsigned long long)n_enum);
+    }
+#endif
 }
 
 // K8a: presence prefilter.  A MEM of length >= L that starts in the item's slice [a,b) contains a k-mer window
@@ -1026,7 +1051,11 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     WorkspaceLayout w;
     w.max_items = strands * (num_queries + query_bytes / kSliceLen + 1);
     uint64_t off = 0;
+#ifdef SLAMEM_K8_STATS
+    w.off_total = off;    off = align_up(off + 16384, 256);  // + the diagnostic counters at word 1024
+#else
     w.off_total = off;    off = align_up(off + 64, 256);
+#endif
     w.off_cnt = off;      off = align_up(off + (num_queries + 2) * 4, 256);
     w.off_first = off;    off = align_up(off + (num_queries + 2) * 4, 256);
     w.off_scan32 = off;   off = align_up(off + scan_u32_tmp_words(num_queries + 1) * 4, 256);
@@ -1108,7 +1137,11 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     do {
         hipError_t e;
 #define STEP(call, what) if ((e = (call)) != hipSuccess) { rc = hip_fail(e, what, __FILE__, __LINE__); break; }
+#ifdef SLAMEM_K8_STATS
+        STEP(hipMemsetAsync(d_total, 0, 16384, stream), "memset");
+#else
         STEP(hipMemsetAsync(d_total, 0, 64, stream), "memset");
+#endif
         // ---- work items: one per strand, long records cut into slices (v1 scans whole strands) ----------------
         uint64_t nitems = num_blocks;
         hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
@@ -1199,6 +1232,15 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         STEP(hipMemcpyAsync(&listed, d_total, 8, hipMemcpyDeviceToHost, stream), "memcpy");
         STEP(hipMemcpyAsync(&total, d_itemoff + nitems, 8, hipMemcpyDeviceToHost, stream), "memcpy");
         STEP(hipStreamSynchronize(stream), "k_find_mems (sync)");
+#ifdef SLAMEM_K8_STATS
+        {
+            unsigned long long dbg[8];
+            (void)hipMemcpy(dbg, d_total + 1024, sizeof(dbg), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[K8 stats] items %llu: FM block loads top %llu + bottom %llu, record pairs: failed extension %llu, "
+                            "pending parent %llu, flush %llu; lane trips %llu, positions %llu, enumerations %llu\n",
+                    (unsigned long long)nitems, dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+        }
+#endif
         *total_out = total;
         if (total > mems_capacity || listed > mems_capacity) {
             // the atomic list also holds the records of abandoned slice attempts: ask for room for those too
