@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 5;  // 5: the presence filter also holds the (k-2)-mers (two-level prefilter)
+constexpr uint32_t kArenaVersion = 6;  // 6: the presence filter holds the (k-2)-, k- and (k+2)-mers (cascaded prefilter)
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -96,8 +96,10 @@ __host__ __device__ inline uint64_t kfilter_hash(uint64_t kmer) {
     kmer ^= kmer >> 33;
     return kmer;
 }
-// the filter holds two k-mer lengths, k and k-2; the shorter ones are hashed with this salt
+// the filter holds three k-mer lengths, k-2, k and k+2 (the last only while k+2 <= 32); the shorter and the longer
+// ones are hashed with these salts
 constexpr uint64_t kFilterShortSalt = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t kFilterLongSalt = 0xD6E8FEB86659FD93ull;
 __host__ __device__ inline uint64_t kfilter_bits(uint64_t h) { return (1ull << ((h >> 52) & 63u)) | (1ull << ((h >> 58) & 63u)); }
 
 // Raw record written by the search kernel before the per-block compaction (K9).

@@ -216,8 +216,9 @@ __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restric
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i + (k - 2u) > n) return;
     const uint64_t wmask = (1ull << log2_words) - 1ull;
+    const uint32_t kmax = k + 2u <= 32u ? k + 2u : k;
     uint64_t km = 0;
-    for (uint32_t d = 0; d < k && i + d < n; d++) {
+    for (uint32_t d = 0; d < kmax && i + d < n; d++) {
         uint32_t c = nibble_at(pk, i + d);
         if (c < 2u) return;  // N inside the window
         km = (km << 2) | (uint64_t)(c - 2u);
@@ -227,6 +228,10 @@ __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restric
         }
         if (d + 1u == k) {
             uint64_t h = kfilter_hash(km);
+            atomicOr(&filter[h & wmask], (unsigned long long)kfilter_bits(h));
+        }
+        if (d + 1u == k + 2u) {  // third level (k + 2 <= 32: it fits the 64-bit rolling value)
+            uint64_t h = kfilter_hash(km ^ kFilterLongSalt);
             atomicOr(&filter[h & wmask], (unsigned long long)kfilter_bits(h));
         }
     }

@@ -847,10 +847,16 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
         if (p0 <= pmax) {
             QueryCursor qc;
             qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
-            const uint64_t mask = (1ull << (2u * k)) - 1ull, mask1 = (1ull << (2u * k1)) - 1ull;
+            // third level: if the MEM is at least k+2 long it also contains the (k+2)-mer that starts at max(m, s'-2), where
+            // s' is the start of the k-mer above -- one of s'-2, s'-1, s'.  For L == k+2 that makes the test exact up to the
+            // filter's false positives: a strand survives only if it really shares L letters with the text.
+            const bool three = L >= k + 2u && k + 2u <= 32u;
+            const uint32_t kw = three ? k + 2u : k;  // letters kept in the rolling value
+            const uint64_t mask = kw >= 32u ? ~0ull : (1ull << (2u * kw)) - 1ull;
+            const uint64_t maskk = (1ull << (2u * k)) - 1ull, mask1 = (1ull << (2u * k1)) - 1ull;
             uint64_t km = 0;
-            uint32_t run = 0, confirm = 0;
-            uint64_t x = p0 >= 2 ? p0 - 2 : 0, xend = pmax + k1 + 1;  // two letters more for the k-mers at p-1 and p
+            uint32_t run = 0, confirm = 0, confirm2 = 0;
+            uint64_t x = p0 >= 4 ? p0 - 4 : 0, xend = pmax + k1 + 1 + (three ? 2u : 0u);
             if (xend > (uint64_t)d.len - 1) xend = (uint64_t)d.len - 1;
             for (; x <= xend && !res; x++) {
                 uint32_t c = qc.at((uint32_t)x);
@@ -871,7 +877,20 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
                     if (x + 1 >= k) {                           // the k-mer [x+1-k, x+1) lies inside the strand
                         if (run < k) res = 1;
                         else {
-                            uint64_t h = kfilter_hash(km), bits = kfilter_bits(h);
+                            uint64_t h = kfilter_hash(km & maskk), bits = kfilter_bits(h);
+                            if ((ix.kfilter[h & wmask] & bits) == bits) {
+                                if (three) confirm2 = 3;        // (k+2)-mers ending at x, x+1, x+2
+                                else res = 1;
+                            }
+                        }
+                    }
+                }
+                if (confirm2 && !res) {
+                    confirm2--;
+                    if (x + 1 >= k + 2u) {
+                        if (run < k + 2u) res = 1;
+                        else {
+                            uint64_t h = kfilter_hash(km ^ kFilterLongSalt), bits = kfilter_bits(h);
                             if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
                         }
                     }
