@@ -172,7 +172,7 @@ int slamem_char_at_bwt_pos_batch(const slamem_index *idx, const uint32_t *rows_d
  * length >= min_len is reported.
  *
  *   queries_dev       concatenated query characters (A,C,G,T,N; other bytes = N);
- *                     8-byte aligned and readable up to the next multiple of 8 bytes
+ *                     16-byte aligned and readable up to the next multiple of 16 bytes
  *   offsets_dev       uint64[num_queries+1]; record i is [offsets[i], offsets[i+1])
  *   query_bytes       offsets[num_queries] (total characters; sizes the work-item tables: records longer than 4096
  *                     characters are cut into slices that different lanes scan)

@@ -196,32 +196,57 @@ struct __attribute__((aligned(16))) ItemDesc {
     uint32_t slice_rev;  // slice index | reverse strand << 31
 };
 
-struct QueryCursor {
-    const uint64_t* words;
-    uint64_t base;    // byte offset of the record
-    uint64_t wlo, whi;  // first / last word index that holds characters of this record
+// Letters of one strand of a query record, read through a window of kBytes (16 or 32) held in registers: aligned
+// 16-byte loads, 5-10 per strand of 150 letters.  (With 8-byte words, a word per 8 letters, the line was fetched
+// again for almost every word: the random index traffic evicts it from L1 and L2 between two uses.)
+// The buffer is 16-byte aligned (checked by the host side); a half window is read only if it overlaps the record.
+template <uint32_t kBytes>
+struct QueryCursorT {
+    const uint64_t* words;  // the query buffer
+    uint64_t base;          // byte offset of the record
     uint32_t len;
-    uint32_t rev;     // reverse-complement view
-    uint64_t widx, wnidx;
-    uint64_t w, wn;   // current word and the next one in scan direction (prefetched one word ahead)
+    uint32_t rev;           // reverse-complement view
+    uint64_t cidx;          // offset of the window held, ~0 = none
+    uint64_t q0, q1, q2, q3;
     __device__ __forceinline__ void init(const uint64_t* q, uint64_t b, uint32_t l, uint32_t r) {
-        words = q; base = b; len = l; rev = r; widx = ~0ull; wnidx = ~0ull; w = 0; wn = 0;
-        wlo = b >> 3; whi = l ? (b + l - 1u) >> 3 : wlo;
+        words = q; base = b; len = l; rev = r; cidx = ~0ull;
+        q0 = q1 = q2 = q3 = 0;
     }
+    __device__ __forceinline__ void forget() { cidx = ~0ull; }
     // letter id of position j of the scanned strand
     __device__ __forceinline__ uint32_t at(uint32_t j) {
-        uint64_t p = base + (rev ? (uint64_t)(len - 1u - j) : (uint64_t)j);
-        uint64_t wi = p >> 3;
-        if (wi != widx) {
-            w = (wi == wnidx) ? wn : words[wi];
-            widx = wi;
-            // the scan moves right-to-left on the strand: down in memory for forward, up for reverse
-            if (rev ? wi < whi : wi > wlo) { wnidx = rev ? wi + 1u : wi - 1u; wn = words[wnidx]; }
+        uint64_t addr = base + (rev ? (uint64_t)(len - 1u - j) : (uint64_t)j);  // byte offset in the buffer
+        uint64_t chunk = addr & ~(uint64_t)(kBytes - 1u);
+        if (chunk != cidx) {
+            const uint4* p = reinterpret_cast<const uint4*>(words) + (chunk >> 4);
+            uint4 a = p[0];  // holds the letter, or (32-byte window) at least overlaps the record -- see below
+            q0 = u64_of(a.x, a.y); q1 = u64_of(a.z, a.w);
+            if (kBytes == 32u) {
+                // only halves that overlap the record's characters are read: the buffer may end right behind it
+                uint64_t lo = base, hi = base + len;  // record = [lo, hi)
+                bool h0 = chunk + 16 > lo && chunk < hi, h1 = chunk + 32 > lo && chunk + 16 < hi;
+                uint4 b = make_uint4(0, 0, 0, 0);
+                if (!h0) { q0 = 0; q1 = 0; }
+                if (h1) b = p[1];
+                q2 = u64_of(b.x, b.y); q3 = u64_of(b.z, b.w);
+            }
+            cidx = chunk;
         }
-        uint32_t c = ascii_code_q((uint32_t)(w >> ((p & 7u) * 8u)) & 0xFFu);
+        uint32_t o = (uint32_t)(addr & (uint64_t)(kBytes - 1u));
+        // (picked with masks, not with ?: on the members: the optimiser turns a conditional over adjacent members into an
+        //  indexed load, and an indexed load keeps the whole cursor in scratch memory)
+        uint64_t m8 = (o & 8u) ? ~0ull : 0ull;
+        uint64_t q = q0 ^ ((q0 ^ q1) & m8);
+        if (kBytes == 32u) {
+            uint64_t m16 = (o & 16u) ? ~0ull : 0ull, qb = q2 ^ ((q2 ^ q3) & m8);
+            q = q ^ ((q ^ qb) & m16);
+        }
+        uint32_t c = ascii_code_q((uint32_t)(q >> ((o & 7u) * 8u)) & 0xFFu);
         return (rev && c >= 2u) ? 7u - c : c;  // A<->T, C<->G; N stays N  (sequence.c:419-426)
     }
 };
+typedef QueryCursorT<16> QueryCursor;      // the search kernels (registers are scarce there)
+typedef QueryCursorT<32> QueryCursorWide;  // the prefilter
 
 __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t row, uint32_t j,
                                      uint32_t len) {
@@ -689,7 +714,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                         j = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
                                                                                                 : b_pos + (kWarmUp << (2u * attempt));
                         top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; k = 0;
-                        qc.widx = ~0ull; qc.wnidx = ~0ull;
+                        qc.forget();
                         st = ST_EXT;
                         dir_moved = false;
                     } else if (kc == 16u && !special && j > a_pos && dir_r >= 16u && qc.base + j >= 16u) {
@@ -764,7 +789,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                     j = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
                                                                                             : b_pos + (kWarmUp << (2u * attempt));
                     top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; k = 0;
-                    qc.widx = ~0ull; qc.wnidx = ~0ull;
+                    qc.forget();
                 } else if (j == 0u) {
                     strand_end = true;
                 } else if (kDirect && st == ST_EXT && top == bot && depth >= A.direct_min_depth && A.direct_min_depth >= 0 &&
@@ -845,7 +870,7 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
         uint64_t pmax = (uint64_t)b + s1 - 2;
         if (pmax > d.len - k1) pmax = d.len - k1;
         if (p0 <= pmax) {
-            QueryCursor qc;
+            QueryCursorWide qc;
             qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
             // third level: if the MEM is at least k+2 long it also contains the (k+2)-mer that starts at max(m, s'-2), where
             // s' is the start of the k-mer above -- one of s'-2, s'-1, s'.  For L == k+2 that makes the test exact up to the
@@ -902,7 +927,7 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
         uint64_t pmax = (uint64_t)b + s - 2;                     // last window start that can serve this slice
         if (pmax > d.len - k) pmax = d.len - k;
         if (p0 <= pmax) {
-            QueryCursor qc;
+            QueryCursorWide qc;
             qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
             const uint64_t mask = (1ull << (2u * k)) - 1ull;
             uint64_t km = 0;
@@ -1120,8 +1145,8 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         set_error("slamem_find_mems_device: minimum MEM length must be >= 1");
         return SLAMEM_ERR_ARG;
     }
-    if (((uintptr_t)queries_dev & 7u) != 0) {
-        set_error("slamem_find_mems_device: queries_dev must be 8-byte aligned");
+    if (((uintptr_t)queries_dev & 15u) != 0) {
+        set_error("slamem_find_mems_device: queries_dev must be 16-byte aligned");
         return SLAMEM_ERR_ARG;
     }
     const uint32_t strands = both_strands ? 2u : 1u;
