@@ -246,7 +246,53 @@ struct QueryCursorT {
     }
 };
 typedef QueryCursorT<16> QueryCursor;      // the search kernels (registers are scarce there)
-typedef QueryCursorT<32> QueryCursorWide;  // the prefilter
+typedef QueryCursorT<32> QueryCursorWide;  // (random access with a wide window; unused by the kernels now)
+
+// Letters of a strand in ascending position order (the prefilter's scan): eight bytes in a register are consumed with
+// a shift, sixteen more wait in registers, one aligned 16-byte load per 16 letters.  ~15 instructions per letter, where
+// the random-access cursor needs ~45 -- and the prefilter is bound by instruction issue (a wave64 VALU instruction
+// occupies its SIMD for four cycles).
+struct QueryStream {
+    const uint4* p;      // next 16-byte chunk (forward strand: ascending addresses, reverse strand: descending)
+    uint64_t cur, nxt;   // bytes being consumed / the other half of the last chunk
+    uint32_t left;       // bytes of cur not consumed yet
+    uint32_t have_nxt, rev;
+    __device__ __forceinline__ void init(const uint64_t* words, uint64_t base, uint32_t len, uint32_t r, uint32_t start) {
+        rev = r;
+        uint64_t addr = base + (r ? (uint64_t)(len - 1u - start) : (uint64_t)start);  // byte offset of the first letter
+        p = reinterpret_cast<const uint4*>(words) + (addr >> 4);
+        uint4 a = *p;
+        uint64_t lo = u64_of(a.x, a.y), hi = u64_of(a.z, a.w);
+        uint32_t o = (uint32_t)(addr & 15ull);
+        if (!r) {
+            p++;
+            if (o < 8u) { cur = lo >> (8u * o); left = 8u - o; nxt = hi; have_nxt = 1; }
+            else { cur = hi >> (8u * (o - 8u)); left = 16u - o; nxt = 0; have_nxt = 0; }
+        } else {  // the letters come from descending addresses: take them from the top of the register
+            p--;
+            if (o >= 8u) { cur = hi << (8u * (15u - o)); left = o - 7u; nxt = lo; have_nxt = 1; }
+            else { cur = lo << (8u * (7u - o)); left = o + 1u; nxt = 0; have_nxt = 0; }
+        }
+    }
+    // letter id of the next position (the caller never asks for more letters than the strand has)
+    __device__ __forceinline__ uint32_t next() {
+        if (left == 0u) {
+            if (have_nxt) { cur = nxt; have_nxt = 0; }
+            else {
+                uint4 a = *p;  // holds the letter that is asked for: inside the buffer
+                uint64_t lo = u64_of(a.x, a.y), hi = u64_of(a.z, a.w);
+                if (!rev) { cur = lo; nxt = hi; p++; } else { cur = hi; nxt = lo; p--; }
+                have_nxt = 1;
+            }
+            left = 8u;
+        }
+        left--;
+        uint32_t b;
+        if (!rev) { b = (uint32_t)cur & 0xFFu; cur >>= 8; } else { b = (uint32_t)(cur >> 56); cur <<= 8; }
+        uint32_t c = ascii_code_q(b);
+        return (rev && c >= 2u) ? 7u - c : c;  // A<->T, C<->G; N stays N  (sequence.c:419-426)
+    }
+};
 
 __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t row, uint32_t j,
                                      uint32_t len) {
@@ -866,12 +912,12 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
         // k-mers are probed only behind a (k-2)-mer that is present: s1/s times fewer probes for an empty strand, and
         // far fewer chance survivors (a random strand needs a (k-2)-mer hit and a k-mer hit next to it).
         const uint32_t k1 = k - 2u, s1 = L - k1 + 1u;
-        uint64_t p0 = ((uint64_t)a + s1 - 1) / s1 * s1;
-        uint64_t pmax = (uint64_t)b + s1 - 2;
-        if (pmax > d.len - k1) pmax = d.len - k1;
+        // (all positions fit 32 bits: a record is shorter than 2^32 letters; the per-letter loop is instruction bound --
+        //  a wave64 VALU instruction occupies its SIMD for four cycles -- so no 64-bit arithmetic and no division in it)
+        const uint32_t p0 = (a + s1 - 1u) / s1 * s1;
+        uint32_t pmax = (uint32_t)(((uint64_t)b + s1 - 2u < (uint64_t)(d.len - k1)) ? b + s1 - 2u : d.len - k1);
         if (p0 <= pmax) {
-            QueryCursorWide qc;
-            qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
+            QueryStream qs;
             // third level: if the MEM is at least k+2 long it also contains the (k+2)-mer that starts at max(m, s'-2), where
             // s' is the start of the k-mer above -- one of s'-2, s'-1, s'.  For L == k+2 that makes the test exact up to the
             // filter's false positives: a strand survives only if it really shares L letters with the text.
@@ -881,25 +927,27 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
             const uint64_t maskk = (1ull << (2u * k)) - 1ull, mask1 = (1ull << (2u * k1)) - 1ull;
             uint64_t km = 0;
             uint32_t run = 0, confirm = 0, confirm2 = 0;
-            uint64_t x = p0 >= 4 ? p0 - 4 : 0, xend = pmax + k1 + 1 + (three ? 2u : 0u);
-            if (xend > (uint64_t)d.len - 1) xend = (uint64_t)d.len - 1;
+            uint32_t x = p0 >= 4u ? p0 - 4u : 0u;
+            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, x);
+            uint64_t xe64 = (uint64_t)pmax + k1 + 1u + (three ? 2u : 0u);
+            const uint32_t xend = xe64 > (uint64_t)d.len - 1u ? d.len - 1u : (uint32_t)xe64;
+            uint32_t wend = p0 + k1 - 1u;  // letter at which the next probed (k-2)-mer window ends
+            const uint32_t wlast = pmax + k1 - 1u;
             for (; x <= xend && !res; x++) {
-                uint32_t c = qc.at((uint32_t)x);
+                uint32_t c = qs.next();
                 if (c >= 2u) { km = ((km << 2) | (uint64_t)(c - 2u)) & mask; run++; }
                 else { km = 0; run = 0; }
-                if (x + 1 >= p0 + k1) {
-                    uint64_t p = x + 1 - k1;                    // short window [p, p+k1)
-                    if (p <= pmax && p % s1 == 0) {
-                        if (run < k1) res = 1;                  // holds an N: cannot be ruled out
-                        else {
-                            uint64_t h = kfilter_hash((km & mask1) ^ kFilterShortSalt), bits = kfilter_bits(h);
-                            if ((ix.kfilter[h & wmask] & bits) == bits) confirm = 3;  // k-mers ending at x, x+1, x+2
-                        }
+                if (x == wend && wend <= wlast) {               // short window [x+1-k1, x+1)
+                    wend += s1;
+                    if (run < k1) res = 1;                      // holds an N: cannot be ruled out
+                    else {
+                        uint64_t h = kfilter_hash((km & mask1) ^ kFilterShortSalt), bits = kfilter_bits(h);
+                        if ((ix.kfilter[h & wmask] & bits) == bits) confirm = 3;  // k-mers ending at x, x+1, x+2
                     }
                 }
                 if (confirm && !res) {
                     confirm--;
-                    if (x + 1 >= k) {                           // the k-mer [x+1-k, x+1) lies inside the strand
+                    if (x + 1u >= k) {                          // the k-mer [x+1-k, x+1) lies inside the strand
                         if (run < k) res = 1;
                         else {
                             uint64_t h = kfilter_hash(km & maskk), bits = kfilter_bits(h);
@@ -912,7 +960,7 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
                 }
                 if (confirm2 && !res) {
                     confirm2--;
-                    if (x + 1 >= k + 2u) {
+                    if (x + 1u >= k + 2u) {
                         if (run < k + 2u) res = 1;
                         else {
                             uint64_t h = kfilter_hash(km ^ kFilterLongSalt), bits = kfilter_bits(h);
@@ -923,27 +971,26 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
             }
         }
     } else if (d.len >= k && d.len - a >= 1u) {
-        uint64_t p0 = ((uint64_t)a + s - 1) / s * s;            // first sampled window start >= a
-        uint64_t pmax = (uint64_t)b + s - 2;                     // last window start that can serve this slice
-        if (pmax > d.len - k) pmax = d.len - k;
+        const uint32_t p0 = (a + s - 1u) / s * s;               // first sampled window start >= a
+        // last window start that can serve this slice
+        const uint32_t pmax = (uint32_t)(((uint64_t)b + s - 2u < (uint64_t)(d.len - k)) ? b + s - 2u : d.len - k);
         if (p0 <= pmax) {
-            QueryCursorWide qc;
-            qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
+            QueryStream qs;
+            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, p0);
             const uint64_t mask = (1ull << (2u * k)) - 1ull;
             uint64_t km = 0;
-            uint32_t run = 0;
-            for (uint64_t x = p0; x <= pmax + k - 1 && !res; x++) {
-                uint32_t c = qc.at((uint32_t)x);
+            uint32_t run = 0, wend = p0 + k - 1u;               // letter at which the next probed window ends
+            const uint32_t xend = pmax + k - 1u;
+            for (uint32_t x = p0; x <= xend && !res; x++) {
+                uint32_t c = qs.next();
                 if (c >= 2u) { km = ((km << 2) | (uint64_t)(c - 2u)) & mask; run++; }
                 else { km = 0; run = 0; }
-                if (x + 1 >= p0 + k) {
-                    uint64_t p = x + 1 - k;                     // window [p, p+k)
-                    if (p % s == 0) {
-                        if (run < k) res = 1;                   // holds an N: cannot be ruled out
-                        else {
-                            uint64_t h = kfilter_hash(km), bits = kfilter_bits(h);
-                            if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
-                        }
+                if (x == wend) {                                // window [x+1-k, x+1)
+                    wend += s;
+                    if (run < k) res = 1;                       // holds an N: cannot be ruled out
+                    else {
+                        uint64_t h = kfilter_hash(km), bits = kfilter_bits(h);
+                        if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
                     }
                 }
             }
