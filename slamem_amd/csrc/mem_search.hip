@@ -245,7 +245,7 @@ struct QueryCursorT {
         return (rev && c >= 2u) ? 7u - c : c;  // A<->T, C<->G; N stays N  (sequence.c:419-426)
     }
 };
-typedef QueryCursorT<16> QueryCursor;      // the search kernels (registers are scarce there)
+typedef QueryCursorT<32> QueryCursor;      // the search kernels
 typedef QueryCursorT<32> QueryCursorWide;  // (random access with a wide window; unused by the kernels now)
 
 // Letters of a strand in ascending position order (the prefilter's scan): eight bytes in a register are consumed with
