@@ -253,36 +253,45 @@ typedef QueryCursorT<32> QueryCursorWide;  // (random access with a wide window;
 // the random-access cursor needs ~45 -- and the prefilter is bound by instruction issue (a wave64 VALU instruction
 // occupies its SIMD for four cycles).
 struct QueryStream {
-    const uint4* p;      // next 16-byte chunk (forward strand: ascending addresses, reverse strand: descending)
-    uint64_t cur, nxt;   // bytes being consumed / the other half of the last chunk
-    uint32_t left;       // bytes of cur not consumed yet
-    uint32_t have_nxt, rev;
+    const uint4* p;          // next 16-byte chunk (forward strand: ascending addresses, reverse strand: descending)
+    uint64_t cur, n1, n2, n3;  // bytes being consumed / the 8-byte pieces that follow, in consumption order
+    uint32_t left;           // bytes of cur not consumed yet
+    uint32_t nq;             // pieces waiting in n1..n3
+    uint32_t chunks;         // 16-byte chunks not loaded yet that still overlap the record
+    uint32_t rev;
     __device__ __forceinline__ void init(const uint64_t* words, uint64_t base, uint32_t len, uint32_t r, uint32_t start) {
         rev = r;
         uint64_t addr = base + (r ? (uint64_t)(len - 1u - start) : (uint64_t)start);  // byte offset of the first letter
         p = reinterpret_cast<const uint4*>(words) + (addr >> 4);
+        chunks = r ? (uint32_t)((addr >> 4) - (base >> 4)) : (uint32_t)(((base + len - 1u) >> 4) - (addr >> 4));
         uint4 a = *p;
         uint64_t lo = u64_of(a.x, a.y), hi = u64_of(a.z, a.w);
         uint32_t o = (uint32_t)(addr & 15ull);
+        n1 = n2 = n3 = 0;
         if (!r) {
             p++;
-            if (o < 8u) { cur = lo >> (8u * o); left = 8u - o; nxt = hi; have_nxt = 1; }
-            else { cur = hi >> (8u * (o - 8u)); left = 16u - o; nxt = 0; have_nxt = 0; }
+            if (o < 8u) { cur = lo >> (8u * o); left = 8u - o; n1 = hi; nq = 1; }
+            else { cur = hi >> (8u * (o - 8u)); left = 16u - o; nq = 0; }
         } else {  // the letters come from descending addresses: take them from the top of the register
             p--;
-            if (o >= 8u) { cur = hi << (8u * (15u - o)); left = o - 7u; nxt = lo; have_nxt = 1; }
-            else { cur = lo << (8u * (7u - o)); left = o + 1u; nxt = 0; have_nxt = 0; }
+            if (o >= 8u) { cur = hi << (8u * (15u - o)); left = o - 7u; n1 = lo; nq = 1; }
+            else { cur = lo << (8u * (7u - o)); left = o + 1u; nq = 0; }
         }
     }
     // letter id of the next position (the caller never asks for more letters than the strand has)
     __device__ __forceinline__ uint32_t next() {
         if (left == 0u) {
-            if (have_nxt) { cur = nxt; have_nxt = 0; }
+            if (nq) { cur = n1; n1 = n2; n2 = n3; nq--; }
             else {
-                uint4 a = *p;  // holds the letter that is asked for: inside the buffer
-                uint64_t lo = u64_of(a.x, a.y), hi = u64_of(a.z, a.w);
-                if (!rev) { cur = lo; nxt = hi; p++; } else { cur = hi; nxt = lo; p--; }
-                have_nxt = 1;
+                // 32 bytes at a time when two more chunks overlap the record (a chunk that does not may lie behind the buffer)
+                uint4 a = *p, b = make_uint4(0, 0, 0, 0);
+                const bool two = chunks >= 2u;
+                if (two) b = rev ? p[-1] : p[1];
+                uint64_t alo = u64_of(a.x, a.y), ahi = u64_of(a.z, a.w), blo = u64_of(b.x, b.y), bhi = u64_of(b.z, b.w);
+                if (!rev) { cur = alo; n1 = ahi; n2 = blo; n3 = bhi; p += two ? 2 : 1; }
+                else { cur = ahi; n1 = alo; n2 = bhi; n3 = blo; p -= two ? 2 : 1; }
+                nq = two ? 3u : 1u;
+                chunks -= two ? 2u : 1u;
             }
             left = 8u;
         }
