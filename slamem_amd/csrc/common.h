@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 6;  // 6: the presence filter holds the (k-2)-, k- and (k+2)-mers (cascaded prefilter)
+constexpr uint32_t kArenaVersion = 7;  // 7: pair row records + separate SA; 6: three k-mer lengths in the presence filter
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -33,14 +33,16 @@ struct __attribute__((aligned(64))) FMBlock {
 };
 static_assert(sizeof(FMBlock) == 64, "FM block must be one 64-byte line");
 
-// Per-row record: everything the parent-interval operation and locate need about a row in ONE 16-byte
-// load (two rows = one round trip; rows t and t+1 share a 64-byte line 3 times out of 4).
-//   lcp1 = LCP[row] + 1 (0 = the -1 sentinel of rows 0 and n+1, lcparray.c:624,667)
-//   psv  = nearest row above with a smaller LCP, nsv = nearest row below with a smaller LCP
-//          (what the reference's sampled prefix links encode, lcparray.c:782-989)
-//   sa   = SA[row] (the reference samples every 32nd row and LF-walks, bwtindex.c:402-420)
+// Per-row record: what the parent-interval operation needs about the interval boundary BETWEEN this row and the next,
+// in ONE 16-byte load.  The parent of [t,b] is decided by LCP[t] and LCP[b+1] and reaches from PSV[t] to NSV[b+1]-1:
+// record t gives the first pair, record b the second -- for a single row (t = b) that is one record, one line.
+//   lcp1  = LCP[row] + 1 (0 = the -1 sentinel of rows 0 and n+1, lcparray.c:624,667),  psv  = PSV[row]
+//   lcp1n = LCP[row+1] + 1,                                                             nsvn = NSV[row+1]
+//   PSV / NSV = nearest row above / below with a smaller LCP (what the reference's sampled prefix links encode,
+//   lcparray.c:782-989).  SA[row] (the reference samples every 32nd row and LF-walks, bwtindex.c:402-420) lives in its
+//   own array: only an emitted MEM needs it.
 struct __attribute__((aligned(16))) RowRec {
-    uint32_t lcp1, psv, nsv, sa;
+    uint32_t lcp1, psv, lcp1n, nsvn;
 };
 static_assert(sizeof(RowRec) == 16, "row record must be 16 bytes");
 
@@ -51,7 +53,8 @@ struct ArenaHeader {
     uint32_t n;           // text length; rows = n + 1
     uint64_t total_bytes;
     uint64_t off_fm;      // FMBlock[nblocks]
-    uint64_t off_rec;     // RowRec[n+2]    per-row {LCP+1, PSV, NSV, SA}
+    uint64_t off_rec;     // RowRec[n+2]    per-row {LCP+1, PSV, LCP(next)+1, NSV(next)}
+    uint64_t off_sa;      // uint32[n+1]    suffix array
     uint64_t off_nrows;   // uint32[num_n]  sorted BWT rows holding N
     uint64_t off_kfilter; // uint64[1 << kfilter_log2]  k-mer presence filter (0 = absent)
     uint64_t off_ptext;   // uint64[]  the text, 4-bit letter ids, 16 per word, first letter in the top nibble (0 = absent)
@@ -73,6 +76,7 @@ static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 struct IndexView {
     const FMBlock* fm;
     const RowRec* rec;
+    const uint32_t* sa;
     const uint32_t* nrows;
     const uint64_t* kfilter;  // nullptr when the index has no presence filter
     const uint64_t* ptext;    // nullptr when the index has no text-ordered sections (direct extension off)

@@ -392,17 +392,17 @@ __global__ void __launch_bounds__(256) k_parent_depth_text(const uint32_t* __res
     pd[s] = (uint8_t)(d < 255u ? d : 255u);
 }
 
-// interleave the four per-row arrays into the 16-byte row records
+// the 16-byte row records: record i describes the boundaries of row i: {LCP[i]+1, PSV[i], LCP[i+1]+1, NSV[i+1]}
 __global__ void __launch_bounds__(256) k_pack_records(const uint32_t* __restrict__ l32, const uint32_t* __restrict__ psv,
-                                                      const uint32_t* __restrict__ nsv, const uint32_t* __restrict__ sa,
-                                                      uint32_t rows, RowRec* __restrict__ rec) {
+                                                      const uint32_t* __restrict__ nsv, uint32_t rows,
+                                                      RowRec* __restrict__ rec) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > rows) return;
     RowRec r;
     r.lcp1 = l32[i];
     r.psv = psv[i];
-    r.nsv = nsv[i];
-    r.sa = i < rows ? sa[i] : 0u;
+    r.lcp1n = i < rows ? l32[i + 1] : 0u;
+    r.nsvn = i < rows ? nsv[i + 1] : rows;
     rec[i] = r;
 }
 
@@ -522,13 +522,17 @@ __global__ void __launch_bounds__(256) k_bwt_codes(IndexView ix, uint8_t* __rest
     out[r] = (uint8_t)code;
 }
 
-// field 0: LCP (as int32, -1 sentinels), 1: PSV, 2: NSV, 3: SA
-__global__ void __launch_bounds__(256) k_rec_field(const RowRec* __restrict__ rec, uint64_t count, int field,
-                                                   uint32_t* __restrict__ out) {
+// field 0: LCP (as int32, -1 sentinels), 1: PSV, 2: NSV (entries 0 .. n+1), 3: SA (entries 0 .. n)
+__global__ void __launch_bounds__(256) k_rec_field(const RowRec* __restrict__ rec, const uint32_t* __restrict__ sa,
+                                                   uint32_t rows, uint64_t count, int field, uint32_t* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    RowRec r = rec[i];
-    out[i] = field == 0 ? r.lcp1 - 1u : field == 1 ? r.psv : field == 2 ? r.nsv : r.sa;
+    uint32_t v;
+    if (field == 3) v = sa[i];
+    else if (field == 0) v = (i < rows ? rec[i].lcp1 : rec[rows - 1u].lcp1n) - 1u;
+    else if (field == 1) v = i < rows ? rec[i].psv : 0u;
+    else v = i >= 1 ? rec[i - 1].nsvn : rows;
+    out[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -563,6 +567,7 @@ void make_view(slamem_index* idx) {
     const ArenaHeader& h = idx->hdr;
     idx->view.fm = reinterpret_cast<const FMBlock*>(base + h.off_fm);
     idx->view.rec = reinterpret_cast<const RowRec*>(base + h.off_rec);
+    idx->view.sa = reinterpret_cast<const uint32_t*>(base + h.off_sa);
     idx->view.nrows = reinterpret_cast<const uint32_t*>(base + h.off_nrows);
     idx->view.kfilter = h.off_kfilter ? reinterpret_cast<const uint64_t*>(base + h.off_kfilter) : nullptr;
     idx->view.kfilter_log2 = h.kfilter_log2;
@@ -641,6 +646,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     uint64_t off = kHeaderBytes;
     hdr.off_fm = off;    off = align_up(off + (uint64_t)nblocks * sizeof(FMBlock), 256);
     hdr.off_rec = off;   off = align_up(off + (R + 1) * sizeof(RowRec), 256);
+    hdr.off_sa = off;    off = align_up(off + R * 4, 256);
     hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
     {   // k-mer presence filter: 64 bits per text character (rounded up to a power of two of words), n >= k only
         const char* kf = getenv("SLAMEM_KFILTER");
@@ -675,7 +681,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     // only after it), the LCP / PSV / NSV arrays reuse sort buffers, and nothing is freed before the end: the driver
     // wipes freed VRAM in the background at ~33 GiB/s and an allocation that needs memory still waiting for its wipe
     // blocks (measured at 3.1 Gbp: 9.3 of 10.7 s of the build were two such hipMalloc calls; tools/malloc_probe.hip).
-    // Peak = arena + 26.5 B per row (was: 50 B per row, then arena + 24 B per row after a free).
+    // Peak = arena + 22.5 B per row (the suffix array is built in place in the arena).
     DevBuf arena;
     if (arena.alloc(hdr.total_bytes) != hipSuccess) {
         set_error("slamem_index_build: cannot allocate %llu bytes of HBM for the index", (unsigned long long)hdr.total_bytes);
@@ -695,7 +701,8 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     // ---- K2: suffix sort ----------------------------------------------------------------------
     DevBuf keysA, keysB, valsA, valsB, rank, flagA, flagB, tmp32, gh, posA, posB, sorttmp, sabuf;
     // keysA later holds LCP+1 and PSV, posA holds NSV (R+1 words each): sized for that, never borrowed
-    if (sabuf.alloc(R * 4) != hipSuccess || keysA.alloc((R + 1) * 8 + 64) != hipSuccess || rank.alloc(R * 4) != hipSuccess ||
+    sabuf.view(base + hdr.off_sa);  // the suffix array is built in its place in the arena
+    if (keysA.alloc((R + 1) * 8 + 64) != hipSuccess || rank.alloc(R * 4) != hipSuccess ||
         flagA.alloc(R) != hipSuccess || flagB.alloc(R) != hipSuccess || posA.alloc((R + 1) * 4) != hipSuccess ||
         borrow(keysB, R * 8) != hipSuccess || borrow(valsA, R * 4) != hipSuccess || borrow(valsB, R * 4) != hipSuccess ||
         borrow(tmp32, R * 4) != hipSuccess || borrow(gh, R * 4) != hipSuccess || borrow(posB, R * 4) != hipSuccess) {
@@ -885,7 +892,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         hipLaunchKernelGGL(k_links, dim3(grid_for(n)), dim3(256), 0, stream, L, rows, d_psv, d_nsv);
         SLAMEM_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_pack_records, dim3(grid_for(R + 1)), dim3(256), 0, stream, d_l32, d_psv, d_nsv, d_sa, rows, d_rec);
+    hipLaunchKernelGGL(k_pack_records, dim3(grid_for(R + 1)), dim3(256), 0, stream, d_l32, d_psv, d_nsv, rows, d_rec);
     SLAMEM_HIP(hipGetLastError());
     if (hdr.off_ptext) {
         SLAMEM_HIP(hipMemcpyAsync(base + hdr.off_ptext, pk.p, nwords * 8, hipMemcpyDeviceToDevice, stream));
@@ -931,8 +938,8 @@ __global__ void __launch_bounds__(256) k_sampled_stats(const RowRec* __restrict_
     __syncthreads();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // row 0..n
     if (i <= n) {
-        RowRec a = rec[i], b = rec[i + 1];
-        long long lcp = (long long)a.lcp1 - 1, nxt = (long long)b.lcp1 - 1;
+        RowRec a = rec[i];
+        long long lcp = (long long)a.lcp1 - 1, nxt = (long long)a.lcp1n - 1;
         // sum / max run over rows 1..n+1 (value of the NEXT row), lcparray.c:668-669
         atomicAdd(&sh[2], (unsigned long long)nxt);
         if (nxt > 0) atomicMax(&sh[3], (unsigned long long)nxt);
@@ -941,7 +948,7 @@ __global__ void __launch_bounds__(256) k_sampled_stats(const RowRec* __restrict_
             if (lcp == -1 || lcp >= 255) atomicAdd(&sh[1], 1ull);
             long long dist = -1;
             if (nxt > lcp) { if (i != 0) dist = (long long)i - (long long)a.psv; }          // top corner -> PSV
-            else { if (i != n) dist = (long long)b.nsv - 1 - (long long)i; }                // bottom corner -> NSV-1
+            else { if (i != n) dist = (long long)a.nsvn - 1 - (long long)i; }               // bottom corner -> NSV-1
             if (dist >= 0) {
                 atomicAdd(&sh[5], (unsigned long long)dist);
                 atomicMax(&sh[6], (unsigned long long)dist);
@@ -1007,7 +1014,7 @@ int download_array(const slamem_index* idx, int which, void* host_dst, uint64_t 
         return SLAMEM_OK;
     }
     SLAMEM_HIP(d.alloc(want * 4));
-    hipLaunchKernelGGL(k_rec_field, dim3(grid_for(want)), dim3(256), 0, 0, v.rec, want, field, d.as<uint32_t>());
+    hipLaunchKernelGGL(k_rec_field, dim3(grid_for(want)), dim3(256), 0, 0, v.rec, v.sa, (uint32_t)R, want, field, d.as<uint32_t>());
     SLAMEM_HIP(hipGetLastError());
     SLAMEM_HIP(hipMemcpy(host_dst, d.p, want * 4, hipMemcpyDeviceToHost));
     return SLAMEM_OK;

@@ -127,18 +127,19 @@ __device__ __forceinline__ bool follow(const IndexView& ix, uint32_t c, uint32_t
 }
 
 // GetEnclosingLCPInterval: parent LCP-interval of [top,bot]; returns its depth, -1 at the root.
+// rt = record of row top, rb = record of row bot (the same record for a single row).
 __device__ __forceinline__ int parent_from(const uint4& rt, const uint4& rb, uint32_t& top, uint32_t& bot) {
-    uint32_t a = rt.x, b = rb.x;   // {lcp+1, psv, nsv, sa} of rows top and bot+1
+    uint32_t a = rt.x, b = rb.z;   // LCP[top] + 1, LCP[bot+1] + 1
     uint32_t d = a > b ? a : b;
     if (d == 0u) return -1;
     if (a == d) top = rt.y;        // closest row above with a smaller LCP   (lcparray.c:519)
-    if (b == d) bot = rb.z - 1u;   // closest row below with a smaller LCP   (lcparray.c:520-521)
+    if (b == d) bot = rb.w - 1u;   // closest row below with a smaller LCP   (lcparray.c:520-521)
     return (int)(d - 1u);
 }
 
 __device__ __forceinline__ int parent(const IndexView& ix, uint32_t& top, uint32_t& bot) {
     const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
-    uint4 rt = R[top], rb = R[bot + 1u];  // both boundary rows: one round trip
+    uint4 rt = R[top], rb = R[bot];  // both boundary records: one round trip (one record for a single row)
     return parent_from(rt, rb, top, bot);
 }
 
@@ -305,7 +306,7 @@ struct QueryStream {
 
 __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t row, uint32_t j,
                                      uint32_t len) {
-    uint32_t r = A.ix.rec[row].sa;  // FMI_PositionInText
+    uint32_t r = A.ix.sa[row];  // FMI_PositionInText
     unsigned long long slot = atomicAdd(A.total, 1ull);  // the compiler aggregates this per wave
     if (slot < A.capacity) {
         A.raw_key[slot] = RawKey{blockid, k};
@@ -659,7 +660,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 // (its depth is needed now), or speculatively while the match is short (off by default)
                 want_rec = depth <= A.spec_depth || (pend && pub >= L);
             } else if (kDirect && st == ST_DSA) {
-                rt = R[top];  // SA of the single row
+                rt.w = ix.sa[top];  // SA of the single row
             } else if (kDirect && st == ST_DISA) {
                 isa_row = ix.isa[dir_r];
             } else if (kDirect && st == ST_DIR) {
@@ -681,7 +682,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
 #ifdef SLAMEM_K8_STATS
             n_trips++; n_rec_fail += st == ST_REC; n_rec_flush += st == ST_FLUSH;
 #endif
-            if (want_rec) { rt = R[top]; rb = R[bot + 1u]; }
+            if (want_rec) { rt = R[top]; rb = R[bot]; }
             if (st == ST_EXT) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
 
             // ---- compute phase -------------------------------------------------------------------------------
@@ -1011,7 +1012,7 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
 // K9 for v3: inline slots and overflow records -> grouped output, BWT rows resolved to text positions here
 __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__ inl, const uint32_t* __restrict__ counts,
                                                       const uint64_t* __restrict__ item_off, uint64_t nitems,
-                                                      const RowRec* __restrict__ rec, uint64_t capacity,
+                                                      const uint32_t* __restrict__ sa, uint64_t capacity,
                                                       slamem_mem* __restrict__ out) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nitems) return;
@@ -1021,14 +1022,14 @@ __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__
     for (uint32_t i = 0; i < cnt; i++) {
         if (off + i >= capacity) return;
         RawRow r = inl[g * kInlineMems + i];
-        out[off + i] = slamem_mem{rec[r.row].sa, r.pos, r.len};
+        out[off + i] = slamem_mem{sa[r.row], r.pos, r.len};
     }
 }
 
 __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict__ key, const slamem_mem* __restrict__ raw,
                                                         uint64_t count, const uint64_t* __restrict__ item_off,
                                                         const uint8_t* __restrict__ item_attempt,
-                                                        const RowRec* __restrict__ rec, uint64_t capacity,
+                                                        const uint32_t* __restrict__ sa, uint64_t capacity,
                                                         slamem_mem* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -1037,7 +1038,7 @@ __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict
     slamem_mem m = raw[i];
     uint64_t pos = item_off[kk.block] + (kk.k & 0x0FFFFFFFu);
     if (pos >= capacity) return;
-    m.ref_pos = rec[m.ref_pos].sa;
+    m.ref_pos = sa[m.ref_pos];
     out[pos] = m;
 }
 
@@ -1122,7 +1123,7 @@ __global__ void __launch_bounds__(256) k_locate_batch(IndexView ix, const uint32
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     uint32_t r = rows[i];
-    out[i] = r <= ix.n ? ix.rec[r].sa : 0xFFFFFFFFu;
+    out[i] = r <= ix.n ? ix.sa[r] : 0xFFFFFFFFu;
 }
 
 __global__ void __launch_bounds__(256) k_bwtchar_batch(IndexView ix, const uint32_t* __restrict__ rows, char* out,
@@ -1351,12 +1352,12 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         } else if (kernel_version == 3) {
             if (total) {
                 hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
-                                   d_itemoff, nitems, idx->view.rec, mems_capacity, mems_dev);
+                                   d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);
                 STEP(hipGetLastError(), "k_place_inline");
             }
             if (listed) {
                 hipLaunchKernelGGL(k_place_overflow, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                                   (uint64_t)listed, d_itemoff, A.item_attempt, idx->view.rec, mems_capacity, mems_dev);
+                                   (uint64_t)listed, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev);
                 STEP(hipGetLastError(), "k_place_overflow");
             }
         } else if (listed) {
