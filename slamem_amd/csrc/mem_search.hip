@@ -246,8 +246,7 @@ struct QueryCursorT {
         return (rev && c >= 2u) ? 7u - c : c;  // A<->T, C<->G; N stays N  (sequence.c:419-426)
     }
 };
-typedef QueryCursorT<32> QueryCursor;      // the search kernels
-typedef QueryCursorT<32> QueryCursorWide;  // (random access with a wide window; unused by the kernels now)
+typedef QueryCursorT<32> QueryCursor;  // the search kernels (a 16-byte window saves 8 VGPRs and costs twice the loads)
 
 // Letters of a strand in ascending position order (the prefilter's scan): eight bytes in a register are consumed with
 // a shift, sixteen more wait in registers, one aligned 16-byte load per 16 letters.  ~15 instructions per letter, where
