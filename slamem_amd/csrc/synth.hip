@@ -97,21 +97,22 @@ extern "C" int slamem_gather_bench(const void* table_dev, uint64_t nblk, uint64_
 //   mode 0: every lane reads ONE 16-B piece of a random line                (1 lane access / line)
 //   mode 1: the 4 lanes of a quad read the 4 pieces of the SAME random line  (4 lane accesses / line, 1 instruction)
 //   mode 2: the 16 lanes of a row read 4 consecutive lines (256 B)           (rows of 256 B)
+//   mode 3: 8 lanes read 2 consecutive lines (an aligned 128-B pair)          (what a 128-byte index block would cost)
 __global__ void __launch_bounds__(256) k_gather_modes(const uint4* __restrict__ table, uint64_t nblk, uint32_t iters,
                                                       int mode, uint64_t* __restrict__ sink) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t lane = threadIdx.x & 63u;
-    uint64_t chain = mode == 0 ? g : mode == 1 ? (g >> 2) : (g >> 4);
-    uint32_t piece = mode == 0 ? (uint32_t)(g & 3u) : mode == 1 ? (lane & 3u) : (lane & 15u);
+    uint64_t chain = mode == 0 ? g : mode == 1 ? (g >> 2) : mode == 2 ? (g >> 4) : (g >> 3);
+    uint32_t piece = mode == 0 ? (uint32_t)(g & 3u) : mode == 1 ? (lane & 3u) : mode == 2 ? (lane & 15u) : (lane & 7u);
     uint64_t s = draw(0x777u, chain);
     uint64_t acc = 0;
-    uint64_t span = mode == 2 ? 4 : 1;
+    uint64_t span = mode == 2 ? 4 : mode == 3 ? 2 : 1;
     for (uint32_t it = 0; it < iters; it++) {
         uint64_t b = (s % (nblk / span)) * span;
         uint4 a = table[b * 4 + piece];
         uint32_t v = a.x ^ a.y;
         // every lane of the group must follow the same chain: take the group leader's value
-        uint32_t lead = mode == 0 ? v : mode == 1 ? __shfl(v, lane & ~3u) : __shfl(v, lane & ~15u);
+        uint32_t lead = mode == 0 ? v : mode == 1 ? __shfl(v, lane & ~3u) : mode == 2 ? __shfl(v, lane & ~15u) : __shfl(v, lane & ~7u);
         acc += v;
         s = draw(s + lead, it);
     }

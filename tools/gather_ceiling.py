@@ -32,7 +32,7 @@ def main():
         nblk = mb * (1 << 20) // 64
         table = torch.randint(0, 2 ** 31, (nblk * 16,), dtype=torch.int32, device=dev)
         if a.modes:
-            for mode in (0, 1, 2):
+            for mode in (0, 1, 2, 3):
                 iters = 64
                 S.slamem_gather_modes(table.data_ptr(), nblk, lanes, 4, mode, sink.data_ptr(), None)
                 torch.cuda.synchronize()
@@ -44,7 +44,7 @@ def main():
                 ms = e0.elapsed_time(e1)
                 lane_acc = lanes * iters
                 lines = lane_acc // (1 if mode == 0 else 4)
-                print(json.dumps({"table_MB": mb, "mode": ["lane16B", "quad64B", "row256B"][mode], "ms": ms,
+                print(json.dumps({"table_MB": mb, "mode": ["lane16B", "quad64B", "row256B", "pair128B"][mode], "ms": ms,
                                   "Glane_accesses_per_s": lane_acc / ms / 1e6, "Glines_per_s": lines / ms / 1e6}), flush=True)
             del table
             continue
