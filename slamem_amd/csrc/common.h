@@ -15,32 +15,23 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 8;  // 8: 128-byte FM blocks with two-letter steps; 7: pair row records + separate SA
+constexpr uint32_t kArenaVersion = 7;  // 7: pair row records + separate SA; 6: three k-mer lengths in the presence filter
 constexpr uint64_t kHeaderBytes = 4096;
-constexpr uint32_t kFmRowsLog2 = 6;  // 64 BWT rows per FM block
+constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
 
-// FM block: 64 BWT rows in ONE aligned 128-byte pair of lines.  A random aligned 128-byte fetch costs this memory
-// system the same as a random 64-byte one (profiles/r01_gather_modes.jsonl, pair128B), so the second line is free --
-// it holds what a backward step by TWO letters needs.
-//   first line (everything a one-letter step needs, plus the planes of the second letter):
-//   cnt[c-2] = C[c] + occ(c, rows < 64k) for c in A,C,G,T            (reference a1: letterJumpsSample, bwtindex.c:1454,1481)
-//   p0/p1    = two bit-planes of (letter id - 2) of BWT[row] = T[SA-1] (reference a1: bwtBits[3], bwtindex.c:33-37)
-//   ex       = rows whose BWT letter is N or '$' (their plane bits are 0)
-//   q0/q1    = the same for the letter before that, T[SA-2] = BWT[LF(row)];  ex2 = rows where either letter is N or '$'
-//   second line:
-//   cnt2[4*(c1-2) + (c2-2)] = row that LF(LF(., c1), c2) maps the block's first row to
-//            = C[c2] + occ(c2, C[c1]) + #(rows < 64k with T[SA-1] = c1 and T[SA-2] = c2)
-// so that for letters c1 (nearer) and c2:  LF(LF(r,c1),c2) = cnt2[c1,c2] + #(rows < r in the block with that pair).
-// N is searched through the sorted list of N rows (rare letter), '$' is one known row; steps that involve them are
-// one-letter steps.
-struct __attribute__((aligned(128))) FMBlock {
+// FM block: 128 BWT rows in ONE 64-byte line (one HBM/L2 sector pair per rank query).
+//   cnt[c-2] = C[c] + occ(c, rows < 128k) for c in A,C,G,T          (reference a1: letterJumpsSample, bwtindex.c:1454,1481)
+//   p0/p1    = two bit-planes of (letter id - 2) for A,C,G,T rows    (reference a1: bwtBits[3], bwtindex.c:33-37)
+//   ex       = rows whose letter is N or '$' (their plane bits are 0)
+// N is searched through the sorted list of N rows (rare letter), '$' is one known row.
+struct __attribute__((aligned(64))) FMBlock {
     uint32_t cnt[4];
-    uint64_t p0, p1, ex;
-    uint64_t q0, q1, ex2;
-    uint32_t cnt2[16];
+    uint64_t p0[2];
+    uint64_t p1[2];
+    uint64_t ex[2];
 };
-static_assert(sizeof(FMBlock) == 128, "FM block must be one aligned 128-byte pair of lines");
+static_assert(sizeof(FMBlock) == 64, "FM block must be one 64-byte line");
 
 // Per-row record: what the parent-interval operation needs about the interval boundary BETWEEN this row and the next,
 // in ONE 16-byte load.  The parent of [t,b] is decided by LCP[t] and LCP[b+1] and reaches from PSV[t] to NSV[b+1]-1:

@@ -149,42 +149,49 @@ __global__ void __launch_bounds__(256) k_round_keys(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: BWT -> FM blocks.  One lane per BWT row, one wave per 64-row block.
+// K3: BWT -> FM blocks.  One lane per BWT row, one wave per 64-row half block.
 // ------------------------------------------------------------------------------------------
-// letter planes of T[SA-1] and T[SA-2], per-block letter counts (blk1) and pair counts (blk2, first-letter major:
-// blk2[c1 * nblocks + block] = counts for c2 = A,C,G,T)
 __global__ void __launch_bounds__(256) k_bwt_planes(const uint32_t* __restrict__ sa, const uint64_t* __restrict__ pk,
                                                     uint32_t rows, uint32_t nblocks, FMBlock* __restrict__ fm,
-                                                    uint4* __restrict__ blk1, uint4* __restrict__ blk2,
-                                                    uint8_t* __restrict__ is_n, uint32_t* __restrict__ dollar_row) {
+                                                    uint4* __restrict__ halfcnt, uint8_t* __restrict__ is_n,
+                                                    uint32_t* __restrict__ dollar_row) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t code = 0, code2 = 0;
+    uint32_t code = 0;
     bool valid = r < rows;
     if (valid) {
         uint32_t s = sa[r];
         if (s == 0) { *dollar_row = (uint32_t)r; code = 0; }
         else code = nibble_at(pk, (uint64_t)s - 1);  // BWT[r] = T[SA[r]-1]   (bwtindex.c:1092,1204)
-        if (s >= 2) code2 = nibble_at(pk, (uint64_t)s - 2);  // the letter before it = BWT[LF(r)]
         is_n[r] = (code == 1);
     }
-    bool ex = !valid || code < 2, ex2 = ex || code2 < 2;
-    uint32_t c1 = code - 2u, c2 = code2 - 2u;
-    unsigned long long b0 = __ballot(!ex && (c1 & 1u)), b1 = __ballot(!ex && (c1 & 2u)), be = __ballot(ex);
-    unsigned long long d0 = __ballot(!ex2 && (c2 & 1u)), d1 = __ballot(!ex2 && (c2 & 2u)), be2 = __ballot(ex2);
-    uint64_t blk = r >> kFmRowsLog2;
-    if ((threadIdx.x & 63u) == 0 && blk < nblocks) {
-        FMBlock* b = &fm[blk];
-        b->p0 = b0; b->p1 = b1; b->ex = be;
-        b->q0 = d0; b->q1 = d1; b->ex2 = be2;
-        const unsigned long long ne = ~be, ne2 = ~be2;
-        unsigned long long m1[4] = {~b0 & ~b1 & ne, b0 & ~b1 & ne, ~b0 & b1 & ne, b0 & b1 & ne};
-        unsigned long long m2[4] = {~d0 & ~d1 & ne2, d0 & ~d1 & ne2, ~d0 & d1 & ne2, d0 & d1 & ne2};
-        blk1[blk] = make_uint4(__popcll(m1[0]), __popcll(m1[1]), __popcll(m1[2]), __popcll(m1[3]));
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-            blk2[(uint64_t)x * nblocks + blk] = make_uint4(__popcll(m1[x] & m2[0]), __popcll(m1[x] & m2[1]),
-                                                           __popcll(m1[x] & m2[2]), __popcll(m1[x] & m2[3]));
+    bool ex = !valid || code < 2;
+    uint32_t c2 = code - 2u;
+    unsigned long long b0 = __ballot(!ex && (c2 & 1u));
+    unsigned long long b1 = __ballot(!ex && (c2 & 2u));
+    unsigned long long be = __ballot(ex);
+    uint64_t half = r >> 6;  // 64-row half block index
+    if ((threadIdx.x & 63u) == 0 && (half >> 1) < nblocks) {
+        FMBlock* b = &fm[half >> 1];
+        uint32_t hsel = (uint32_t)(half & 1u);
+        b->p0[hsel] = b0;
+        b->p1[hsel] = b1;
+        b->ex[hsel] = be;
+        unsigned long long ne = ~be;
+        uint4 c;
+        c.x = __popcll(~b0 & ~b1 & ne);  // A
+        c.y = __popcll(b0 & ~b1 & ne);   // C
+        c.z = __popcll(~b0 & b1 & ne);   // G
+        c.w = __popcll(b0 & b1 & ne);    // T
+        halfcnt[half] = c;
     }
+}
+
+__global__ void __launch_bounds__(256) k_block_counts(const uint4* __restrict__ halfcnt, uint32_t nblocks,
+                                                      uint4* __restrict__ blkcnt) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    uint4 a = halfcnt[2 * (uint64_t)b], c = halfcnt[2 * (uint64_t)b + 1];
+    blkcnt[b] = make_uint4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
 }
 
 // cnt[c-2] = C[c] + occ(c, rows before the block)      (reference: letterJumpsSample, bwtindex.c:1454,1481)
@@ -197,35 +204,6 @@ __global__ void __launch_bounds__(256) k_rank_samples(const uint4* __restrict__ 
     fm[b].cnt[1] = C.y + p.y;
     fm[b].cnt[2] = C.z + p.z;
     fm[b].cnt[3] = C.w + p.w;
-}
-
-// base[4*x + y] = C[y] + occ(y, rows < C[x]): where LF(LF(., x), y) sends row 0 of the text's rows that carry the pair
-// (x = letter id - 2 of the nearer letter).  Sixteen lanes, after k_rank_samples.
-__global__ void k_pair_bases(const FMBlock* __restrict__ fm, uint4 C, uint32_t* __restrict__ base) {
-    uint32_t t = threadIdx.x;
-    if (t >= 16u) return;
-    uint32_t x = t >> 2, y = t & 3u;
-    uint32_t row = x == 0 ? C.x : x == 1 ? C.y : x == 2 ? C.z : C.w;  // first row of the suffixes that start with x
-    const FMBlock* b = &fm[row >> kFmRowsLog2];
-    uint32_t off = row & (kFmRows - 1u);
-    uint64_t f0 = (y & 1u) ? ~0ull : 0ull, f1 = (y & 2u) ? ~0ull : 0ull;
-    uint64_t m = ~(b->p0 ^ f0) & ~(b->p1 ^ f1) & ~b->ex;
-    base[t] = b->cnt[y] + (uint32_t)__popcll(m & ((1ull << off) - 1ull));
-}
-
-// cnt2[4*x + y] = base[4*x + y] + #(rows before the block whose letters are (x, y))
-__global__ void __launch_bounds__(256) k_rank_samples2(const uint4* __restrict__ pre2, uint32_t nblocks,
-                                                       const uint32_t* __restrict__ base, FMBlock* __restrict__ fm) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-        uint4 p = pre2[(uint64_t)x * nblocks + b];
-        fm[b].cnt2[4 * x + 0] = base[4 * x + 0] + p.x;
-        fm[b].cnt2[4 * x + 1] = base[4 * x + 1] + p.y;
-        fm[b].cnt2[4 * x + 2] = base[4 * x + 2] + p.z;
-        fm[b].cnt2[4 * x + 3] = base[4 * x + 3] + p.w;
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -537,10 +515,10 @@ __global__ void __launch_bounds__(256) k_bwt_codes(IndexView ix, uint8_t* __rest
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > ix.n) return;
     const FMBlock* b = &ix.fm[r >> kFmRowsLog2];
-    uint32_t bit = (uint32_t)r & (kFmRows - 1);
+    uint32_t o = (uint32_t)r & (kFmRows - 1), hsel = o >> 6, bit = o & 63u;
     uint32_t code;
-    if ((b->ex >> bit) & 1ull) code = (r == ix.dollar_row) ? 0u : 1u;
-    else code = 2u + (uint32_t)((b->p0 >> bit) & 1ull) + 2u * (uint32_t)((b->p1 >> bit) & 1ull);
+    if ((b->ex[hsel] >> bit) & 1ull) code = (r == ix.dollar_row) ? 0u : 1u;
+    else code = 2u + (uint32_t)((b->p0[hsel] >> bit) & 1ull) + 2u * (uint32_t)((b->p1[hsel] >> bit) & 1ull);
     out[r] = (uint8_t)code;
 }
 
@@ -820,37 +798,25 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     // ---- K3: BWT planes + rank samples ------------------------------------------------------------
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
     SLAMEM_HIP(hipMemsetAsync(d_fm, 0, (uint64_t)nblocks * sizeof(FMBlock), stream));
-    // scratch (in the first sort key buffer, 8 bytes per row): letter counts and their prefix sums (nblocks uint4 each),
-    // pair counts and their prefix sums (4 * nblocks uint4 each, first-letter major), the 16 pair bases
-    uint4* d_blk1 = keysA.as<uint4>();
-    uint4* d_pre1 = d_blk1 + nblocks;
-    uint4* d_blk2 = d_pre1 + nblocks;
-    uint4* d_pre2 = d_blk2 + 4ull * nblocks;
-    uint32_t* d_base = reinterpret_cast<uint32_t*>(d_pre2 + 4ull * nblocks);
-    DevBuf small;                                 // tiny texts: the buffer is too small for that, use a private one
-    if ((uint64_t)nblocks * 160 + 64 > R * 8) {
-        SLAMEM_HIP(small.alloc((uint64_t)nblocks * 160 + 64));
-        d_blk1 = small.as<uint4>();
-        d_pre1 = d_blk1 + nblocks;
-        d_blk2 = d_pre1 + nblocks;
-        d_pre2 = d_blk2 + 4ull * nblocks;
-        d_base = reinterpret_cast<uint32_t*>(d_pre2 + 4ull * nblocks);
+    uint4* d_half = keysA.as<uint4>();            // 2*nblocks uint4  (scratch reuse: 4*nblocks*16 <= R*8 for R >= 8*nblocks)
+    uint4* d_blk = d_half + 2 * (uint64_t)nblocks;  // nblocks uint4
+    uint4* d_pre = d_blk + nblocks;               // nblocks uint4
+    DevBuf small;                                 // tiny texts: the aliasing bound above fails, use a private buffer
+    if ((uint64_t)nblocks * 64 > R * 8) {
+        SLAMEM_HIP(small.alloc((uint64_t)nblocks * 64));
+        d_half = small.as<uint4>();
+        d_blk = d_half + 2 * (uint64_t)nblocks;
+        d_pre = d_blk + nblocks;
     }
+    SLAMEM_HIP(hipMemsetAsync(d_half, 0, (uint64_t)nblocks * 32, stream));
     hipLaunchKernelGGL(k_bwt_planes, dim3(grid_for((uint64_t)nblocks * kFmRows)), dim3(256), 0, stream, d_sa,
-                       pk.as<uint64_t>(), rows, nblocks, d_fm, d_blk1, d_blk2, flagA.as<uint8_t>(), d_scal + 8);
+                       pk.as<uint64_t>(), rows, nblocks, d_fm, d_half, flagA.as<uint8_t>(), d_scal + 8);
     SLAMEM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_block_counts, dim3(grid_for(nblocks)), dim3(256), 0, stream, d_half, nblocks, d_blk);
     need = tmp_bytes;
-    SLAMEM_HIP(scan_sum_exclusive_uint4(sorttmp.p, need, d_blk1, d_pre1, nblocks, stream));
-    for (int x = 0; x < 4; x++) {
-        need = tmp_bytes;
-        SLAMEM_HIP(scan_sum_exclusive_uint4(sorttmp.p, need, d_blk2 + (uint64_t)x * nblocks, d_pre2 + (uint64_t)x * nblocks,
-                                            nblocks, stream));
-    }
-    const uint4 C4 = make_uint4(hdr.C[2], hdr.C[3], hdr.C[4], hdr.C[5]);
-    hipLaunchKernelGGL(k_rank_samples, dim3(grid_for(nblocks)), dim3(256), 0, stream, d_pre1, nblocks, C4, d_fm);
-    hipLaunchKernelGGL(k_pair_bases, dim3(1), dim3(64), 0, stream, (const FMBlock*)d_fm, C4, d_base);
-    hipLaunchKernelGGL(k_rank_samples2, dim3(grid_for(nblocks)), dim3(256), 0, stream, d_pre2, nblocks,
-                       (const uint32_t*)d_base, d_fm);
+    SLAMEM_HIP(scan_sum_exclusive_uint4(sorttmp.p, need, d_blk, d_pre, nblocks, stream));
+    hipLaunchKernelGGL(k_rank_samples, dim3(grid_for(nblocks)), dim3(256), 0, stream, d_pre, nblocks,
+                       make_uint4(hdr.C[2], hdr.C[3], hdr.C[4], hdr.C[5]), d_fm);
     SLAMEM_HIP(hipGetLastError());
     if (num_n) {
         need = tmp_bytes;

@@ -27,12 +27,11 @@ namespace slamem {
 // ------------------------------------------------------------------------------------------
 // device-side index queries
 // ------------------------------------------------------------------------------------------
-// The first line of an FM block (everything but the pair counters), in registers.
 struct Blk {
     uint4 a;  // cnt[0..3]
-    uint4 b;  // p0, p1
-    uint4 c;  // ex, q0
-    uint4 d;  // q1, ex2
+    uint4 b;  // p0[0], p0[1]
+    uint4 c;  // p1[0], p1[1]
+    uint4 d;  // ex[0], ex[1]
 };
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
@@ -44,23 +43,19 @@ __device__ __forceinline__ Blk load_blk(const FMBlock* __restrict__ fm, uint32_t
     return k;
 }
 
-// rows of the block whose BWT letter is c2 + 2 (c2 in 0..3)
-__device__ __forceinline__ uint64_t letter_mask(const Blk& k, uint32_t c2) {
-    uint64_t p0 = u64_of(k.b.x, k.b.y), p1 = u64_of(k.b.z, k.b.w), e = u64_of(k.c.x, k.c.y);
-    uint64_t f0 = (c2 & 1u) ? ~0ull : 0ull, f1 = (c2 & 2u) ? ~0ull : 0ull;
-    return ~(p0 ^ f0) & ~(p1 ^ f1) & ~e;
-}
-// rows whose letter before that (T[SA-2]) is y + 2, and whose two letters are both A/C/G/T
-__device__ __forceinline__ uint64_t second_mask(const Blk& k, uint32_t y) {
-    uint64_t q0 = u64_of(k.c.z, k.c.w), q1 = u64_of(k.d.x, k.d.y), e2 = u64_of(k.d.z, k.d.w);
-    uint64_t f0 = (y & 1u) ? ~0ull : 0ull, f1 = (y & 2u) ? ~0ull : 0ull;
-    return ~(q0 ^ f0) & ~(q1 ^ f1) & ~e2;
-}
-
-// C[c] + occ(c, rows < off of this block), c2 = letter id - 2 in 0..3, off in 0..63
+// C[c] + occ(c, rows < off of this block), c2 = letter id - 2 in 0..3, off in 0..127
 __device__ __forceinline__ uint32_t occ_lt(const Blk& k, uint32_t c2, uint32_t off) {
+    uint64_t p00 = u64_of(k.b.x, k.b.y), p01 = u64_of(k.b.z, k.b.w);
+    uint64_t p10 = u64_of(k.c.x, k.c.y), p11 = u64_of(k.c.z, k.c.w);
+    uint64_t e0 = u64_of(k.d.x, k.d.y), e1 = u64_of(k.d.z, k.d.w);
+    uint64_t f0 = (c2 & 1u) ? ~0ull : 0ull, f1 = (c2 & 2u) ? ~0ull : 0ull;
+    uint64_t m0 = ~(p00 ^ f0) & ~(p10 ^ f1) & ~e0;
+    uint64_t m1 = ~(p01 ^ f0) & ~(p11 ^ f1) & ~e1;
     uint32_t cnt = c2 == 0 ? k.a.x : c2 == 1 ? k.a.y : c2 == 2 ? k.a.z : k.a.w;
-    return cnt + (uint32_t)__popcll(letter_mask(k, c2) & ((1ull << off) - 1ull));
+    uint32_t lo = off < 64u ? off : 64u, hi = off < 64u ? 0u : off - 64u;
+    uint64_t mlo = lo == 64u ? ~0ull : ((1ull << lo) - 1ull);
+    uint64_t mhi = (1ull << hi) - 1ull;  // hi <= 63
+    return cnt + (uint32_t)__popcll(m0 & mlo) + (uint32_t)__popcll(m1 & mhi);
 }
 
 // number of N rows strictly below `row`
@@ -76,14 +71,14 @@ __device__ __forceinline__ uint32_t n_rows_lt(const IndexView& ix, uint32_t row)
 // FMI_GetCharAtBWTPos as a letter id
 __device__ __forceinline__ uint32_t bwt_code(const IndexView& ix, uint32_t row) {
     const FMBlock* b = ix.fm + (row >> kFmRowsLog2);
-    uint32_t bit = row & (kFmRows - 1u);
-    uint64_t e = b->ex;
+    uint32_t o = row & (kFmRows - 1u), hs = o >> 6, bit = o & 63u;
+    uint64_t e = b->ex[hs];
     if ((e >> bit) & 1ull) return row == ix.dollar_row ? 0u : 1u;
-    return 2u + (uint32_t)((b->p0 >> bit) & 1ull) + 2u * (uint32_t)((b->p1 >> bit) & 1ull);
+    return 2u + (uint32_t)((b->p0[hs] >> bit) & 1ull) + 2u * (uint32_t)((b->p1[hs] >> bit) & 1ull);
 }
 
 // The FM blocks of rows `top` and `bot+1`, kept in registers across retries: after a parent step the widened
-// interval usually still starts / ends in the same 64-row block, so the retry costs no memory access.
+// interval usually still starts / ends in the same 128-row block, so the retry costs no memory access.
 struct BlkCache {
     Blk t, b;
     uint32_t it, ib;  // block indices held (0xFFFFFFFF = none)
@@ -607,7 +602,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     QueryCursor qc;
     qc.init(A.qwords, 0, 0, 0);
     // FM block of `top`, kept across trips: after a parent step the widened interval usually still lies in the
-    // same 64-row block, so the retry fetches nothing
+    // same 128-row block, so the retry fetches nothing
     Blk kt;
     kt.a = kt.b = kt.c = kt.d = make_uint4(0, 0, 0, 0);
     uint32_t tag_t = 0xFFFFFFFFu;
