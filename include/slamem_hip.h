@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SLAMEM_ABI_VERSION 1
+#define SLAMEM_ABI_VERSION 2
 
 enum {
     SLAMEM_OK = 0,
@@ -79,7 +79,36 @@ typedef struct {
     float search_total_ms;    /* K8 + scan + K9 scatter                           */
     uint64_t search_launches; /* number of K8 launches accumulated since reset    */
     double search_kernel_ms_sum;
+    float prefilter_ms;       /* K8a (work-item fill + presence prefilter), part of search_kernel_ms */
+    float reserved0;
+    double prefilter_ms_sum;
 } slamem_timings;
+
+/* Load counters of ONE diagnostic search launch (slamem_search_stats_enable): how many loads of each kind the lanes of
+ * K8a / K8 issued.  The diagnostic launch runs separate kernel instantiations that carry the counters; the normal
+ * (timed) kernels carry none.  "lines" are 64-byte lines: FM blocks are one line each, a row-record pair is one or two.
+ * bench.py prices roofline.traffic from these (cross-checked against the rocprofv3 PMC pass kept under profiles/). */
+typedef struct {
+    uint64_t fm_lines_top;          /* K8: FM block of `top` fetched (one per backward step unless still in registers) */
+    uint64_t fm_lines_bottom;       /* K8: FM block of `bottom+1` when it is a different block                         */
+    uint64_t rec_lines_fail;        /* K8: row-record lines after a failed extension (parent step)                     */
+    uint64_t rec_lines_pend;        /* K8: row-record lines for the exact parent depth of a pending position           */
+    uint64_t rec_lines_flush;       /* K8: row-record lines at strand ends                                             */
+    uint64_t query_loads;           /* K8: 32-byte query windows loaded                                                */
+    uint64_t lane_trips;            /* K8: loop trips summed over active lanes                                         */
+    uint64_t wave_trips;            /* K8: loop trips summed over waves (lane_trips / (64 * wave_trips) = lane use)    */
+    uint64_t positions;             /* K8: query positions consumed                                                    */
+    uint64_t enum_jobs;             /* K8: wave-cooperative enumeration jobs                                           */
+    uint64_t prefilter_probes;      /* K8a: presence-filter words read                                                 */
+    uint64_t prefilter_query_loads; /* K8a: 16-byte query loads                                                        */
+    uint64_t prefilter_items;       /* K8a: work items screened                                                        */
+    uint64_t items;                 /* work items of the batch                                                         */
+    uint64_t survivors;             /* work items K8 scanned                                                           */
+    uint64_t mems;                  /* MEMs found                                                                      */
+    uint64_t overflow_records;      /* MEMs that went through the atomic overflow list                                 */
+    uint64_t valid;                 /* 1 when the counters describe a launch                                           */
+    uint64_t reserved[6];
+} slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */
 int slamem_abi_version(void);
@@ -91,6 +120,10 @@ int slamem_device_count(int *count_out);
 int slamem_device_warmup(int device);
 int slamem_get_timings(slamem_timings *out);
 int slamem_reset_timings(void);
+/* on != 0: the NEXT slamem_find_mems_device calls of this thread run the diagnostic kernel instantiations (same results,
+ * slower) and slamem_get_search_stats returns the counters of the last one.  No reference counterpart. */
+int slamem_search_stats_enable(int on);
+int slamem_get_search_stats(slamem_search_stats *out);
 
 /* ---- (a) index construction ------------------------------------------- */
 /* Replaces FMI_BuildIndex(texts,sizes,1,&lcp,verbose) (bwtindex.h:7, call at
@@ -118,6 +151,10 @@ int slamem_index_attach(void *arena_dev, uint64_t bytes, int device, slamem_inde
 int slamem_index_adopt_arena(slamem_index *idx);
 int slamem_index_save(const slamem_index *idx, const char *path);
 int slamem_index_load(const char *path, int device, slamem_index **out);
+/* Host-only check of the first bytes (>= 256) of an arena or index file against the bytes available: magic, version, and
+ * every section offset / size the kernels will index (aligned, ordered, inside the arena).  load and attach run the
+ * same check; a corrupt or truncated index is SLAMEM_ERR_FORMAT, never a GPU fault. */
+int slamem_index_validate_header(const void *header, uint64_t header_bytes, uint64_t available_bytes);
 
 /* Structure-level parity (all uniquely defined by the text).
  * which: one of SLAMEM_ARRAY_*; host_dst must hold count elements of the stated type. */

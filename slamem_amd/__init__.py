@@ -5,4 +5,4 @@ The product is ``csrc/libslamem_hip.so`` (hand-written HIP kernels for gfx950 be
 around the C ABI used by the tests and ``bench.py``; importing it does not load the library, every
 compute call does and fails loudly when it is missing (there is no CPU fallback).
 """
-__all__ = ["capi", "engine", "synth", "fasta"]
+__all__ = ["capi", "engine", "shard", "synth"]

@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "slamem_get_timings", "slamem_reset_timings", "slamem_device_warmup",
     "slamem_index_build", "slamem_index_build_device", "slamem_index_free", "slamem_index_get_info",
     "slamem_index_arena", "slamem_index_export", "slamem_index_attach", "slamem_index_adopt_arena", "slamem_index_save", "slamem_index_load",
+    "slamem_index_validate_header", "slamem_search_stats_enable", "slamem_get_search_stats",
     "slamem_index_download", "slamem_index_sampled_lcp_stats",
     "slamem_follow_letter_batch", "slamem_enclosing_interval_batch", "slamem_position_in_text_batch",
     "slamem_char_at_bwt_pos_batch",
@@ -60,10 +61,21 @@ class Timings(C.Structure):
     _fields_ = [("build_total_ms", C.c_float), ("build_pack_ms", C.c_float), ("build_sort_ms", C.c_float),
                 ("build_bwt_ms", C.c_float), ("build_lcp_ms", C.c_float), ("build_links_ms", C.c_float),
                 ("search_kernel_ms", C.c_float), ("search_total_ms", C.c_float),
-                ("search_launches", C.c_uint64), ("search_kernel_ms_sum", C.c_double)]
+                ("search_launches", C.c_uint64), ("search_kernel_ms_sum", C.c_double),
+                ("prefilter_ms", C.c_float), ("reserved0", C.c_float), ("prefilter_ms_sum", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
+
+
+class SearchStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "fm_lines_top", "fm_lines_bottom", "rec_lines_fail", "rec_lines_pend", "rec_lines_flush", "query_loads",
+        "lane_trips", "wave_trips", "positions", "enum_jobs", "prefilter_probes", "prefilter_query_loads",
+        "prefilter_items", "items", "survivors", "mems", "overflow_records", "valid")] + [("reserved", C.c_uint64 * 6)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
 
 
 _LIB = None
@@ -88,6 +100,9 @@ def _declare(L):
     L.slamem_index_adopt_arena.argtypes = [vp]
     L.slamem_index_save.argtypes = [vp, C.c_char_p]
     L.slamem_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.slamem_index_validate_header.argtypes = [vp, u64, u64]
+    L.slamem_search_stats_enable.argtypes = [i32]
+    L.slamem_get_search_stats.argtypes = [C.POINTER(SearchStats)]
     L.slamem_index_download.argtypes = [vp, i32, vp, u64]
     L.slamem_index_sampled_lcp_stats.argtypes = [vp, C.POINTER(SslcpStats)]
     L.slamem_follow_letter_batch.argtypes = [vp, vp, vp, vp, vp, u64, vp]
@@ -129,7 +144,7 @@ def lib():
         _load_torch_runtime_first()
         L = C.CDLL(LIB_PATH)
         _declare(L)
-        if L.slamem_abi_version() != 1:
+        if L.slamem_abi_version() != 2:
             raise ImportError("libslamem_hip.so ABI version mismatch")
         _LIB = L
     return _LIB
@@ -145,6 +160,7 @@ def synth_lib():
         S.slamem_synth_reference.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         S.slamem_synth_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
                                          C.c_double, C.c_uint64, C.c_uint32, C.c_void_p]
+        S.slamem_synth_plant_repeats.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
         _SYNTH = S
     return _SYNTH
 

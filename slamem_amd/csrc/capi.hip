@@ -28,6 +28,10 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 Timings& thread_timings() { return g_tm; }
+static thread_local bool g_want_stats = false;
+static thread_local slamem_search_stats g_stats;
+bool search_stats_wanted() { return g_want_stats; }
+slamem_search_stats& last_search_stats() { return g_stats; }
 
 int download_array(const slamem_index* idx, int which, void* host_dst, uint64_t count);
 int sampled_lcp_stats(const slamem_index* idx, slamem_sslcp_stats* out);
@@ -50,14 +54,41 @@ static int check_device(int device) {
     return SLAMEM_OK;
 }
 
+// Every section the kernels will index must lie inside the arena, in order, aligned for the paired 64-byte FM blocks:
+// a truncated, stale or corrupted file / peer buffer is refused here instead of faulting on the GPU.
 static int header_ok(const ArenaHeader& h, uint64_t bytes) {
     if (h.magic_lo != kArenaMagicLo || h.magic_hi != kArenaMagicHi || h.version != kArenaVersion) {
         set_error("not a slamem index arena (bad magic / version)");
         return SLAMEM_ERR_FORMAT;
     }
-    if (h.total_bytes > bytes || h.off_nrows >= h.total_bytes || h.off_fm != kHeaderBytes) {
+    if (h.total_bytes > bytes || h.total_bytes < kHeaderBytes) {
         set_error("index arena truncated: header says %llu bytes, got %llu", (unsigned long long)h.total_bytes,
                   (unsigned long long)bytes);
+        return SLAMEM_ERR_FORMAT;
+    }
+    const uint64_t R = (uint64_t)h.n + 1;
+    const char* bad = nullptr;
+    uint64_t end = kHeaderBytes;  // end of the previous section
+    auto section = [&](uint64_t off, uint64_t size, const char* name) {
+        if (bad) return;
+        if ((off & 127u) != 0 || off < end || off > h.total_bytes || size > h.total_bytes - off) bad = name;
+        end = off + size;
+    };
+    if (h.n == 0 || h.n > 0xFFFFFFF0u) bad = "text length";
+    if (!bad && h.nblocks != (uint32_t)((R + 1 + kFmRows - 1) >> kFmRowsLog2)) bad = "FM block count";
+    if (!bad && h.off_fm != kHeaderBytes) bad = "FM block offset";
+    section(h.off_fm, (uint64_t)h.nblocks * sizeof(FMBlock), "FM blocks");
+    section(h.off_rec, (R + 1) * sizeof(RowRec), "row records");
+    section(h.off_sa, R * 4, "suffix array");
+    if (!bad && h.num_n > h.n) bad = "N row count";
+    section(h.off_nrows, (uint64_t)(h.num_n ? h.num_n : 1) * 4, "N row list");
+    if (h.off_kfilter) {
+        if (!bad && (h.kfilter_log2 < 10 || h.kfilter_log2 > 40 || h.kfilter_k < 4 || h.kfilter_k > 31)) bad = "presence filter parameters";
+        if (!bad) section(h.off_kfilter, 8ull << h.kfilter_log2, "presence filter");
+    }
+    if (!bad && h.dollar_row > h.n) bad = "'$' row";
+    if (bad) {
+        set_error("index arena is corrupt or truncated: bad %s", bad);
         return SLAMEM_ERR_FORMAT;
     }
     return SLAMEM_OK;
@@ -105,6 +136,17 @@ int slamem_device_warmup(int device) {
 int slamem_get_timings(slamem_timings* out) {
     if (!out) return SLAMEM_ERR_ARG;
     *out = g_tm.t;
+    return SLAMEM_OK;
+}
+
+int slamem_search_stats_enable(int on) {
+    g_want_stats = on != 0;
+    return SLAMEM_OK;
+}
+
+int slamem_get_search_stats(slamem_search_stats* out) {
+    if (!out) return SLAMEM_ERR_ARG;
+    *out = g_stats;
     return SLAMEM_OK;
 }
 
@@ -177,6 +219,7 @@ int slamem_index_export(const slamem_index* idx, void* dst_dev, uint64_t dst_byt
 
 int slamem_index_attach(void* arena_dev, uint64_t bytes, int device, slamem_index** out) {
     if (!arena_dev || !out || bytes < kHeaderBytes) { set_error("slamem_index_attach: bad arena"); return SLAMEM_ERR_ARG; }
+    if (((uintptr_t)arena_dev & 127u) != 0) { set_error("slamem_index_attach: the arena must be 128-byte aligned"); return SLAMEM_ERR_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
     SLAMEM_HIP(hipSetDevice(device));
@@ -222,19 +265,29 @@ int slamem_index_save(const slamem_index* idx, const char* path) {
     return rc;
 }
 
+int slamem_index_validate_header(const void* header, uint64_t header_bytes, uint64_t available_bytes) {
+    if (!header || header_bytes < sizeof(ArenaHeader)) { set_error("slamem_index_validate_header: need the first %zu bytes", sizeof(ArenaHeader)); return SLAMEM_ERR_ARG; }
+    ArenaHeader h;
+    memcpy(&h, header, sizeof(h));
+    return header_ok(h, available_bytes);
+}
+
 int slamem_index_load(const char* path, int device, slamem_index** out) {
     if (!path || !out) return SLAMEM_ERR_ARG;
-    int rc = check_device(device);
-    if (rc) return rc;
+    int rc;
     FILE* f = fopen(path, "rb");
     if (!f) { set_error("cannot open <%s>", path); return SLAMEM_ERR_IO; }
     ArenaHeader h;
     if (fread(&h, 1, sizeof(h), f) != sizeof(h)) { fclose(f); set_error("<%s> is too short", path); return SLAMEM_ERR_FORMAT; }
-    rc = header_ok(h, h.total_bytes);
+    uint64_t file_bytes = 0;
+    if (fseeko(f, 0, SEEK_END) == 0) { off_t e2 = ftello(f); if (e2 > 0) file_bytes = (uint64_t)e2; }
+    rc = header_ok(h, file_bytes);  // before any device call: a bad file is reported as such on any machine
+    if (rc == SLAMEM_OK) rc = check_device(device);
     if (rc) { fclose(f); return rc; }
-    SLAMEM_HIP(hipSetDevice(device));
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { fclose(f); return hip_fail(e, "hipSetDevice", __FILE__, __LINE__); }
     void* arena = nullptr;
-    hipError_t e = hipMalloc(&arena, h.total_bytes);
+    e = hipMalloc(&arena, h.total_bytes);
     if (e != hipSuccess) { fclose(f); return hip_fail(e, "hipMalloc(load)", __FILE__, __LINE__); }
     const uint64_t chunk = 64ull << 20;
     char* buf = static_cast<char*>(malloc(chunk));

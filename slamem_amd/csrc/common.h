@@ -57,9 +57,7 @@ struct ArenaHeader {
     uint64_t off_sa;      // uint32[n+1]    suffix array
     uint64_t off_nrows;   // uint32[num_n]  sorted BWT rows holding N
     uint64_t off_kfilter; // uint64[1 << kfilter_log2]  k-mer presence filter (0 = absent)
-    uint64_t off_ptext;   // uint64[]  the text, 4-bit letter ids, 16 per word, first letter in the top nibble (0 = absent)
-    uint64_t off_isa;     // uint32[n+1]  inverse suffix array: BWT row of the suffix that starts at text position s
-    uint64_t off_pd;      // uint8[n+1]   text-ordered parent depth: min(255, max(LCP[row], LCP[row+1])), row = ISA[s]
+    uint64_t reserved_off[3];
     uint32_t kfilter_log2;
     uint32_t kfilter_k;
     uint32_t nblocks;
@@ -79,9 +77,6 @@ struct IndexView {
     const uint32_t* sa;
     const uint32_t* nrows;
     const uint64_t* kfilter;  // nullptr when the index has no presence filter
-    const uint64_t* ptext;    // nullptr when the index has no text-ordered sections (direct extension off)
-    const uint32_t* isa;
-    const uint8_t* pd;
     uint32_t n;
     uint32_t nblocks;
     uint32_t dollar_row;
@@ -122,6 +117,8 @@ struct Timings {
     slamem_timings t;
 };
 Timings& thread_timings();
+bool search_stats_wanted();
+slamem_search_stats& last_search_stats();
 
 }  // namespace slamem
 

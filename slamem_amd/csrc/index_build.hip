@@ -377,21 +377,6 @@ __global__ void k_lcp_sentinels(uint32_t rows, uint32_t* l32, uint32_t* psv, uin
     }
 }
 
-// text-ordered parent depth: for the suffix starting at text position s (BWT row r = ISA[s]) the depth of the parent
-// of the single-row interval [r,r] = max(LCP[r], LCP[r+1]) (lcparray.c:514-518), clipped to 255 = "255 or more".
-// Lets the direct extension of a unique match know, from sequential memory, at which positions an ancestor interval
-// may still be >= min_len deep.
-__global__ void __launch_bounds__(256) k_parent_depth_text(const uint32_t* __restrict__ isa, const uint32_t* __restrict__ l32,
-                                                           uint32_t rows, uint8_t* __restrict__ pd) {
-    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= rows) return;
-    uint32_t r = isa[s];
-    uint32_t a = l32[r], b = l32[r + 1];  // LCP+1 (0 = sentinel)
-    uint32_t d = (a > b ? a : b);
-    d = d ? d - 1u : 0u;
-    pd[s] = (uint8_t)(d < 255u ? d : 255u);
-}
-
 // the 16-byte row records: record i describes the boundaries of row i: {LCP[i]+1, PSV[i], LCP[i+1]+1, NSV[i+1]}
 __global__ void __launch_bounds__(256) k_pack_records(const uint32_t* __restrict__ l32, const uint32_t* __restrict__ psv,
                                                       const uint32_t* __restrict__ nsv, uint32_t rows,
@@ -572,9 +557,6 @@ void make_view(slamem_index* idx) {
     idx->view.kfilter = h.off_kfilter ? reinterpret_cast<const uint64_t*>(base + h.off_kfilter) : nullptr;
     idx->view.kfilter_log2 = h.kfilter_log2;
     idx->view.kfilter_k = h.kfilter_k;
-    idx->view.ptext = h.off_ptext ? reinterpret_cast<const uint64_t*>(base + h.off_ptext) : nullptr;
-    idx->view.isa = h.off_ptext ? reinterpret_cast<const uint32_t*>(base + h.off_isa) : nullptr;
-    idx->view.pd = h.off_ptext ? reinterpret_cast<const uint8_t*>(base + h.off_pd) : nullptr;
     idx->view.n = h.n;
     idx->view.nblocks = h.nblocks;
     idx->view.dollar_row = h.dollar_row;
@@ -664,14 +646,6 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
             hdr.kfilter_log2 = lg;
             hdr.kfilter_k = kf_k;
             off = align_up(off + (8ull << lg), 256);
-        }
-    }
-    {   // text-ordered sections for the direct extension of unique matches (K8): packed text, ISA, parent depths
-        const char* de = getenv("SLAMEM_DIRECT");
-        if (de && atoi(de) != 0) {  // experimental: off unless asked for
-            hdr.off_ptext = off; off = align_up(off + nwords * 8, 256);
-            hdr.off_isa = off;   off = align_up(off + R * 4, 256);
-            hdr.off_pd = off;    off = align_up(off + R + 64, 256);
         }
     }
     hdr.total_bytes = off;
@@ -894,14 +868,6 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
     hipLaunchKernelGGL(k_pack_records, dim3(grid_for(R + 1)), dim3(256), 0, stream, d_l32, d_psv, d_nsv, rows, d_rec);
     SLAMEM_HIP(hipGetLastError());
-    if (hdr.off_ptext) {
-        SLAMEM_HIP(hipMemcpyAsync(base + hdr.off_ptext, pk.p, nwords * 8, hipMemcpyDeviceToDevice, stream));
-        SLAMEM_HIP(hipMemcpyAsync(base + hdr.off_isa, rank.p, R * 4, hipMemcpyDeviceToDevice, stream));
-        SLAMEM_HIP(hipMemsetAsync(base + hdr.off_pd, 0xFF, R + 64, stream));
-        hipLaunchKernelGGL(k_parent_depth_text, dim3(grid_for(R)), dim3(256), 0, stream, rank.as<uint32_t>(), d_l32, rows,
-                           reinterpret_cast<uint8_t*>(base + hdr.off_pd));
-        SLAMEM_HIP(hipGetLastError());
-    }
     SLAMEM_HIP(hipEventRecord(ev.b, stream));
     SLAMEM_HIP(hipMemcpyAsync(h_scal, d_scal, sizeof(h_scal), hipMemcpyDeviceToHost, stream));
     SLAMEM_HIP(hipStreamSynchronize(stream));

@@ -173,8 +173,7 @@ struct SearchArgs {
     const uint8_t* item_alive;  // v3: nullptr, or 0 for items the k-mer presence filter proved empty
     const uint32_t* work_ids;   // v3: nullptr (work = all items), or the ids of the items that survived the prefilter
     const uint32_t* work_count; // v3: device word holding their number
-    int32_t direct_min_depth;   // v3: unique matches at least this long are extended by direct text comparison (<0: off)
-    uint32_t pad2;
+    unsigned long long* stats;  // diagnostic instantiations only: SC_COUNT counters
     uint64_t query_words;       // v3: 8-byte words of the query buffer that may be read
 };
 
@@ -214,6 +213,10 @@ struct QueryCursorT {
         q0 = q1 = q2 = q3 = 0;
     }
     __device__ __forceinline__ void forget() { cidx = ~0ull; }
+    __device__ __forceinline__ uint32_t would_load(uint32_t j) const {  // diagnostics: does at(j) fetch a new window?
+        uint64_t addr = base + (rev ? (uint64_t)(len - 1u - j) : (uint64_t)j);
+        return (addr & ~(uint64_t)(kBytes - 1u)) != cidx ? 1u : 0u;
+    }
     // letter id of position j of the scanned strand
     __device__ __forceinline__ uint32_t at(uint32_t j) {
         uint64_t addr = base + (rev ? (uint64_t)(len - 1u - j) : (uint64_t)j);  // byte offset in the buffer
@@ -259,8 +262,10 @@ struct QueryStream {
     uint32_t nq;             // pieces waiting in n1..n3
     uint32_t chunks;         // 16-byte chunks not loaded yet that still overlap the record
     uint32_t rev;
+    uint32_t loads;          // 16-byte loads issued (read by the diagnostic instantiation only; dead code otherwise)
     __device__ __forceinline__ void init(const uint64_t* words, uint64_t base, uint32_t len, uint32_t r, uint32_t start) {
         rev = r;
+        loads = 1;
         uint64_t addr = base + (r ? (uint64_t)(len - 1u - start) : (uint64_t)start);  // byte offset of the first letter
         p = reinterpret_cast<const uint4*>(words) + (addr >> 4);
         chunks = r ? (uint32_t)((addr >> 4) - (base >> 4)) : (uint32_t)(((base + len - 1u) >> 4) - (addr >> 4));
@@ -292,6 +297,7 @@ struct QueryStream {
                 else { cur = ahi; n1 = alo; n2 = bhi; n3 = blo; p -= two ? 2 : 1; }
                 nq = two ? 3u : 1u;
                 chunks -= two ? 2u : 1u;
+                loads += two ? 2u : 1u;
             }
             left = 8u;
         }
@@ -468,6 +474,7 @@ __device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32
     if (kk < kInlineMems) {
         A.inline_rows[(uint64_t)g * kInlineMems + kk] = RawRow{row, pos, len};
     } else {
+        if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(A.total) + 9, 1u);  // the ordinal would run into the tag: reported as an error
         unsigned long long slot = atomicAdd(A.total, 1ull);
         if (slot < A.capacity) {
             A.raw_key[slot] = RawKey{g, kk | tag};  // tag = attempt << 28: records of abandoned attempts are skipped
@@ -516,58 +523,26 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
     return k;
 }
 
-// ---- direct extension of a unique match ---------------------------------------------------------------------
-// Once the interval is a single row, the matched string occurs exactly once in the text, at r = SA[row]; extending it
-// to the left is then a comparison of the query with the text itself -- sequential memory, 32 letters per trip --
-// instead of one random FM-block line per letter.  Nothing can be emitted on the way as long as the letters agree
-// (the single row's BWT letter IS the left letter) and the parent of the single-row interval stays shallower than
-// min_len, which the text-ordered parent-depth bytes tell without touching the row records.  The run ends at the
-// first disagreeing letter, at a position whose parent may qualify, or at the slice / text boundary; ISA gives the
-// row back and the normal machinery (parent step, enumeration) takes over.  The reference walks these positions
-// one FMI_FollowLetter at a time (slamem.c:121).
-// 8 query bytes -> 8 letter ids (A=2 C=3 G=4 T=5, anything else 1), one id in the low bits of every byte (SWAR).
-__device__ __forceinline__ uint64_t letter_ids8(uint64_t x, bool complement) {
-    const uint64_t k01 = 0x0101010101010101ull, k7f = 0x7F7F7F7F7F7F7F7Full;
-    uint64_t b = x & 0xDFDFDFDFDFDFDFDFull;                  // upper case
-    uint64_t v0 = (b >> 1) & k01, v1 = (b >> 2) & k01;        // A:00 C:01 T:10 G:11 (v1 v0)
-    uint64_t t = v1 & ~v0 & k01;                              // T
-    uint64_t expect = (0x41ull * k01) ^ t ^ (t << 4);         // the other six bits an A/C/G/T byte must have
-    uint64_t y = (b & 0xF9F9F9F9F9F9F9F9ull) ^ expect;        // zero byte <=> really one of A,C,G,T
-    uint64_t nz = ((y & k7f) + k7f) | y;                      // bit 7 of a byte set <=> byte != 0
-    uint64_t ok = (~nz >> 7) & k01;                           // 1 per valid byte
-    uint64_t code = v0 ^ v1;                                  // low bit of the 2-bit order value: A0 C1 G0 T1 ...
-    code = (v1 << 1) | (v0 ^ v1);                             // A:0 C:1 G:2 T:3
-    if (complement) code ^= 3ull * k01;                       // A<->T, C<->G
-    uint64_t id = code + 2ull * k01;                          // 2..5
-    return (id & (ok * 0xFFull)) | ((ok ^ k01));              // invalid bytes -> 1 (N)
-}
-// 8 bytes (ids in their low nibbles) -> 8 nibbles; byte 0 becomes the LOWEST nibble
-__device__ __forceinline__ uint32_t pack_nibbles8(uint64_t c) {
-    c &= 0x0F0F0F0F0F0F0F0Full;
-    c = (c | (c >> 4)) & 0x00FF00FF00FF00FFull;
-    c = (c | (c >> 8)) & 0x0000FFFF0000FFFFull;
-    c = (c | (c >> 16));
-    return (uint32_t)c;
-}
-__device__ __forceinline__ uint32_t reverse_nibbles32(uint32_t v) {
-    v = __builtin_bswap32(v);
-    return ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
-}
-// bytes of a 128-bit value that are >= lim (lim <= 128) or 255: bit 7 of each such byte
-__device__ __forceinline__ uint64_t bytes_ge(uint64_t p, uint32_t lim) {
-    const uint64_t k7f = 0x7F7F7F7F7F7F7F7Full;
-    return (((p & k7f) + (uint64_t)(0x80u - lim) * 0x0101010101010101ull) | p) & 0x8080808080808080ull;
-}
-__device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t byte_shift) {  // bytes [s, s+8) of hi:lo
-    return byte_shift ? (lo >> (8u * byte_shift)) | (hi << (64u - 8u * byte_shift)) : lo;
-}
+enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2 };
 
-enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DISA = 5 };
+// Counters of a diagnostic launch (template parameter kStats; the timed kernels are the kStats = false instantiations,
+// which carry none of this): how many loads of each kind the lanes issue.  One 64-bit word each, at SearchArgs::stats.
+enum : uint32_t {
+    SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
+    SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS, SC_COUNT
+};
+template <bool kStats>
+__device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
+    if (!kStats) return;
+    // wave-reduced: one atomic per wave and counter
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(dst, (unsigned long long)v);
+}
 
 #ifndef SLAMEM_V3_WAVES
 #define SLAMEM_V3_WAVES 1
 #endif
-template <bool kDirect>
+template <bool kStats>
 __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
     __shared__ ItemDesc lds_item[4][kChunkMax];
     const IndexView& ix = A.ix;
@@ -590,12 +565,12 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     }
     __syncthreads();
 
-#ifdef SLAMEM_K8_STATS
-    // diagnostic build: how many loads of each kind the lanes issue (reported per launch by find_mems_device)
-    uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_pos = 0, n_enum = 0;
-#endif
-    bool active = false, pend = false, dir_moved = false;
-    uint32_t st = ST_EXT, dir_r = 0;  // state; text position where the current (unique) match starts
+    // diagnostic instantiation only
+    uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_wtrips = 0, n_pos = 0,
+             n_enum = 0, n_qloads = 0;
+
+    bool active = false, pend = false;
+    uint32_t st = ST_EXT;
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
     uint32_t a_pos = 0, b_pos = 0, attempt = 0;  // emitted slice [a_pos, b_pos) of the strand, warm-up attempt
     int depth = 0, pub = -1;
@@ -622,7 +597,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 b_pos = d.len - a_pos < kSliceLen ? d.len : a_pos + kSliceLen;
                 attempt = 0;
                 j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
-                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; dir_moved = false; k = 0;
+                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; k = 0;
                 if (d.len == 0) {  // empty record: nothing to scan
                     A.block_counts[g] = 0;
                     A.item_attempt[g] = 0;
@@ -634,6 +609,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             if (next >= chunk_end) break;
             continue;
         }
+        if (kStats) n_wtrips += lane == 0u;
 
         // enumeration job of this trip (rare): rows that the lane does not emit itself
         bool e_on = false, e_level0 = false, e_up = false;
@@ -644,45 +620,29 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             // ---- memory phase: every load of this trip, no use in between -------------------------------------
             uint4 rt = make_uint4(0, 0, 0, 0), rb = rt;
             bool want_rec = st == ST_REC || st == ST_FLUSH;
-            uint32_t c = 0, isa_row = 0, W = 0, lo = 0;
-            uint64_t tw0 = 0, tw1 = 0, pw0 = 0, pw1 = 0, pw2 = 0, qw0 = 0, qw1 = 0, qw2 = 0, qb = 0;
+            uint32_t c = 0;
             Blk kb;  // block of bot+1 when it differs from top's (wide intervals only: not kept across trips)
             kb.a = kb.b = kb.c = kb.d = make_uint4(0, 0, 0, 0);
             if (st == ST_EXT) {
                 uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
-#ifdef SLAMEM_K8_STATS
-                n_kt += bt != tag_t; n_kb += bb != bt; n_rec_pend += (pend && pub >= L);
-#endif
+                if (kStats) { n_kt += bt != tag_t; n_kb += bb != bt; }
                 if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
                 if (bb != bt) kb = load_blk(ix.fm, bb);
                 // records together with the blocks: when a pending position's parent may still be >= min_len deep
                 // (its depth is needed now), or speculatively while the match is short (off by default)
                 want_rec = depth <= A.spec_depth || (pend && pub >= L);
-            } else if (kDirect && st == ST_DSA) {
-                rt.w = ix.sa[top];  // SA of the single row
-            } else if (kDirect && st == ST_DISA) {
-                isa_row = ix.isa[dir_r];
-            } else if (kDirect && st == ST_DIR) {
-                // 16 letters per trip: text [dir_r-16, dir_r), their parent-depth bytes, the 16 query letters below j
-                lo = dir_r - 16u;
-                const uint64_t* tp = ix.ptext + (lo >> 4);
-                tw0 = tp[0]; tw1 = tp[1];
-                const uint64_t* pp = reinterpret_cast<const uint64_t*>(ix.pd) + (lo >> 3);
-                pw0 = pp[0]; pw1 = pp[1]; pw2 = pp[2];
-                uint64_t qs = qc.base + (qc.rev ? (uint64_t)(qc.len - j) : (uint64_t)j - 16u);
-                qb = qs >> 3;
-                const uint64_t nw = A.query_words;
-                qw0 = qb < nw ? qc.words[qb] : 0ull;
-                qw1 = qb + 1 < nw ? qc.words[qb + 1] : 0ull;
-                qw2 = qb + 2 < nw ? qc.words[qb + 2] : 0ull;
-                W = j - a_pos;  // positions that may still be consumed by this item
-                if (W > 16u) W = 16u;
+                if (kStats && want_rec) n_rec_pend += 1u + ((top >> 2) != (bot >> 2));
             }
-#ifdef SLAMEM_K8_STATS
-            n_trips++; n_rec_fail += st == ST_REC; n_rec_flush += st == ST_FLUSH;
-#endif
+            if (kStats) {
+                n_trips++;
+                if (st == ST_REC) n_rec_fail += 1u + ((top >> 2) != (bot >> 2));
+                if (st == ST_FLUSH) n_rec_flush += 1u + ((top >> 2) != (bot >> 2));
+            }
             if (want_rec) { rt = R[top]; rb = R[bot]; }
-            if (st == ST_EXT) c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
+            if (st == ST_EXT) {
+                if (kStats) n_qloads += qc.would_load(j - 1u);
+                c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
+            }
 
             // ---- compute phase -------------------------------------------------------------------------------
             bool strand_end = false;  // position 0 has been consumed: flush what is pending, finish
@@ -699,87 +659,6 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 int d = parent_from(rt, rb, top, bot);
                 if (d < 0) { depth = 0; pub = -1; consumed = true; }
                 else { depth = d; pub = d - 1; }
-            } else if (kDirect && st == ST_DSA) {
-                dir_r = rt.w;
-                dir_moved = false;
-                // the 16-letter windows must lie inside the text and the query buffer; the few positions at their
-                // very beginning go the normal way
-                st = (dir_r >= 16u && qc.base + j >= 16u) ? ST_DIR : ST_EXT;
-            } else if (kDirect && st == ST_DISA) {
-                top = bot = isa_row;
-                dir_moved = false;
-                st = ST_EXT;
-                if (j == 0u) strand_end = true;
-            } else if (kDirect && st == ST_DIR) {
-                uint32_t kc = 0, last_pd = 0;
-                bool special = false;
-                {
-                    // text window: letter of position dir_r-1 in the lowest nibble
-                    uint32_t sh = (lo & 15u) * 4u;
-                    uint64_t T = sh ? (tw0 << sh) | (tw1 >> (64u - sh)) : tw0;
-                    // query window in the same layout
-                    uint64_t qs = qc.base + (qc.rev ? (uint64_t)(qc.len - j) : (uint64_t)j - 16u);
-                    uint32_t bs = (uint32_t)(qs & 7u);
-                    uint64_t q0 = funnel64(qw0, qw1, bs), q1 = funnel64(qw1, qw2, bs);  // memory bytes 0..7, 8..15
-                    uint32_t n0 = pack_nibbles8(letter_ids8(q0, qc.rev != 0u)), n1 = pack_nibbles8(letter_ids8(q1, qc.rev != 0u));
-                    uint64_t Q;
-                    if (qc.rev) Q = ((uint64_t)n1 << 32) | n0;  // memory byte 0 is position j-1: already "last letter lowest"
-                    else Q = ((uint64_t)reverse_nibbles32(n0) << 32) | reverse_nibbles32(n1);  // byte 15 is position j-1
-                    uint64_t x = T ^ Q;
-                    uint32_t km = x ? (uint32_t)__builtin_ctzll(x) >> 2 : 16u;
-                    if (km > W) km = W;
-                    if (km != 0u) {
-                        // parent-depth bytes of positions lo..lo+15 (byte k of P0 / P1 = position lo+k / lo+8+k)
-                        uint32_t ps = lo & 7u;
-                        uint64_t P0 = funnel64(pw0, pw1, ps), P1 = funnel64(pw1, pw2, ps);
-                        uint64_t s1 = bytes_ge(P1, (uint32_t)L), s0 = bytes_ge(P0, (uint32_t)L);
-                        uint64_t m1 = km >= 8u ? s1 : s1 & (~0ull << (8u * (8u - km)));
-                        uint64_t m0 = km > 8u ? s0 & (~0ull << (8u * (16u - km))) : 0ull;
-                        if (m1) {          // the special position closest to the match start wins
-                            uint32_t bidx = (63u - (uint32_t)__builtin_clzll(m1)) >> 3;
-                            kc = 8u - bidx;
-                            last_pd = (uint32_t)(P1 >> (8u * bidx)) & 0xFFu;
-                            special = true;
-                        } else if (m0) {
-                            uint32_t bidx = (63u - (uint32_t)__builtin_clzll(m0)) >> 3;
-                            kc = 16u - bidx;
-                            last_pd = (uint32_t)(P0 >> (8u * bidx)) & 0xFFu;
-                            special = true;
-                        } else {
-                            kc = km;
-                            uint32_t bi = 16u - kc;  // byte index of position dir_r - kc in the 16-byte window
-                            last_pd = bi >= 8u ? (uint32_t)(P1 >> (8u * (bi - 8u))) & 0xFFu : (uint32_t)(P0 >> (8u * bi)) & 0xFFu;
-                        }
-                    }
-                }
-                if (kc != 0u) {
-                    const uint32_t j_old = j;
-                    depth += (int)kc;
-                    j -= kc;
-                    dir_r -= kc;
-                    dir_moved = true;
-                    pub = last_pd == 255u ? 0x3FFFFFFF : (int)last_pd;  // exact parent depth of the new single-row interval
-                    const bool in_slice = j >= a_pos && j < b_pos;
-                    pend = depth >= L && depth > 0 && in_slice;
-                    uint32_t e = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
-                                                                                                       : b_pos + (kWarmUp << (2u * attempt));
-                    const bool touched = j < b_pos && j_old - 1u >= a_pos;
-                    if (touched && e < qc.len && (uint32_t)depth == e - j) {  // the match reaches the scan start: redo
-                        attempt++;
-                        j = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
-                                                                                                : b_pos + (kWarmUp << (2u * attempt));
-                        top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; k = 0;
-                        qc.forget();
-                        st = ST_EXT;
-                        dir_moved = false;
-                    } else if (kc == 16u && !special && j > a_pos && dir_r >= 16u && qc.base + j >= 16u) {
-                        st = ST_DIR;   // the whole window agreed: keep going
-                    } else {
-                        st = ST_DISA;  // hand back: the row of the new match start
-                    }
-                } else {
-                    st = dir_moved ? ST_DISA : ST_EXT;  // first letter disagrees (or nothing left): the normal step decides
-                }
             } else {  // ST_EXT
                 uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
                 uint32_t nt, nb1;
@@ -830,9 +709,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 }
             }
             if (consumed) {
-#ifdef SLAMEM_K8_STATS
-                n_pos++;
-#endif
+                if (kStats) n_pos++;
                 j--;  // position j is done: it matched `depth` characters
                 bool in_slice = j >= a_pos && j < b_pos;
                 pend = depth >= L && depth > 0 && in_slice;  // slamem.c:130
@@ -847,9 +724,6 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                     qc.forget();
                 } else if (j == 0u) {
                     strand_end = true;
-                } else if (kDirect && st == ST_EXT && top == bot && depth >= A.direct_min_depth && A.direct_min_depth >= 0 &&
-                           j > a_pos && !(pend && pub >= L)) {
-                    st = ST_DSA;  // a unique match that is long enough: extend it by comparing with the text
                 }
             }
             if (strand_end) {  // strand finished; rows still pending have nothing to their left (slamem.c:138)
@@ -882,19 +756,15 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             A.item_attempt[g] = (uint8_t)attempt;
             active = false;
         }
-#ifdef SLAMEM_K8_STATS
-        n_enum += e_on;
-#endif
+        if (kStats) n_enum += e_on;
     }
-#ifdef SLAMEM_K8_STATS
-    {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.total) + 1024;  // see find_mems_device
-        atomicAdd(dbg + 0, (unsigned long long)n_kt); atomicAdd(dbg + 1, (unsigned long long)n_kb);
-        atomicAdd(dbg + 2, (unsigned long long)n_rec_fail); atomicAdd(dbg + 3, (unsigned long long)n_rec_pend);
-        atomicAdd(dbg + 4, (unsigned long long)n_rec_flush); atomicAdd(dbg + 5, (unsigned long long)n_trips);
-        atomicAdd(dbg + 6, (unsigned long long)n_pos); atomicAdd(dbg + 7, (unsigned long long)n_enum);
+    if (kStats) {
+        stat_flush<kStats>(A.stats + SC_FM_TOP, n_kt); stat_flush<kStats>(A.stats + SC_FM_BOT, n_kb);
+        stat_flush<kStats>(A.stats + SC_REC_FAIL_LINES, n_rec_fail); stat_flush<kStats>(A.stats + SC_REC_PEND_LINES, n_rec_pend);
+        stat_flush<kStats>(A.stats + SC_REC_FLUSH_LINES, n_rec_flush); stat_flush<kStats>(A.stats + SC_QUERY_LOADS, n_qloads);
+        stat_flush<kStats>(A.stats + SC_LANE_TRIPS, n_trips); stat_flush<kStats>(A.stats + SC_WAVE_TRIPS, n_wtrips);
+        stat_flush<kStats>(A.stats + SC_POSITIONS, n_pos); stat_flush<kStats>(A.stats + SC_ENUM_JOBS, n_enum);
     }
-#endif
 }
 
 // K8a: presence prefilter.  A MEM of length >= L that starts in the item's slice [a,b) contains a k-mer window
@@ -902,11 +772,16 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
 // "absent": no false negatives) the item cannot emit anything and K8 skips it.  Windows holding an N count as
 // present.  One lane per item, early exit at the first present window (the matching strand of a read exits after
 // a few probes; the other strand pays ~ len/s probes instead of a full scan).
+template <bool kStats>
 __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __restrict__ alive) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= A.num_items) return;
+    const bool live = g < A.num_items;
+    if (!kStats && !live) return;
+    if (!live) g = 0;  // diagnostic instantiation: idle lanes stay for the wave reduction at the end (they store nothing)
+    uint32_t n_probe = 0, n_qload = 0;
     const IndexView& ix = A.ix;
     ItemDesc d = A.items[g];
+    if (!live) d.len = 0;
     const uint32_t k = ix.kfilter_k, L = A.min_len;
     const uint32_t s = L - k + 1u;
     uint32_t sl = d.slice_rev & 0x7FFFFFFFu;
@@ -951,6 +826,7 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
                     if (run < k1) res = 1;                      // holds an N: cannot be ruled out
                     else {
                         uint64_t h = kfilter_hash((km & mask1) ^ kFilterShortSalt), bits = kfilter_bits(h);
+                        if (kStats) n_probe++;
                         if ((ix.kfilter[h & wmask] & bits) == bits) confirm = 3;  // k-mers ending at x, x+1, x+2
                     }
                 }
@@ -960,7 +836,8 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
                         if (run < k) res = 1;
                         else {
                             uint64_t h = kfilter_hash(km & maskk), bits = kfilter_bits(h);
-                            if ((ix.kfilter[h & wmask] & bits) == bits) {
+                            if (kStats) n_probe++;
+                        if ((ix.kfilter[h & wmask] & bits) == bits) {
                                 if (three) confirm2 = 3;        // (k+2)-mers ending at x, x+1, x+2
                                 else res = 1;
                             }
@@ -973,11 +850,13 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
                         if (run < k + 2u) res = 1;
                         else {
                             uint64_t h = kfilter_hash(km ^ kFilterLongSalt), bits = kfilter_bits(h);
-                            if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
+                            if (kStats) n_probe++;
+                        if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
                         }
                     }
                 }
             }
+            if (kStats) n_qload += qs.loads;
         }
     } else if (d.len >= k && d.len - a >= 1u) {
         const uint32_t p0 = (a + s - 1u) / s * s;               // first sampled window start >= a
@@ -999,13 +878,20 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
                     if (run < k) res = 1;                       // holds an N: cannot be ruled out
                     else {
                         uint64_t h = kfilter_hash(km), bits = kfilter_bits(h);
+                        if (kStats) n_probe++;
                         if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
                     }
                 }
             }
+            if (kStats) n_qload += qs.loads;
         }
     }
-    alive[g] = res;
+    if (live) alive[g] = res;
+    if (kStats) {
+        stat_flush<kStats>(A.stats + SC_PF_PROBES, n_probe);
+        stat_flush<kStats>(A.stats + SC_PF_QUERY_LOADS, n_qload);
+        stat_flush<kStats>(A.stats + SC_PF_ITEMS, live ? 1u : 0u);
+    }
 }
 
 // K9 for v3: inline slots and overflow records -> grouped output, BWT rows resolved to text positions here
@@ -1151,11 +1037,7 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     WorkspaceLayout w;
     w.max_items = strands * (num_queries + query_bytes / kSliceLen + 1);
     uint64_t off = 0;
-#ifdef SLAMEM_K8_STATS
-    w.off_total = off;    off = align_up(off + 16384, 256);  // + the diagnostic counters at word 1024
-#else
-    w.off_total = off;    off = align_up(off + 64, 256);
-#endif
+    w.off_total = off;    off = align_up(off + 64 + SC_COUNT * 8, 256);  // scalars, then the diagnostic counters
     w.off_cnt = off;      off = align_up(off + (num_queries + 2) * 4, 256);
     w.off_first = off;    off = align_up(off + (num_queries + 2) * 4, 256);
     w.off_scan32 = off;   off = align_up(off + scan_u32_tmp_words(num_queries + 1) * 4, 256);
@@ -1229,19 +1111,17 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     const int kernel_version = match_type == 1 ? 1 : env_kernel_version;
 
     Timings& tm = thread_timings();
-    hipEvent_t e0, e1, e2;
-    SLAMEM_HIP(hipEventCreate(&e0));
-    SLAMEM_HIP(hipEventCreate(&e1));
-    SLAMEM_HIP(hipEventCreate(&e2));
+    const bool want_stats = search_stats_wanted();
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, ep = nullptr;
     int rc = SLAMEM_OK;
     do {
         hipError_t e;
 #define STEP(call, what) if ((e = (call)) != hipSuccess) { rc = hip_fail(e, what, __FILE__, __LINE__); break; }
-#ifdef SLAMEM_K8_STATS
-        STEP(hipMemsetAsync(d_total, 0, 16384, stream), "memset");
-#else
-        STEP(hipMemsetAsync(d_total, 0, 64, stream), "memset");
-#endif
+        STEP(hipEventCreate(&e0), "hipEventCreate");
+        STEP(hipEventCreate(&e1), "hipEventCreate");
+        STEP(hipEventCreate(&e2), "hipEventCreate");
+        STEP(hipEventCreate(&ep), "hipEventCreate");
+        STEP(hipMemsetAsync(d_total, 0, 64 + SC_COUNT * 8, stream), "memset");
         // ---- work items: one per strand, long records cut into slices (v1 scans whole strands) ----------------
         uint64_t nitems = num_blocks;
         hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
@@ -1272,15 +1152,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         A.num_items = nitems;
         A.item_attempt = reinterpret_cast<uint8_t*>(ws + w.off_attempt);
         A.query_words = (query_bytes + 7) / 8;
-        {   // direct extension: on when the index has the text-ordered sections; threshold = where random matches stop
-            static const bool use_direct = [] { const char* v = getenv("SLAMEM_DIRECT"); return v && atoi(v) != 0; }();
-            if (min_len > 128) { /* the SWAR parent-depth test handles limits up to 128 */ }
-            int lg = 0;
-            for (uint64_t v = idx->hdr.n; v > 1; v >>= 2) lg++;
-            A.direct_min_depth = (use_direct && idx->view.ptext && min_len <= 128) ? lg + 5 : -1;
-            const char* e3 = getenv("SLAMEM_DIRECT_DEPTH");
-            if (e3 && A.direct_min_depth >= 0) A.direct_min_depth = atoi(e3);
-        }
+        A.stats = d_total + 8;  // behind the 64 bytes of scalars
         {
             A.spec_depth = -1;  // measured: fetching the records speculatively costs more lines than the trips it saves
             const char* e1 = getenv("SLAMEM_SPEC_DEPTH");
@@ -1290,6 +1162,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             if (e2 && atoi(e2) > 0) A.chunk = (uint32_t)atoi(e2);
             if (A.chunk > kChunkMax) A.chunk = kChunkMax;
         }
+        bool prefiltered = false;
         (void)hipEventRecord(e0, stream);
         if (nitems && kernel_version == 3) {
             hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first,
@@ -1298,8 +1171,11 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
             if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
                 uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
-                hipLaunchKernelGGL(k_prefilter, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
+                if (want_stats) hipLaunchKernelGGL(k_prefilter<true>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
+                else hipLaunchKernelGGL(k_prefilter<false>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
                 STEP(hipGetLastError(), "k_prefilter");
+                (void)hipEventRecord(ep, stream);
+                prefiltered = true;
                 A.item_alive = d_alive;
                 // dead items emit nothing: their counts are zero; the survivors become a dense work list
                 STEP(hipMemsetAsync(d_counts, 0, nitems * 4, stream), "memset");
@@ -1312,7 +1188,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                 A.work_count = d_nwork;
             }
             uint64_t waves = (nitems + A.chunk - 1) / A.chunk;
-            if (A.direct_min_depth >= 0) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             else hipLaunchKernelGGL(k_find_mems_v3<false>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             STEP(hipGetLastError(), "k_find_mems_v3");
         } else if (nitems && match_type == 1) {
@@ -1329,18 +1205,35 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                            num_queries, strands, nitems, block_offsets_dev);
         STEP(hipGetLastError(), "k_block_offsets");
         unsigned long long listed = 0, total = 0;  // listed: records in the atomic list; total: all MEMs
-        STEP(hipMemcpyAsync(&listed, d_total, 8, hipMemcpyDeviceToHost, stream), "memcpy");
+        unsigned long long scal[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] listed; u32 word 8: survivors of K8a, word 9: ordinal overflow flag
+        STEP(hipMemcpyAsync(scal, d_total, sizeof(scal), hipMemcpyDeviceToHost, stream), "memcpy");
         STEP(hipMemcpyAsync(&total, d_itemoff + nitems, 8, hipMemcpyDeviceToHost, stream), "memcpy");
         STEP(hipStreamSynchronize(stream), "k_find_mems (sync)");
-#ifdef SLAMEM_K8_STATS
-        {
-            unsigned long long dbg[8];
-            (void)hipMemcpy(dbg, d_total + 1024, sizeof(dbg), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[K8 stats] items %llu: FM block loads top %llu + bottom %llu, record pairs: failed extension %llu, "
-                            "pending parent %llu, flush %llu; lane trips %llu, positions %llu, enumerations %llu\n",
-                    (unsigned long long)nitems, dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+        listed = scal[0];
+        if ((uint32_t)(scal[4] >> 32) != 0u) {
+            set_error("slamem_find_mems_device: one work item emits 2^28 or more MEMs (a 4096-position slice against a highly "
+                      "repetitive text with a small minimum length); raise min_len");
+            rc = SLAMEM_ERR_CAPACITY;
+            *total_out = total;
+            break;
         }
-#endif
+        if (want_stats) {
+            unsigned long long c[SC_COUNT];
+            const uint32_t nwork = (uint32_t)scal[4];
+            STEP(hipMemcpy(c, A.stats, sizeof(c), hipMemcpyDeviceToHost), "memcpy(stats)");
+            slamem_search_stats& o = last_search_stats();
+            memset(&o, 0, sizeof(o));
+            o.fm_lines_top = c[SC_FM_TOP]; o.fm_lines_bottom = c[SC_FM_BOT];
+            o.rec_lines_fail = c[SC_REC_FAIL_LINES]; o.rec_lines_pend = c[SC_REC_PEND_LINES]; o.rec_lines_flush = c[SC_REC_FLUSH_LINES];
+            o.query_loads = c[SC_QUERY_LOADS]; o.lane_trips = c[SC_LANE_TRIPS]; o.wave_trips = c[SC_WAVE_TRIPS];
+            o.positions = c[SC_POSITIONS]; o.enum_jobs = c[SC_ENUM_JOBS];
+            o.prefilter_probes = c[SC_PF_PROBES]; o.prefilter_query_loads = c[SC_PF_QUERY_LOADS]; o.prefilter_items = c[SC_PF_ITEMS];
+            o.items = nitems;
+            o.survivors = prefiltered ? nwork : nitems;
+            o.mems = total;
+            o.overflow_records = listed;
+            o.valid = kernel_version == 3 ? 1 : 0;
+        }
         *total_out = total;
         if (total > mems_capacity || listed > mems_capacity) {
             // the atomic list also holds the records of abandoned slice attempts: ask for room for those too
@@ -1373,11 +1266,16 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             tm.t.search_kernel_ms_sum += ms;
             tm.t.search_launches++;
         }
+        if (prefiltered && hipEventElapsedTime(&ms, e0, ep) == hipSuccess) {  // item fill + K8a (K8 = the rest up to e1)
+            tm.t.prefilter_ms = ms;
+            tm.t.prefilter_ms_sum += ms;
+        }
         if (hipEventElapsedTime(&ms, e0, e2) == hipSuccess) tm.t.search_total_ms = ms;
     } while (0);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
+    if (ep) (void)hipEventDestroy(ep);
     return rc;
 }
 

@@ -1,6 +1,6 @@
 // prims.h -- device-wide building blocks used by the index build and the MEM output path.
-// Narrow internal interface so that the implementation behind it (hand-written LDS radix
-// passes in radix_sort.hip, rocPRIM scans/compaction in prims.hip) can change freely.
+// Narrow internal interface; everything behind it is hand-written (LDS radix passes in radix_sort.hip, tile scans and
+// flagged compaction in scan.hip): no library primitive is linked into libslamem_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint64_t* __restric
 
 }  // namespace
 
-hipError_t radix_sort_pairs_u64_u32(void* tmp, size_t& tmp_bytes, uint64_t* keys_in, uint64_t* keys_out,
+hipError_t sort_pairs_u64_u32(void* tmp, size_t& tmp_bytes, uint64_t* keys_in, uint64_t* keys_out,
                                     uint32_t* vals_in, uint32_t* vals_out, size_t n, int begin_bit, int end_bit,
                                     hipStream_t stream) {
     const uint64_t tiles = (n + kTile - 1) / kTile;

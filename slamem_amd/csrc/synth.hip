@@ -55,6 +55,53 @@ extern "C" int slamem_synth_reads(const void* ref_dev, uint64_t n, void* out_dev
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Repeat model of SURVEY.md 8(d) for the chromosome-sized configurations (BASELINE.json configs[3] and [4]):
+// 0.5 % of the text is overwritten by copies of 1-10 kbp segments with 1 % substitutions.  Fully determined by
+// (n, seed) -- same values as slamem_amd/synth.py::plant_repeats:
+//   stream P = seed + kRepeatSalt, stream M = seed + kRepeatSalt + 1
+//   segment k: len = 1000 + P[3k] % 9001, src = P[3k+1] % (n-len+1), dst = P[3k+2] % (n-len+1); segments are planted
+//   until their lengths add up to >= n/200; a later segment overwrites an earlier one where destinations overlap
+//   letter i of segment k = base(src+i) -- the UNPLANTED text "ACGT"[draw(seed, src+i) & 3], so segments do not depend
+//   on each other -- substituted when (u32)M[k*16384+i] < 0.01 * 2^32 by alt(c)[(M[..] >> 32) % 3]
+// ---------------------------------------------------------------------------------------------------
+static const uint64_t kRepeatSalt = 0x7265706561747321ull;
+
+static inline uint64_t draw_host(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void k_plant_segment(uint8_t* text, uint64_t seed, uint64_t k, uint64_t src, uint64_t dst, uint32_t len,
+                                uint32_t sub_thr) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    uint32_t code = (uint32_t)(draw(seed, src + i) & 3u);
+    uint8_t c = "ACGT"[code];
+    uint64_t x = draw(seed + kRepeatSalt + 1, k * 16384ull + i);
+    if ((uint32_t)x < sub_thr) c = "CGTAGTACTACG"[code * 3 + (uint32_t)((x >> 32) % 3)];
+    text[dst + i] = c;
+}
+
+// returns the number of planted letters through *planted_out (may be null)
+extern "C" int slamem_synth_plant_repeats(void* text_dev, uint64_t n, uint64_t seed, void* stream, uint64_t* planted_out) {
+    if (n < 20000) return -1;
+    const uint32_t thr = (uint32_t)(uint64_t)(0.01 * 4294967296.0);
+    uint64_t planted = 0;
+    for (uint64_t k = 0; planted < n / 200; k++) {
+        uint32_t len = 1000u + (uint32_t)(draw_host(seed + kRepeatSalt, 3 * k) % 9001u);
+        uint64_t src = draw_host(seed + kRepeatSalt, 3 * k + 1) % (n - len + 1);
+        uint64_t dst = draw_host(seed + kRepeatSalt, 3 * k + 2) % (n - len + 1);
+        hipLaunchKernelGGL(k_plant_segment, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint8_t*)text_dev, seed,
+                           k, src, dst, len, thr);
+        planted += len;
+    }
+    if (planted_out) *planted_out = planted;
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Random 64-byte-line gather ceiling (SURVEY.md 7.2 "Roofline honesty"): every lane walks ILP independent
 // chains of dependent random reads of whole 64-B blocks (4 x 16-B loads, the access shape of an FM-block
 // rank query in k_find_mems).  Also the calibration workload for FETCH_SIZE on this access pattern:

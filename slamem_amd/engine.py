@@ -249,6 +249,20 @@ def reset_timings() -> None:
     capi.lib().slamem_reset_timings()
 
 
+def search_stats(matcher: "Matcher", queries_dev: torch.Tensor, offsets_dev: torch.Tensor, min_len: int) -> dict:
+    """One extra launch of the search through the diagnostic kernel instantiations: the load counters of K8a / K8 for
+    this batch (slamem_search_stats; same results as the normal launch, slower)."""
+    L = capi.lib()
+    L.slamem_search_stats_enable(1)
+    try:
+        matcher.run(queries_dev, offsets_dev, min_len)
+    finally:
+        L.slamem_search_stats_enable(0)
+    st = capi.SearchStats()
+    capi.check(L.slamem_get_search_stats(C.byref(st)))
+    return st.as_dict()
+
+
 # ---- bench / test support: synthetic inputs generated on the GPU (csrc/synth.hip) ----------------------
 def synth_reference(n: int, seed: int = 42, device="cuda:0") -> torch.Tensor:
     dev = _require_gpu(device)
@@ -257,6 +271,16 @@ def synth_reference(n: int, seed: int = 42, device="cuda:0") -> torch.Tensor:
     if rc:
         raise RuntimeError(f"synth kernel launch failed: hip error {rc}")
     return out
+
+
+def synth_plant_repeats(ref: torch.Tensor, seed: int = 42) -> int:
+    """Repeat model of SURVEY.md 8(d) applied in place to a text made by synth_reference(n, seed); returns the planted
+    letters.  Same values as slamem_amd.synth.plant_repeats."""
+    planted = C.c_uint64()
+    rc = capi.synth_lib().slamem_synth_plant_repeats(_ptr(ref), ref.numel(), seed, _stream_handle(ref.device), C.byref(planted))
+    if rc:
+        raise RuntimeError(f"synth kernel launch failed: hip error {rc}")
+    return int(planted.value)
 
 
 def synth_reads(ref: torch.Tensor, first: int, count: int, length: int = 150, sub: float = 0.02, seed: int = 42,

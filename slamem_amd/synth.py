@@ -74,6 +74,42 @@ def make_reads(ref: np.ndarray, first: int, count: int, length: int = 150, sub: 
     return np.ascontiguousarray(c)
 
 
+REPEAT_SALT = 0x7265706561747321
+
+
+def repeat_segments(n: int, seed: int = 42):
+    """Segments (k, length, src, dst) of the repeat model of SURVEY.md 8(d) -- see csrc/synth.hip: 0.5 % of the text
+    overwritten by copies of 1-10 kbp segments with 1 % substitutions, fully determined by (n, seed)."""
+    if n < 20000:
+        raise ValueError("repeat model needs n >= 20000")
+    segs, planted, k = [], 0, 0
+    sp = (seed + REPEAT_SALT) & 0xFFFFFFFFFFFFFFFF
+    while planted < n // 200:
+        d = splitmix64_at(sp, np.arange(3 * k, 3 * k + 3, dtype=np.uint64))
+        ln = 1000 + int(d[0] % np.uint64(9001))
+        src = int(d[1] % np.uint64(n - ln + 1))
+        dst = int(d[2] % np.uint64(n - ln + 1))
+        segs.append((k, ln, src, dst))
+        planted += ln
+        k += 1
+    return segs
+
+
+def plant_repeats(ref: np.ndarray, seed: int = 42) -> int:
+    """Apply the repeat model in place to a text made by make_reference(n, seed); returns the planted letters."""
+    n = ref.shape[0]
+    thr = np.uint64(int(0.01 * 4294967296.0))
+    sm = (seed + REPEAT_SALT + 1) & 0xFFFFFFFFFFFFFFFF
+    planted = 0
+    for k, ln, src, dst in repeat_segments(n, seed):
+        code = (splitmix64_at(seed, np.arange(src, src + ln, dtype=np.uint64)) & np.uint64(3)).astype(np.int64)
+        x = splitmix64_at(sm, np.uint64(k * 16384) + np.arange(ln, dtype=np.uint64))
+        alt = _ALT[code, ((x >> np.uint64(32)) % np.uint64(3)).astype(np.int64)]
+        ref[dst:dst + ln] = np.where((x & np.uint64(0xFFFFFFFF)) < thr, alt, _ACGT[code])
+        planted += ln
+    return planted
+
+
 def write_fasta_reference(path: str, ref: np.ndarray, name: str | None = None, width: int = 80) -> None:
     n = ref.shape[0]
     name = name or f"synthetic_ref_{n}"

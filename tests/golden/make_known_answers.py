@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Record known answers of the REAL reference (oracle/_ref/slaMEM, compiled from /root/reference by oracle/Makefile;
+build container only) for workloads too large for per-MEM fixtures: the answer is the digest of tools/mems_digest.py
+-- {mems, sum_len, max_len, sha256 over the sorted (strand block, ref, query, length) rows} -- stored under a case name
+in tests/golden/known_answers.json and asserted by the -m gpu tests on the same seeded inputs.
+
+    tests/golden/make_known_answers.py <case> [--keep]
+
+Cases (inputs: slamem_amd/synth.py generators, SURVEY.md Appendix C.2 + the repeat model of 8(d)):
+  config4_first1M   BASELINE.json configs[3]: 248 Mbp text WITH the repeat model, the first 1 M of the 150 bp reads
+                    (2 % substitutions, half reverse-complemented), -b -l 50
+  config1_pair      BASELINE.json configs[0]: a 4.64 Mbp genome against a 1.5 %-diverged strain with three
+                    inversions and two deletions (tests/golden_cases.py::ecoli_like_pair), -b -l 20
+
+Every MEM the reference prints is also checked here against the texts (real match, maximal on both sides) before the
+digest is recorded: the reference is known to print impossible MEMs on some texts with an LCP >= 255 (DESIGN.md 5,
+B.11); a case that trips this is recorded with "reference_valid": false and the tests pin it on the oracle instead.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+from slamem_amd import synth  # noqa: E402
+from mems_digest import digest_rows, parse  # noqa: E402
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "slaMEM")
+OUT_JSON = os.path.join(HERE, "known_answers.json")
+
+_COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGT", b"TGCA"):
+    _COMP[_a] = _b
+
+
+def check_rows_against_text(rows, ref, reads, strands):
+    """rows: (block, ref1, query1, len) as printed.  reads: (count, L) array or a list of 1-D arrays.  Returns the
+    number of rows that are not real two-sided-maximal matches."""
+    bad = 0
+    n = ref.shape[0]
+    cache = {}
+    for blk, r1, q1, ln in rows:
+        blk, r, q, ln = int(blk), int(r1) - 1, int(q1) - 1, int(ln)
+        k, rev = (blk // strands, blk % strands) if strands == 2 else (blk, 0)
+        key = (k, rev)
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            rd = np.asarray(reads[k])
+            cache[key] = _COMP[rd[::-1]] if rev else rd
+        rd = cache[key]
+        L = rd.shape[0]
+        ok = r >= 0 and q >= 0 and r + ln <= n and q + ln <= L and bool((ref[r:r + ln] == rd[q:q + ln]).all())
+        ok = ok and (r == 0 or q == 0 or ref[r - 1] != rd[q - 1])
+        ok = ok and (r + ln == n or q + ln == L or ref[r + ln] != rd[q + ln])
+        bad += not ok
+    return bad
+
+
+def run_reference(args, cwd):
+    t0 = time.time()
+    with open(os.path.join(cwd, "stdout.txt"), "wb") as so:
+        rc = subprocess.run([REF_BIN] + args, cwd=cwd, stdout=so).returncode
+    return rc, time.time() - t0
+
+
+def case_config4_first1M(tmp):
+    n, nreads, L, min_len = 248_000_000, 1_000_000, 150, 50
+    assert (n + 1) % 64 != 0
+    ref = synth.make_reference(n, 42)
+    planted = synth.plant_repeats(ref, 42)
+    synth.write_fasta_reference(os.path.join(tmp, "ref.fa"), ref)
+    reads = np.empty((nreads, L), dtype=np.uint8)
+    with open(os.path.join(tmp, "qry.fa"), "wb") as f:
+        step = 100_000
+        for first in range(0, nreads, step):
+            part = synth.make_reads(ref, first, step, L, 0.02, 42, 50)
+            reads[first:first + step] = part
+            f.write(b"".join(b">q%d\n" % (first + i) + part[i].tobytes() + b"\n" for i in range(step)))
+    rc, secs = run_reference(["-b", "-l", str(min_len), "-o", "out.txt", "ref.fa", "qry.fa"], tmp)
+    rows = parse(os.path.join(tmp, "out.txt"), True)
+    bad = check_rows_against_text(rows, ref, reads, 2)
+    d = digest_rows(rows)
+    d.update({"reference_rc": rc, "reference_seconds": round(secs, 1), "reference_valid": bad == 0, "invalid_rows": bad,
+              "workload": f"n={n} seed 42 + repeat model ({planted} planted letters), reads 0..{nreads - 1} of 150 bp, "
+                          f"2% substitutions, 50% reverse-complemented, -b -l {min_len}"})
+    return d
+
+
+def case_config1_pair(tmp):
+    from golden_cases import ecoli_like_pair
+    ref, qry = ecoli_like_pair()
+    synth.write_fasta_reference(os.path.join(tmp, "ref.fa"), ref, "ecoli_like_ref")
+    synth.write_fasta_reference(os.path.join(tmp, "qry.fa"), qry, "ecoli_like_strain")
+    rc, secs = run_reference(["-b", "-l", "20", "-o", "out.txt", "ref.fa", "qry.fa"], tmp)
+    import hashlib
+    data = open(os.path.join(tmp, "out.txt"), "rb").read()
+    rows = []
+    blk = -1
+    for line in data.split(b"\n"):
+        if line[:1] == b">":
+            blk += 1
+        elif line:
+            a, b, c = line.split(b"\t")
+            rows.append((blk, int(a), int(b), int(c)))
+    rows = np.array(rows, dtype=np.uint32)
+    bad = check_rows_against_text(rows, ref, [qry], 2)
+    d = digest_rows(rows)
+    d.update({"file_bytes": len(data), "file_sha256": hashlib.sha256(data).hexdigest(), "reference_rc": rc,
+              "reference_seconds": round(secs, 1), "reference_valid": bad == 0, "invalid_rows": bad,
+              "workload": f"ecoli_like_pair(): {ref.shape[0]} bp genome vs {qry.shape[0]} bp strain, -b -l 20"})
+    return d
+
+
+CASES = {"config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair}
+
+
+def main():
+    case = sys.argv[1]
+    tmp = os.path.join("/tmp", "known_answers", case)
+    os.makedirs(tmp, exist_ok=True)
+    d = CASES[case](tmp)
+    known = json.load(open(OUT_JSON)) if os.path.exists(OUT_JSON) else {}
+    known[case] = d
+    with open(OUT_JSON, "w") as f:
+        json.dump(known, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print(json.dumps(d))
+    if "--keep" not in sys.argv:
+        for fn in ("ref.fa", "qry.fa", "out.txt"):
+            try:
+                os.remove(os.path.join(tmp, fn))
+            except OSError:
+                pass
+
+
+if __name__ == "__main__":
+    main()

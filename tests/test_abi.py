@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"libslamem_hip.so does not export {n}"
     assert set(names) == set(capi.ABI_SYMBOLS)
-    assert L.slamem_abi_version() == 1
+    assert L.slamem_abi_version() == 2
     assert L.slamem_strerror(0) == b"ok"
 
 
@@ -64,3 +64,60 @@ def test_rccl_companion_library_exports_replicate():
     assert " T slamem_index_replicate" in syms
     text = open(os.path.join(ROOT, "include", "slamem_rccl.h")).read()
     assert "slamem_index_replicate" in text
+
+
+def _arena_header(n=100_000, num_n=3, with_filter=True):
+    """A consistent arena header, laid out as slamem_amd/csrc/common.h::ArenaHeader does (host-side mirror for the test)."""
+    import struct
+    R = n + 1
+    al = lambda x: (x + 255) // 256 * 256
+    nblocks = (R + 1 + 127) >> 7
+    off = 4096
+    off_fm = off; off = al(off + nblocks * 64)
+    off_rec = off; off = al(off + (R + 1) * 16)
+    off_sa = off; off = al(off + R * 4)
+    off_nrows = off; off = al(off + max(num_n, 1) * 4)
+    lg, k = 17, 13
+    off_kf = off if with_filter else 0
+    if with_filter:
+        off = al(off + (8 << lg))
+    fields = dict(magic_lo=0x4D414C53, magic_hi=0x58494845, version=7, n=n, total_bytes=off, off_fm=off_fm, off_rec=off_rec,
+                  off_sa=off_sa, off_nrows=off_nrows, off_kfilter=off_kf, r0=0, r1=0, r2=0, kfilter_log2=lg if with_filter else 0,
+                  kfilter_k=k if with_filter else 0, nblocks=nblocks, dollar_row=17, num_n=num_n, max_lcp=20, sort_rounds=1)
+    order = ["magic_lo", "magic_hi", "version", "n", "total_bytes", "off_fm", "off_rec", "off_sa", "off_nrows", "off_kfilter",
+             "r0", "r1", "r2", "kfilter_log2", "kfilter_k", "nblocks", "dollar_row", "num_n", "max_lcp", "sort_rounds"]
+    fmt = "<4I9Q7I"
+    def pack(**over):
+        f = dict(fields); f.update(over)
+        return struct.pack(fmt, *[f[k] for k in order]) + b"\0" * (4096 - struct.calcsize(fmt))
+    return fields, pack
+
+
+def test_header_validation_rejects_corrupt_arenas(tmp_path):
+    """every section offset / size the kernels index is checked on the host; a truncated, stale or corrupted
+    index is SLAMEM_ERR_FORMAT before any device call (so this runs without a GPU)."""
+    from slamem_amd import capi
+    L = capi.lib()
+    ERR_FORMAT = 5
+    f, pack = _arena_header()
+    good = pack()
+    assert L.slamem_index_validate_header(good, len(good), f["total_bytes"]) == 0
+    f2, pack2 = _arena_header(with_filter=False)
+    assert L.slamem_index_validate_header(pack2(), 4096, f2["total_bytes"]) == 0
+    assert L.slamem_index_validate_header(good, len(good), f["total_bytes"] - 1) == ERR_FORMAT       # truncated file
+    bad = [dict(magic_lo=1), dict(version=6), dict(n=0), dict(nblocks=f["nblocks"] - 1), dict(nblocks=f["nblocks"] + 1),
+           dict(off_fm=8192), dict(off_rec=f["off_rec"] + 64), dict(off_rec=f["off_fm"]), dict(off_sa=f["total_bytes"]),
+           dict(off_sa=f["off_rec"] + 256), dict(off_nrows=f["off_sa"]), dict(off_kfilter=f["total_bytes"] - 256),
+           dict(kfilter_log2=48), dict(kfilter_log2=f["kfilter_log2"] + 1), dict(kfilter_k=40), dict(num_n=f["n"] + 1),
+           dict(num_n=1 << 24), dict(dollar_row=f["n"] + 1), dict(total_bytes=f["total_bytes"] - 256),
+           dict(total_bytes=100), dict(n=f["n"] + 4096)]
+    for over in bad:
+        assert L.slamem_index_validate_header(pack(**over), 4096, f["total_bytes"]) == ERR_FORMAT, over
+    # through slamem_index_load: format errors come before the device check, so they are the same on any machine
+    import ctypes as C
+    p = tmp_path / "bad.idx"
+    p.write_bytes(pack(off_sa=f["off_rec"] + 256) + b"\0" * 4096)
+    h = C.c_void_p()
+    assert L.slamem_index_load(str(p).encode(), 0, C.byref(h)) == ERR_FORMAT and not h.value
+    p.write_bytes(good)  # header fine, file far shorter than total_bytes
+    assert L.slamem_index_load(str(p).encode(), 0, C.byref(h)) == ERR_FORMAT and not h.value
