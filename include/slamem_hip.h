@@ -75,13 +75,14 @@ typedef struct {
     float build_bwt_ms;       /* K3 BWT planes + rank samples                     */
     float build_lcp_ms;       /* K5 exact LCP                                     */
     float build_links_ms;     /* K7 PSV / NSV                                     */
-    float search_kernel_ms;   /* K8 the MEM search kernel alone                   */
+    float search_kernel_ms;   /* K8a + K8: prefilter, work-list compaction, search */
     float search_total_ms;    /* K8 + scan + K9 scatter                           */
     uint64_t search_launches; /* number of K8 launches accumulated since reset    */
     double search_kernel_ms_sum;
     float prefilter_ms;       /* K8a (work-item fill + presence prefilter), part of search_kernel_ms */
-    float reserved0;
+    float k8_ms;              /* K8 k_find_mems_v3 alone, part of search_kernel_ms */
     double prefilter_ms_sum;
+    double k8_ms_sum;
 } slamem_timings;
 
 /* Load counters of ONE diagnostic search launch (slamem_search_stats_enable): how many loads of each kind the lanes of

@@ -62,10 +62,11 @@ class Timings(C.Structure):
                 ("build_bwt_ms", C.c_float), ("build_lcp_ms", C.c_float), ("build_links_ms", C.c_float),
                 ("search_kernel_ms", C.c_float), ("search_total_ms", C.c_float),
                 ("search_launches", C.c_uint64), ("search_kernel_ms_sum", C.c_double),
-                ("prefilter_ms", C.c_float), ("reserved0", C.c_float), ("prefilter_ms_sum", C.c_double)]
+                ("prefilter_ms", C.c_float), ("k8_ms", C.c_float), ("prefilter_ms_sum", C.c_double),
+                ("k8_ms_sum", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class SearchStats(C.Structure):
@@ -160,6 +161,8 @@ def synth_lib():
         S.slamem_synth_reference.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         S.slamem_synth_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
                                          C.c_double, C.c_uint64, C.c_uint32, C.c_void_p]
+        S.slamem_gather_modes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        S.slamem_gather_bench.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         S.slamem_synth_plant_repeats.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
         _SYNTH = S
     return _SYNTH

@@ -1112,7 +1112,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
 
     Timings& tm = thread_timings();
     const bool want_stats = search_stats_wanted();
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, ep = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, ep = nullptr, ek = nullptr;
     int rc = SLAMEM_OK;
     do {
         hipError_t e;
@@ -1121,6 +1121,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         STEP(hipEventCreate(&e1), "hipEventCreate");
         STEP(hipEventCreate(&e2), "hipEventCreate");
         STEP(hipEventCreate(&ep), "hipEventCreate");
+        STEP(hipEventCreate(&ek), "hipEventCreate");
         STEP(hipMemsetAsync(d_total, 0, 64 + SC_COUNT * 8, stream), "memset");
         // ---- work items: one per strand, long records cut into slices (v1 scans whole strands) ----------------
         uint64_t nitems = num_blocks;
@@ -1162,7 +1163,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             if (e2 && atoi(e2) > 0) A.chunk = (uint32_t)atoi(e2);
             if (A.chunk > kChunkMax) A.chunk = kChunkMax;
         }
-        bool prefiltered = false;
+        bool prefiltered = false, timed_k8 = false;
         (void)hipEventRecord(e0, stream);
         if (nitems && kernel_version == 3) {
             hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first,
@@ -1188,6 +1189,8 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                 A.work_count = d_nwork;
             }
             uint64_t waves = (nitems + A.chunk - 1) / A.chunk;
+            (void)hipEventRecord(ek, stream);
+            timed_k8 = true;
             if (want_stats) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             else hipLaunchKernelGGL(k_find_mems_v3<false>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             STEP(hipGetLastError(), "k_find_mems_v3");
@@ -1266,9 +1269,13 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             tm.t.search_kernel_ms_sum += ms;
             tm.t.search_launches++;
         }
-        if (prefiltered && hipEventElapsedTime(&ms, e0, ep) == hipSuccess) {  // item fill + K8a (K8 = the rest up to e1)
+        if (prefiltered && hipEventElapsedTime(&ms, e0, ep) == hipSuccess) {  // work-item fill + K8a
             tm.t.prefilter_ms = ms;
             tm.t.prefilter_ms_sum += ms;
+        }
+        if (timed_k8 && hipEventElapsedTime(&ms, ek, e1) == hipSuccess) {    // K8 alone
+            tm.t.k8_ms = ms;
+            tm.t.k8_ms_sum += ms;
         }
         if (hipEventElapsedTime(&ms, e0, e2) == hipSuccess) tm.t.search_total_ms = ms;
     } while (0);
@@ -1276,6 +1283,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     if (e1) (void)hipEventDestroy(e1);
     if (e2) (void)hipEventDestroy(e2);
     if (ep) (void)hipEventDestroy(ep);
+    if (ek) (void)hipEventDestroy(ek);
     return rc;
 }
 

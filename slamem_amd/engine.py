@@ -95,6 +95,21 @@ class Index:
         capi.check(capi.lib().slamem_index_export(self._h, _ptr(out), out.numel(), _stream_handle(self.device)))
         return out
 
+    def arena_view(self) -> torch.Tensor:
+        """Zero-copy uint8 tensor over the index arena (slamem_index_arena): what rank 0 hands to the broadcast, so the
+        index is never held twice.  Valid while this Index is alive."""
+        ptr, nbytes = C.c_void_p(), C.c_uint64()
+        capi.check(capi.lib().slamem_index_arena(self._h, C.byref(ptr), C.byref(nbytes)))
+
+        class _Arena:  # the CUDA array interface torch.as_tensor understands (HIP pointers on ROCm builds)
+            __cuda_array_interface__ = {"shape": (int(nbytes.value),), "typestr": "|u1", "data": (int(ptr.value), False),
+                                        "version": 2, "strides": None}
+        holder = _Arena()
+        t = torch.as_tensor(holder, device=self.device)
+        assert t.data_ptr() == ptr.value and t.numel() == nbytes.value, "arena view must alias the arena"
+        t._slamem_keepalive = (holder, self)
+        return t
+
     def close(self) -> None:
         h, self._h = self._h, None
         if h:
@@ -261,6 +276,30 @@ def search_stats(matcher: "Matcher", queries_dev: torch.Tensor, offsets_dev: tor
     st = capi.SearchStats()
     capi.check(L.slamem_get_search_stats(C.byref(st)))
     return st.as_dict()
+
+
+def random_line_ceiling(index: "Index", lanes: int = 256 * 32 * 64 * 4, iters: int = 64) -> float:
+    """Dependent random 64-byte-line gathers per second over THIS index arena (read-only), measured in a few ms: every
+    lane walks a chain of random lines of the arena, one 16-byte access per line (csrc/synth.hip::k_gather_modes, mode
+    0).  The search kernel's request rate is read against this ceiling."""
+    dev = index.device
+    S = capi.synth_lib()
+    arena = index.arena_view()
+    nblk = arena.numel() // 64
+    sink = torch.zeros(8, dtype=torch.int64, device=dev)
+    st = _stream_handle(dev)
+    best = 0.0
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = S.slamem_gather_modes(arena.data_ptr(), nblk, lanes, iters if rep else 4, 0, sink.data_ptr(), st)
+        e1.record()
+        if rc:
+            raise RuntimeError(f"gather probe launch failed: hip error {rc}")
+        torch.cuda.synchronize(dev)
+        if rep:
+            best = max(best, lanes * iters / (e0.elapsed_time(e1) * 1e-3))
+    return best
 
 
 # ---- bench / test support: synthetic inputs generated on the GPU (csrc/synth.hip) ----------------------

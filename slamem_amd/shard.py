@@ -18,6 +18,9 @@ import torch
 import torch.distributed as dist
 
 
+BROADCAST_PIECE = 1 << 30
+
+
 def world() -> tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -55,7 +58,11 @@ def broadcast_arena(arena: torch.Tensor | None, device, src: int = 0, force: boo
     dist.broadcast(size, src)
     if rank != src:
         arena = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
-    dist.broadcast(arena, src)
+    # one logical broadcast, issued in pieces of at most 1 GiB: the arena is 3 GB at 100 Mbp and 98 GB at 3.1 Gbp, more
+    # elements than some collective front ends count in 32 bits; xGMI moves a GiB per call at full link rate
+    total = arena.numel()
+    for off in range(0, total, BROADCAST_PIECE):
+        dist.broadcast(arena[off:min(total, off + BROADCAST_PIECE)], src)
     return arena
 
 

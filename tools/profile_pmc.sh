@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 run() { # name counters...
   local name=$1; shift
-  timeout -k 10 280 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $EXTRA > $OUT/$name.log 2>&1 || echo "pass $name failed"
+  timeout -k 10 280 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stats --no-host-leg $EXTRA > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 EXTRA="$@"
 run sq    SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
