@@ -22,7 +22,7 @@ With N > 1 the line also carries the other mode's rate, measured in the same pro
 Rank 0 prints ONE JSON line.
   roofline      the dominant kernel (K8 k_find_mems_v3): `traffic` = bytes the kernel's lanes asked HBM for, counted by
                 the kernel's diagnostic instantiation on the same batch in this run (64 B per FM-block / row-record
-                line, 32 B per query window); `achieved` = traffic / K8's mean duration (HIP events on its stream);
+                line, 16 B per packed query window); `achieved` = traffic / K8's mean duration (HIP events on its stream);
                 `frac` = achieved / 8 TB/s.  `request_rate_frac` = lines/s over a dependent-random-line ceiling measured
                 in this process on this index arena.  The SURVEY 8(d) reference-work formula is kept as
                 `reference_work_GBps` (it charges the reference's work, not what this engine moves).
@@ -313,10 +313,14 @@ def main():
         st = engine.search_stats(matcher, reads, offsets, a.min_len) if not a.no_stats else None
         if st is None:
             st = {k: 0 for k in ("fm_lines_top", "fm_lines_bottom", "rec_lines_fail", "rec_lines_pend", "rec_lines_flush",
-                                 "query_loads", "prefilter_probes", "prefilter_query_loads", "lane_trips", "wave_trips")}
+                                 "query_loads", "prefilter_probes", "prefilter_query_loads", "lane_trips", "wave_trips",
+                                 "dir_sa_lines", "dir_group_loads", "dir_rec_lines")}
         k8_lines = (st["fm_lines_top"] + st["fm_lines_bottom"] + st["rec_lines_fail"] + st["rec_lines_pend"]
-                    + st["rec_lines_flush"])
-        k8_bytes = 64 * k8_lines + 32 * st["query_loads"]
+                    + st["rec_lines_flush"] + st.get("dir_sa_lines", 0) + st.get("dir_group_loads", 0)
+                    + st.get("dir_rec_lines", 0))
+        # 64 B per random line; the packed query windows (16 B, 32 letters) and the 16 B of query beside a text group are
+        # sequential within a strand's 80 bytes
+        k8_bytes = 64 * k8_lines + 16 * (st["query_loads"] + st.get("dir_group_loads", 0))
         k8a_bytes = 64 * st["prefilter_probes"] + 16 * st["prefilter_query_loads"]
         k8_s = r["k8_ms"] * 1e-3
         ceiling = engine.random_line_ceiling(index) if hasattr(engine, "random_line_ceiling") else None

@@ -108,7 +108,11 @@ typedef struct {
     uint64_t mems;                  /* MEMs found                                                                      */
     uint64_t overflow_records;      /* MEMs that went through the atomic overflow list                                 */
     uint64_t valid;                 /* 1 when the counters describe a launch                                           */
-    uint64_t reserved[6];
+    uint64_t dir_sa_lines;          /* K8 direct extension: suffix-array lines (one per run)                           */
+    uint64_t dir_group_loads;       /* K8 direct extension: text groups (16 letters + classes, 16 B) with 16 B of query */
+    uint64_t dir_rec_lines;         /* K8 direct extension: text-ordered records (one per run)                         */
+    uint64_t dir_letters;           /* K8 direct extension: query positions consumed by comparing with the text        */
+    uint64_t reserved[2];
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

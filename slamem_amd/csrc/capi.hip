@@ -86,6 +86,10 @@ static int header_ok(const ArenaHeader& h, uint64_t bytes) {
         if (!bad && (h.kfilter_log2 < 10 || h.kfilter_log2 > 40 || h.kfilter_k < 4 || h.kfilter_k > 31)) bad = "presence filter parameters";
         if (!bad) section(h.off_kfilter, 8ull << h.kfilter_log2, "presence filter");
     }
+    if (h.off_tgrp || h.off_prec) {
+        section(h.off_tgrp, ((R >> 4) + 2) * sizeof(TextGroup), "text groups");
+        section(h.off_prec, R * sizeof(TextRec), "text-ordered records");
+    }
     if (!bad && h.dollar_row > h.n) bad = "'$' row";
     if (bad) {
         set_error("index arena is corrupt or truncated: bad %s", bad);

@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 7;  // 7: pair row records + separate SA; 6: three k-mer lengths in the presence filter
+constexpr uint32_t kArenaVersion = 8;  // 8: text-ordered groups + parent records (direct extension); 7: pair row records + separate SA
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -46,6 +46,30 @@ struct __attribute__((aligned(16))) RowRec {
 };
 static_assert(sizeof(RowRec) == 16, "row record must be 16 bytes");
 
+// Text-ordered sections (no reference counterpart): what lets K8 extend a match that has become ONE row -- i.e. one text
+// position r = SA[row] -- by comparing the query with the text itself, 16 letters per trip from sequential memory,
+// instead of one random FM-block line per letter (the reference walks these letters one FMI_FollowLetter at a time,
+// slamem.c:121).
+//   TextGroup g: letters of text positions 16g .. 16g+15 as 4-bit ids (first letter in the top nibble, as K1 packs
+//                them), and for each of them the CLASS of the parent depth of the position to its right:
+//                cls nibble of position s = depth_class(pd[s+1]), pd[x] = max(LCP[ISA[x]], LCP[ISA[x]+1]) = depth of the
+//                parent of the single-row interval of the suffix starting at x (lcparray.c:514-518).  While the letters
+//                agree nothing can be emitted unless that parent is >= min_len deep, which the class tells (conservatively)
+//                without touching the row records.
+//   TextRec s:   row = ISA[s] and the parent interval of [row,row] with its depth + 1 -- where a direct run ends, ONE
+//                16-byte read gives back the row and (when it ended on a disagreeing letter) the widened interval to retry
+//                the letter on, instead of ISA, FM block and row record one after the other.
+struct __attribute__((aligned(16))) TextGroup { uint64_t letters, classes; };
+struct __attribute__((aligned(16))) TextRec { uint32_t row, ptop, pbot, pdepth1; };
+static_assert(sizeof(TextGroup) == 16 && sizeof(TextRec) == 16, "text-ordered records are 16 bytes");
+// parent-depth classes: class c = parent depth in [kDepthClass[c], kDepthClass[c+1]);  -1 (root) is class 0
+__host__ __device__ inline uint32_t depth_class(int d) {
+    const int t[16] = {0, 8, 10, 12, 14, 16, 18, 20, 25, 30, 40, 50, 75, 100, 150, 255};
+    uint32_t c = 0;
+    for (int k = 1; k < 16; k++) c += d >= t[k];
+    return c;
+}
+
 // Arena header (first 4 KiB of the index arena; also the on-disk header).
 struct ArenaHeader {
     uint32_t magic_lo, magic_hi;
@@ -57,7 +81,9 @@ struct ArenaHeader {
     uint64_t off_sa;      // uint32[n+1]    suffix array
     uint64_t off_nrows;   // uint32[num_n]  sorted BWT rows holding N
     uint64_t off_kfilter; // uint64[1 << kfilter_log2]  k-mer presence filter (0 = absent)
-    uint64_t reserved_off[3];
+    uint64_t off_tgrp;    // TextGroup[(n >> 4) + 2]  text-ordered: 16 letters + 16 parent-depth classes per 16 bytes
+    uint64_t off_prec;    // TextRec[n+1]             text-ordered: row and parent interval of the suffix at each position
+    uint64_t reserved_off;
     uint32_t kfilter_log2;
     uint32_t kfilter_k;
     uint32_t nblocks;
@@ -77,6 +103,8 @@ struct IndexView {
     const uint32_t* sa;
     const uint32_t* nrows;
     const uint64_t* kfilter;  // nullptr when the index has no presence filter
+    const TextGroup* tgrp;    // nullptr when the index has no text-ordered sections
+    const TextRec* prec;
     uint32_t n;
     uint32_t nblocks;
     uint32_t dollar_row;

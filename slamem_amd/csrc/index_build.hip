@@ -377,6 +377,41 @@ __global__ void k_lcp_sentinels(uint32_t rows, uint32_t* l32, uint32_t* psv, uin
     }
 }
 
+// text-ordered records (TextRec) and the parent-depth class of every text position (one byte each, packed into the
+// groups by k_text_groups): one random 16-byte read of the row's record per position
+__global__ void __launch_bounds__(256) k_text_records(const uint32_t* __restrict__ isa, const RowRec* __restrict__ rec,
+                                                      uint32_t rows, TextRec* __restrict__ out, uint8_t* __restrict__ cls) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= rows) return;
+    uint32_t row = isa[s];
+    RowRec r = rec[row];
+    uint32_t d1 = r.lcp1 > r.lcp1n ? r.lcp1 : r.lcp1n;  // depth + 1 of the parent of [row,row]  (lcparray.c:514-518)
+    TextRec t;
+    t.row = row;
+    t.ptop = r.lcp1 == d1 ? r.psv : row;
+    t.pbot = r.lcp1n == d1 ? r.nsvn - 1u : row;
+    t.pdepth1 = d1;
+    out[s] = t;
+    cls[s] = (uint8_t)depth_class((int)d1 - 1);
+}
+
+// TextGroup g = the packed letters of positions 16g..16g+15 (K1's word) + the classes of positions 16g+1..16g+16
+__global__ void __launch_bounds__(256) k_text_groups(const uint64_t* __restrict__ pk, const uint8_t* __restrict__ cls,
+                                                     uint32_t rows, uint64_t ngroups, TextGroup* __restrict__ out) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    uint64_t c = 0;
+    for (uint32_t i = 0; i < 16; i++) {
+        uint64_t x = g * 16 + i + 1;  // the position to the right of letter 16g+i
+        uint64_t v = x < rows ? (uint64_t)cls[x] : 15ull;  // past the text: "stop"
+        c |= v << (60u - 4u * i);
+    }
+    TextGroup t;
+    t.letters = pk[g];
+    t.classes = c;
+    out[g] = t;
+}
+
 // the 16-byte row records: record i describes the boundaries of row i: {LCP[i]+1, PSV[i], LCP[i+1]+1, NSV[i+1]}
 __global__ void __launch_bounds__(256) k_pack_records(const uint32_t* __restrict__ l32, const uint32_t* __restrict__ psv,
                                                       const uint32_t* __restrict__ nsv, uint32_t rows,
@@ -555,6 +590,8 @@ void make_view(slamem_index* idx) {
     idx->view.sa = reinterpret_cast<const uint32_t*>(base + h.off_sa);
     idx->view.nrows = reinterpret_cast<const uint32_t*>(base + h.off_nrows);
     idx->view.kfilter = h.off_kfilter ? reinterpret_cast<const uint64_t*>(base + h.off_kfilter) : nullptr;
+    idx->view.tgrp = h.off_tgrp ? reinterpret_cast<const TextGroup*>(base + h.off_tgrp) : nullptr;
+    idx->view.prec = h.off_tgrp ? reinterpret_cast<const TextRec*>(base + h.off_prec) : nullptr;
     idx->view.kfilter_log2 = h.kfilter_log2;
     idx->view.kfilter_k = h.kfilter_k;
     idx->view.n = h.n;
@@ -648,6 +685,14 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
             off = align_up(off + (8ull << lg), 256);
         }
     }
+    const uint64_t ngroups = (R >> 4) + 2;
+    {   // text-ordered sections for the direct extension of unique matches (K8); SLAMEM_TEXT_SECTIONS=0 builds without
+        const char* de = getenv("SLAMEM_TEXT_SECTIONS");
+        if (!(de && atoi(de) == 0)) {
+            hdr.off_tgrp = off; off = align_up(off + ngroups * sizeof(TextGroup), 256);
+            hdr.off_prec = off; off = align_up(off + R * sizeof(TextRec), 256);
+        }
+    }
     hdr.total_bytes = off;
 
     // ---- memory plan -------------------------------------------------------------------------------------------
@@ -663,8 +708,9 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
     char* base = arena.as<char>();
     struct Region { char* p; uint64_t left; };
-    Region lend[2] = {{base + hdr.off_rec, (R + 1) * sizeof(RowRec)},
-                      {hdr.off_kfilter ? base + hdr.off_kfilter : nullptr, hdr.off_kfilter ? (8ull << hdr.kfilter_log2) : 0ull}};
+    Region lend[3] = {{base + hdr.off_rec, (R + 1) * sizeof(RowRec)},
+                      {hdr.off_kfilter ? base + hdr.off_kfilter : nullptr, hdr.off_kfilter ? (8ull << hdr.kfilter_log2) : 0ull},
+                      {hdr.off_prec ? base + hdr.off_prec : nullptr, hdr.off_prec ? R * sizeof(TextRec) : 0ull}};
     auto borrow = [&](DevBuf& b, uint64_t bytes) -> hipError_t {  // from the arena if it fits, else an own allocation
         bytes = align_up(bytes, 16);
         for (Region& r : lend)
@@ -868,6 +914,14 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
     hipLaunchKernelGGL(k_pack_records, dim3(grid_for(R + 1)), dim3(256), 0, stream, d_l32, d_psv, d_nsv, rows, d_rec);
     SLAMEM_HIP(hipGetLastError());
+    if (hdr.off_tgrp) {  // text-ordered sections, last: their regions were lent to the sort, the records are complete now
+        uint8_t* d_cls = flagB.as<uint8_t>();  // one byte per text position (scratch of the sort rounds, dead since K2)
+        hipLaunchKernelGGL(k_text_records, dim3(grid_for(R)), dim3(256), 0, stream, rank.as<uint32_t>(), d_rec, rows,
+                           reinterpret_cast<TextRec*>(base + hdr.off_prec), d_cls);
+        hipLaunchKernelGGL(k_text_groups, dim3(grid_for(ngroups)), dim3(256), 0, stream, pk.as<uint64_t>(), d_cls, rows, ngroups,
+                           reinterpret_cast<TextGroup*>(base + hdr.off_tgrp));
+        SLAMEM_HIP(hipGetLastError());
+    }
     SLAMEM_HIP(hipEventRecord(ev.b, stream));
     SLAMEM_HIP(hipMemcpyAsync(h_scal, d_scal, sizeof(h_scal), hipMemcpyDeviceToHost, stream));
     SLAMEM_HIP(hipStreamSynchronize(stream));

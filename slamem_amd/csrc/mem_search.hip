@@ -158,7 +158,7 @@ struct SearchArgs {
     uint32_t num_queries;
     uint32_t strands;          // 1 or 2
     uint32_t min_len;
-    int32_t spec_depth;        // v3: at or below this match length the parent records are fetched with the FM blocks
+    int32_t spec_depth;        // (unused)
     uint32_t chunk;            // v3: work items owned by one wave
     uint32_t pad;
     uint64_t capacity;         // raw records that fit
@@ -175,12 +175,19 @@ struct SearchArgs {
     const uint32_t* work_count; // v3: device word holding their number
     unsigned long long* stats;  // diagnostic instantiations only: SC_COUNT counters
     uint64_t query_words;       // v3: 8-byte words of the query buffer that may be read
+    const uint64_t* pq;         // v3: the strands as packed letter ids (k_pack_queries), two zero words in front
+    uint64_t* pq_out;           //     (the same buffer, written by k_pack_queries)
+    const uint64_t* item_pk;    // v3: per work item, the word offset of its strand block in pq
+    unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
+    int32_t direct_min_depth;   // v3: a single-row match at least this deep is extended by comparing with the text (<0: off)
+    uint32_t pad3;
 };
 
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
 struct RawRow { uint32_t row, pos, len; };
 constexpr uint32_t kInlineMems = 4;     // MEMs per work item stored in place; more go to the overflow list
-constexpr uint32_t kChunkMax = 128;     // work items per wave (bounds the LDS copy of their descriptors)
+constexpr uint32_t kChunkMax = 128;     // (v1 kernels) work items per wave
+constexpr uint32_t kFetch = 64;         // v3: work items a wave takes from the global cursor at a time
 
 // Work item of K8 v3 = one strand of one query record, or -- for long records (genome against genome) -- one
 // slice of kSliceLen positions of it.  A slice [a,b) is scanned from e = b + warm-up: a scan that starts at e
@@ -523,13 +530,13 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
     return k;
 }
 
-enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2 };
 
 // Counters of a diagnostic launch (template parameter kStats; the timed kernels are the kStats = false instantiations,
 // which carry none of this): how many loads of each kind the lanes issue.  One 64-bit word each, at SearchArgs::stats.
 enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
-    SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS, SC_COUNT
+    SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
+    SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -539,43 +546,147 @@ __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) 
     if ((threadIdx.x & 63u) == 0u && v) atomicAdd(dst, (unsigned long long)v);
 }
 
+// K7q: the strands of the batch as 4-bit letter ids in SCAN coordinates -- position p of the forward strand is letter p
+// of the record, position p of the reverse strand is the complement of letter len-1-p (ReverseComplementSequence,
+// sequence.c:413-430, done once here instead of per letter in the scan) -- 16 letters per 64-bit word, first letter in
+// the top nibble (the layout of the packed text, so that a query window and a text group compare with one XOR).  Every
+// strand block starts on a 16-byte boundary.  16 lanes per work item, one word each per step; ASCII -> id through a
+// 256-byte table in LDS.
+__global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A) {
+    __shared__ uint8_t lut[512];  // [0,256): id; [256,512): id of the complement
+    for (uint32_t i = threadIdx.x; i < 256u; i += 256u) {
+        uint32_t c = ascii_code_q(i);
+        lut[i] = (uint8_t)c;
+        lut[256u + i] = (uint8_t)(c >= 2u ? 7u - c : c);  // A<->T, C<->G; N stays N  (sequence.c:419-426)
+    }
+    __syncthreads();
+    const uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t sub = threadIdx.x & 15u;
+    if (item >= A.num_items) return;
+    const ItemDesc d = A.items[item];
+    // strands the prefilter proved empty are never scanned -- but every slice of a long record is packed: a neighbouring
+    // slice's scan starts in it (warm-up)
+    if (A.item_alive && d.len <= kSliceLen && !A.item_alive[item]) return;
+    const uint32_t rev = d.slice_rev >> 31, sl = d.slice_rev & 0x7FFFFFFFu;
+    const uint32_t a = sl * kSliceLen;
+    const uint32_t b = d.len - a < kSliceLen ? d.len : a + kSliceLen;
+    uint64_t* out = A.pq_out + A.item_pk[item];
+    const uint32_t w0 = a >> 4;
+    // the last slice also writes the zero padding up to the strand's 16-byte-aligned end
+    const uint32_t w1 = b == d.len ? 2u * ((d.len + 31u) >> 5) : (b >> 4);
+    const uint8_t* q = reinterpret_cast<const uint8_t*>(A.qwords);
+    const uint8_t* tab = lut + (rev ? 256u : 0u);
+    for (uint32_t w = w0 + sub; w < w1; w += 16u) {
+        uint32_t whi = 0, wlo = 0;  // the word's two halves: letters 0..7 and 8..15
+        const uint32_t p0 = w * 16u;
+        if (p0 < d.len) {
+            const uint32_t cnt = d.len - p0 < 16u ? d.len - p0 : 16u;
+            // bytes of strand positions p0 .. p0+cnt-1: ascending addresses (forward) or descending (reverse)
+            const uint64_t first = rev ? d.base + (uint64_t)(d.len - p0 - cnt) : d.base + p0;  // lowest address read
+            const uint64_t al = first & ~7ull;
+            const uint32_t sh = (uint32_t)(first - al) * 8u;
+            const uint64_t* src = reinterpret_cast<const uint64_t*>(q + al);
+            const uint64_t last = first + cnt - 1u;  // highest address read
+            uint64_t x0 = src[0], x1 = (al + 8u <= last) ? src[1] : 0ull, x2 = (al + 16u <= last) ? src[2] : 0ull;
+            uint64_t lo = sh ? (x0 >> sh) | (x1 << (64u - sh)) : x0;   // bytes first .. first+7
+            uint64_t hi = sh ? (x1 >> sh) | (x2 << (64u - sh)) : x1;   // bytes first+8 .. first+15
+            const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32), d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
+            if (cnt == 16u) {  // full word: constant shifts
+#define SLAMEM_ID(dw, k) ((uint32_t)tab[((dw) >> (8 * (k))) & 0xFFu])
+                if (!rev) {
+                    whi = SLAMEM_ID(d0, 0) << 28 | SLAMEM_ID(d0, 1) << 24 | SLAMEM_ID(d0, 2) << 20 | SLAMEM_ID(d0, 3) << 16 |
+                          SLAMEM_ID(d1, 0) << 12 | SLAMEM_ID(d1, 1) << 8 | SLAMEM_ID(d1, 2) << 4 | SLAMEM_ID(d1, 3);
+                    wlo = SLAMEM_ID(d2, 0) << 28 | SLAMEM_ID(d2, 1) << 24 | SLAMEM_ID(d2, 2) << 20 | SLAMEM_ID(d2, 3) << 16 |
+                          SLAMEM_ID(d3, 0) << 12 | SLAMEM_ID(d3, 1) << 8 | SLAMEM_ID(d3, 2) << 4 | SLAMEM_ID(d3, 3);
+                } else {  // strand position i is byte 15-i
+                    whi = SLAMEM_ID(d3, 3) << 28 | SLAMEM_ID(d3, 2) << 24 | SLAMEM_ID(d3, 1) << 20 | SLAMEM_ID(d3, 0) << 16 |
+                          SLAMEM_ID(d2, 3) << 12 | SLAMEM_ID(d2, 2) << 8 | SLAMEM_ID(d2, 1) << 4 | SLAMEM_ID(d2, 0);
+                    wlo = SLAMEM_ID(d1, 3) << 28 | SLAMEM_ID(d1, 2) << 24 | SLAMEM_ID(d1, 1) << 20 | SLAMEM_ID(d1, 0) << 16 |
+                          SLAMEM_ID(d0, 3) << 12 | SLAMEM_ID(d0, 2) << 8 | SLAMEM_ID(d0, 1) << 4 | SLAMEM_ID(d0, 0);
+                }
+#undef SLAMEM_ID
+            } else {
+                for (uint32_t i = 0; i < cnt; i++) {
+                    uint32_t bi = rev ? cnt - 1u - i : i;  // byte index (from `first`) of strand position p0+i
+                    uint32_t dw = bi < 4u ? d0 : bi < 8u ? d1 : bi < 12u ? d2 : d3;
+                    uint32_t id = tab[(dw >> (8u * (bi & 3u))) & 0xFFu];
+                    if (i < 8u) whi |= id << (28u - 4u * i); else wlo |= id << (28u - 4u * (i - 8u));
+                }
+            }
+        }
+        out[w] = u64_of(wlo, whi);
+    }
+}
+
+// Letters of one strand from the packed copy (k_pack_queries): a window of 32 letters (one aligned 16-byte load) in
+// registers, 5 loads per strand of 150 letters.
+struct PackedCursor {
+    const uint4* p;   // the strand's first word (16-byte aligned)
+    uint32_t cidx;    // window held, ~0 = none
+    uint64_t q0, q1;
+    __device__ __forceinline__ void init(const uint64_t* base) { p = reinterpret_cast<const uint4*>(base); cidx = ~0u; q0 = q1 = 0; }
+    __device__ __forceinline__ void forget() { cidx = ~0u; }
+    __device__ __forceinline__ uint32_t would_load(uint32_t pos) const { return (pos >> 5) != cidx ? 1u : 0u; }
+    __device__ __forceinline__ uint32_t at(uint32_t pos) {
+        uint32_t chunk = pos >> 5;
+        if (chunk != cidx) {
+            uint4 a = p[chunk];
+            q0 = u64_of(a.x, a.y); q1 = u64_of(a.z, a.w);
+            cidx = chunk;
+        }
+        uint64_t m16 = (pos & 16u) ? ~0ull : 0ull;
+        uint64_t w = q0 ^ ((q0 ^ q1) & m16);
+        return (uint32_t)(w >> (60u - 4u * (pos & 15u))) & 15u;
+    }
+};
+
+// States of a lane.  EXT / REC / FLUSH: the index walk.  DSA / DIR / DEND: direct extension of a match that has become
+// ONE row, i.e. one text position r = SA[row]: the query is compared with the text itself, one TextGroup (16 letters +
+// the parent-depth classes that tell where an ancestor interval may have to be reported) per trip; where the run ends
+// (a letter disagrees, a class says stop, the slice or the text begins) the TextRec of the position gives back the row
+// and -- after a disagreeing letter -- the parent interval on which the letter is retried.  The reference takes these
+// letters one FMI_FollowLetter at a time (slamem.c:121); the output is the same: as long as the letters agree the single
+// row's BWT letter IS the query letter (nothing is left-maximal) and only an ancestor >= min_len could emit.
+enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DEND = 5 };
+
 #ifndef SLAMEM_V3_WAVES
 #define SLAMEM_V3_WAVES 1
 #endif
 template <bool kStats>
 __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
-    __shared__ ItemDesc lds_item[4][kChunkMax];
+    __shared__ ItemDesc lds_item[4][kFetch];
+    __shared__ uint64_t lds_pk[4][kFetch];
+    __shared__ uint32_t lds_id[4][kFetch];
     const IndexView& ix = A.ix;
     const int L = (int)A.min_len;
     const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
-    __shared__ uint32_t lds_id[4][kChunkMax];
-    // the work list: every item, or only those that survived the prefilter (dense, so no lane idles on dead items)
-    const uint64_t nitems = A.work_ids ? (uint64_t)*A.work_count : A.num_items;
+    // the work list: every item, or only those that survived the prefilter (dense, so no lane idles on dead items).
+    // Waves take it in pieces of kFetch items from a global cursor (one atomic per piece), so that every wave stays
+    // busy until the list is empty whatever its strands cost -- with a fixed share per wave, lanes idled at the end
+    // of every share (measured: 58 % lane use once the direct extension made strand costs uneven).
+    const uint32_t nitems = A.work_ids ? *A.work_count : (uint32_t)A.num_items;  // (the host refuses batches near 2^32 items)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    uint64_t next = wave * A.chunk;  // wave-uniform: first unassigned work item of this wave's chunk
-    if (next > nitems) next = nitems;
-    const uint64_t chunk_first = next;
-    const uint64_t chunk_end = next + A.chunk < nitems ? next + A.chunk : nitems;
-    // item descriptors of the chunk -> LDS (one coalesced read per wave instead of a round trip per item)
-    for (uint64_t i = chunk_first + lane; i < chunk_end; i += 64u) {
-        uint32_t id = A.work_ids ? A.work_ids[i] : (uint32_t)i;
-        lds_id[wv][i - chunk_first] = id;
-        lds_item[wv][i - chunk_first] = A.items[id];
-    }
-    __syncthreads();
+    uint32_t next = 0, chunk_first = 0, chunk_end = 0;  // wave-uniform: the piece being handed out
+    bool drained = false;                               // wave-uniform: the cursor is past the end of the list
+    // direct extension: the class threshold of this launch (flag <=> class >= cL; a parent depth >= L implies it)
+    const int dmin = A.direct_min_depth;  // < 0: off
+    const uint32_t cL = depth_class(L);
+    const uint64_t k1 = 0x1111111111111111ull;
+    const uint64_t cls_add = (uint64_t)(8u - (cL & 7u)) * k1;
+    const bool cls_hi = cL >= 8u;
 
     // diagnostic instantiation only
     uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_wtrips = 0, n_pos = 0,
-             n_enum = 0, n_qloads = 0;
+             n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0;
 
-    bool active = false, pend = false;
+    bool active = false, pend = false, dmis = false, dcool = false;
     uint32_t st = ST_EXT;
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
-    uint32_t a_pos = 0, b_pos = 0, attempt = 0;  // emitted slice [a_pos, b_pos) of the strand, warm-up attempt
+    uint32_t a_pos = 0, b_pos = 0, attempt = 0, qlen = 0;  // emitted slice [a_pos, b_pos) of the strand, warm-up attempt
+    uint32_t dir_r = 0;  // direct extension: text position where the current match starts
     int depth = 0, pub = -1;
-    QueryCursor qc;
-    qc.init(A.qwords, 0, 0, 0);
+    PackedCursor qc;
+    qc.init(A.pq);
     // FM block of `top`, kept across trips: after a parent step the widened interval usually still lies in the
     // same 128-row block, so the retry fetches nothing
     Blk kt;
@@ -583,30 +694,53 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     uint32_t tag_t = 0xFFFFFFFFu;
 
     for (;;) {
-        // ---- hand the next items of the chunk to idle lanes ------------------------------------------------
+        // ---- hand the next items to idle lanes ----------------------------------------------------------------
         unsigned long long idle = __ballot(!active);
+        if (idle != 0ull && next >= chunk_end && !drained) {  // fetch the next piece of the work list
+            uint32_t base = 0;
+            if (lane == 0u) base = atomicAdd(A.work_cursor, kFetch);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= nitems) drained = true;
+            else {
+                chunk_first = next = base;
+                chunk_end = nitems - base < kFetch ? nitems : base + kFetch;
+                const uint32_t i = chunk_first + lane;
+                if (i < chunk_end) {  // descriptors -> LDS: one coalesced read per wave instead of a round trip per item
+                    uint32_t id = A.work_ids ? A.work_ids[i] : (uint32_t)i;
+                    lds_id[wv][lane] = id;
+                    lds_item[wv][lane] = A.items[id];
+                    lds_pk[wv][lane] = A.item_pk[id];
+                }
+                // written and read by lanes of this wave only
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
         if (idle != 0ull && next < chunk_end) {
             uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            uint64_t cand = next + rank;
+            uint32_t cand = next + rank;
             if (!active && cand < chunk_end) {
                 g = lds_id[wv][cand - chunk_first];
                 ItemDesc d = lds_item[wv][cand - chunk_first];
-                qc.init(A.qwords, d.base, d.len, d.slice_rev >> 31);
+                qc.init(A.pq + lds_pk[wv][cand - chunk_first]);
+                qlen = d.len;
                 uint32_t sl = d.slice_rev & 0x7FFFFFFFu;
                 a_pos = sl * kSliceLen;
                 b_pos = d.len - a_pos < kSliceLen ? d.len : a_pos + kSliceLen;
                 attempt = 0;
                 j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
-                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; k = 0;
+                top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; k = 0; dcool = false;
                 if (d.len == 0) {  // empty record: nothing to scan
                     A.block_counts[g] = 0;
                     A.item_attempt[g] = 0;
                 } else active = true;
             }
-            next += (uint64_t)__popcll(idle);
+            next += (uint32_t)__popcll(idle);
+            // the LDS slots are reused by the next fetch: every lane has copied its descriptor by then (same wave, in order)
         }
         if (__ballot(active) == 0ull) {
-            if (next >= chunk_end) break;
+            if (drained && next >= chunk_end) break;
             continue;
         }
         if (kStats) n_wtrips += lane == 0u;
@@ -618,9 +752,15 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
 
         if (active) {
             // ---- memory phase: every load of this trip, no use in between -------------------------------------
-            uint4 rt = make_uint4(0, 0, 0, 0), rb = rt;
-            bool want_rec = st == ST_REC || st == ST_FLUSH;
-            uint32_t c = 0;
+            // two generic 16-byte slots, addressed by state: the row records of `top` and `bot`; or the suffix-array
+            // quad of `top`; or a text group and the query words that face it; or the text-ordered record
+            const uint4* a1 = nullptr;
+            const uint2* a2 = nullptr;
+            uint4 rt = make_uint4(0, 0, 0, 0);
+            uint2 rb0 = make_uint2(0, 0), rb1 = rb0;
+            bool want_rec = false;
+            uint32_t c = 0, dm = 0;
+            int qs = 0;
             Blk kb;  // block of bot+1 when it differs from top's (wide intervals only: not kept across trips)
             kb.a = kb.b = kb.c = kb.d = make_uint4(0, 0, 0, 0);
             if (st == ST_EXT) {
@@ -628,24 +768,42 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 if (kStats) { n_kt += bt != tag_t; n_kb += bb != bt; }
                 if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
                 if (bb != bt) kb = load_blk(ix.fm, bb);
-                // records together with the blocks: when a pending position's parent may still be >= min_len deep
-                // (its depth is needed now), or speculatively while the match is short (off by default)
-                want_rec = depth <= A.spec_depth || (pend && pub >= L);
+                // records together with the blocks when a pending position's parent may still be >= min_len deep
+                want_rec = pend && pub >= L;
                 if (kStats && want_rec) n_rec_pend += 1u + ((top >> 2) != (bot >> 2));
+            } else if (st == ST_DSA) {
+                a1 = reinterpret_cast<const uint4*>(ix.sa + (top & ~3u));  // the aligned quad that holds SA[top]
+                if (kStats) n_dsa++;
+            } else if (st == ST_DIR) {
+                const uint32_t gi = (dir_r - 1u) >> 4;  // dir_r >= 1 here
+                dm = dir_r - (gi << 4);                 // letters of the group below dir_r: 1..16
+                a1 = reinterpret_cast<const uint4*>(ix.tgrp + gi);
+                qs = (int)j - (int)dm;                  // strand position that faces the group's first letter (may be < 0)
+                a2 = reinterpret_cast<const uint2*>(reinterpret_cast<const uint64_t*>(qc.p) + (qs >> 4));
+                if (kStats) n_dgrp++;
+            } else if (st == ST_DEND) {
+                a1 = reinterpret_cast<const uint4*>(ix.prec + dir_r);
+                if (kStats) n_drec++;
+            } else {
+                want_rec = true;  // ST_REC, ST_FLUSH
             }
             if (kStats) {
                 n_trips++;
                 if (st == ST_REC) n_rec_fail += 1u + ((top >> 2) != (bot >> 2));
                 if (st == ST_FLUSH) n_rec_flush += 1u + ((top >> 2) != (bot >> 2));
             }
-            if (want_rec) { rt = R[top]; rb = R[bot]; }
+            if (want_rec) { a1 = R + top; a2 = reinterpret_cast<const uint2*>(R + bot); }
+            if (a1) rt = *a1;
+            if (a2) { rb0 = a2[0]; rb1 = a2[1]; }
             if (st == ST_EXT) {
                 if (kStats) n_qloads += qc.would_load(j - 1u);
-                c = qc.at(j - 1u);  // issues the query-word loads (if any) behind the ones above
+                c = qc.at(j - 1u);  // issues the query-window load (if any) behind the ones above
             }
+            const uint4 rb = make_uint4(rb0.x, rb0.y, rb1.x, rb1.y);
 
             // ---- compute phase -------------------------------------------------------------------------------
             bool strand_end = false;  // position 0 has been consumed: flush what is pending, finish
+            bool pub_exact = false;   // strand end reached through DEND: pub is the exact parent depth
             if (st == ST_FLUSH) {  // the strand ended on a match whose parent may qualify too: its depth has arrived
                 st = ST_EXT;
                 uint32_t t2 = top, b2 = bot;
@@ -656,9 +814,72 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 finished = true;
             } else if (st == ST_REC) {  // a deep match ended at this letter: widen, retry next trip
                 st = ST_EXT;
+                dcool = false;
                 int d = parent_from(rt, rb, top, bot);
                 if (d < 0) { depth = 0; pub = -1; consumed = true; }
                 else { depth = d; pub = d - 1; }
+            } else if (st == ST_DSA) {
+                const uint32_t o = top & 3u;
+                dir_r = o == 0u ? rt.x : o == 1u ? rt.y : o == 2u ? rt.z : rt.w;
+                dmis = true;  // read only when the text begins here: '$' on the left never equals a query letter
+                st = dir_r == 0u ? ST_DEND : ST_DIR;
+            } else if (st == ST_DIR) {
+                // the group's letters face strand positions qs .. qs+15, letter i in nibble 15-i.  Letters dm-1, dm-2, ...
+                // (text positions dir_r-1 downwards) are compared with strand positions j-1, j-2, ...
+                const uint64_t T = u64_of(rt.x, rt.y), C = u64_of(rt.z, rt.w);
+                const uint64_t w0 = u64_of(rb0.x, rb0.y), w1 = u64_of(rb1.x, rb1.y);
+                const uint32_t sh = ((uint32_t)qs & 15u) * 4u;
+                const uint64_t Q = sh ? (w0 << sh) | (w1 >> (64u - sh)) : w0;
+                uint64_t x = T ^ Q;
+                x |= x >> 1; x |= x >> 2;
+                const uint64_t mis = x & k1;                                   // nibble LSB set: the letters differ
+                const uint64_t lo3 = C & (7ull * k1), h8 = (C >> 3) & k1;
+                const uint64_t ge = ((lo3 + cls_add) >> 3) & k1;
+                const uint64_t flag = cls_hi ? (h8 & ge) : (h8 | ge);          // class >= cL: an ancestor may qualify
+                const uint32_t W = j - a_pos;                                   // letters this item may still consume (>= 1)
+                const uint32_t take = dm < W ? dm : W;
+                const uint32_t nlo = 16u - dm, nhi = nlo + take;                // nibbles of the letters in play
+                uint64_t mask = nhi >= 16u ? ~0ull : ((1ull << (4u * nhi)) - 1ull);
+                mask &= ~((1ull << (4u * nlo)) - 1ull);
+                const uint64_t stop = (mis | flag) & mask;
+                uint32_t kc;
+                const bool hit = stop != 0ull;
+                if (hit) {
+                    const uint32_t nib = (uint32_t)__builtin_ctzll(stop) >> 2;
+                    kc = nib - nlo;
+                    dmis = ((mis >> (4u * nib)) & 1ull) != 0ull;
+                    dcool = !dmis;  // stopped by a class flag: the index walk takes over until the interval changes
+                } else {
+                    kc = take;
+                    dmis = false;
+                }
+                j -= kc; depth += (int)kc; dir_r -= kc;
+                if (kStats) { n_dlet += kc; n_pos += kc; }
+                if (!hit && j != a_pos) {
+                    if (dir_r == 0u) { dmis = true; st = ST_DEND; }  // the text begins: the next letter cannot match
+                    else st = ST_DIR;                               // the whole group agreed: next group
+                } else {
+                    st = ST_DEND;
+                }
+            } else if (st == ST_DEND) {
+                // rt = {row, parent top, parent bottom, parent depth + 1} of the suffix that starts at dir_r
+                st = ST_EXT;
+                top = bot = rt.x;
+                const int pdepth = (int)rt.w - 1;
+                pub = pdepth;  // exact
+                const bool in_slice = j >= a_pos && j < b_pos;
+                pend = depth >= L && in_slice;
+                if (j == 0u) {
+                    strand_end = true;
+                    pub_exact = true;
+                } else if (dmis && rt.w != 0u && !(pend && pdepth >= L)) {
+                    // the letter to the left differs from the text's: what EXT + REC would do -- the pending row is
+                    // left-maximal (slamem.c:141), then the interval widens to its parent and the letter is retried
+                    if (pend) { emit3_at(A, g, k, attempt << 28, top, j, (uint32_t)depth); k++; pend = false; }
+                    top = rt.y; bot = rt.z; depth = pdepth; pub = pdepth - 1;
+                    dcool = false;
+                }
+                // otherwise the index walk continues from the single row (pending position, exact parent depth)
             } else {  // ST_EXT
                 uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
                 uint32_t nt, nb1;
@@ -701,6 +922,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                         consumed = true;
                     } else if (want_rec) {
                         int d = parent_from(rt, rb, top, bot);
+                        dcool = false;
                         if (d < 0) { depth = 0; pub = -1; consumed = true; }  // root, letter absent (slamem.c:125)
                         else { depth = d; pub = d - 1; }                      // widened; retry the letter next trip
                     } else {
@@ -714,21 +936,25 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 bool in_slice = j >= a_pos && j < b_pos;
                 pend = depth >= L && depth > 0 && in_slice;  // slamem.c:130
                 // scan start of this attempt; a match that reaches it may be truncated: redo with a longer warm-up
-                uint32_t e = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
-                                                                                                   : b_pos + (kWarmUp << (2u * attempt));
-                if (in_slice && e < qc.len && (uint32_t)depth == e - j) {
+                uint32_t e = (attempt >= kMaxAttempt || qlen - b_pos < (kWarmUp << (2u * attempt))) ? qlen
+                                                                                                 : b_pos + (kWarmUp << (2u * attempt));
+                if (in_slice && e < qlen && (uint32_t)depth == e - j) {
                     attempt++;
-                    j = (attempt >= kMaxAttempt || qc.len - b_pos < (kWarmUp << (2u * attempt))) ? qc.len
-                                                                                            : b_pos + (kWarmUp << (2u * attempt));
-                    top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; k = 0;
+                    j = (attempt >= kMaxAttempt || qlen - b_pos < (kWarmUp << (2u * attempt))) ? qlen
+                                                                                          : b_pos + (kWarmUp << (2u * attempt));
+                    top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; k = 0; dcool = false;
                     qc.forget();
                 } else if (j == 0u) {
                     strand_end = true;
+                } else if (st == ST_EXT && top == bot && depth >= dmin && dmin >= 0 && !dcool && j > a_pos &&
+                           !(e < qlen && (uint32_t)depth == e - j)) {
+                    st = ST_DSA;  // one row, too deep to be a chance match: compare with the text itself from here on
                 }
             }
             if (strand_end) {  // strand finished; rows still pending have nothing to their left (slamem.c:138)
                 finished = true;
-                if (pend && pub >= L) { st = ST_FLUSH; finished = false; }  // parent depth needed: next trip
+                if (pend && pub >= L && !pub_exact) { st = ST_FLUSH; finished = false; }  // parent depth needed: next trip
+                else if (pend && pub >= L) { e_on = true; e_level0 = true; e_up = true; e_pos = 0u; e_left = 0xFFu; }
                 else if (pend && top == bot) { emit3_at(A, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; pend = false; }
                 else if (pend) { e_on = true; e_level0 = true; e_up = false; e_pos = 0u; e_left = 0xFFu; }
             }
@@ -764,6 +990,8 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
         stat_flush<kStats>(A.stats + SC_REC_FLUSH_LINES, n_rec_flush); stat_flush<kStats>(A.stats + SC_QUERY_LOADS, n_qloads);
         stat_flush<kStats>(A.stats + SC_LANE_TRIPS, n_trips); stat_flush<kStats>(A.stats + SC_WAVE_TRIPS, n_wtrips);
         stat_flush<kStats>(A.stats + SC_POSITIONS, n_pos); stat_flush<kStats>(A.stats + SC_ENUM_JOBS, n_enum);
+        stat_flush<kStats>(A.stats + SC_DIR_SA, n_dsa); stat_flush<kStats>(A.stats + SC_DIR_GROUPS, n_dgrp);
+        stat_flush<kStats>(A.stats + SC_DIR_RECS, n_drec); stat_flush<kStats>(A.stats + SC_DIR_LETTERS, n_dlet);
     }
 }
 
@@ -929,30 +1157,40 @@ __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict
 
 // ---- work items ------------------------------------------------------------------------------------------
 // slices per strand of every record (>= 1 so that empty records still own an (empty) output block)
+// (and the 64-bit words one strand of the record occupies in the packed copy: a multiple of two, i.e. 16-byte blocks)
 __global__ void __launch_bounds__(256) k_item_counts(const uint64_t* __restrict__ offsets, uint32_t nq, uint32_t slice_len,
-                                                     uint32_t* __restrict__ cnt) {
+                                                     uint32_t* __restrict__ cnt, uint32_t* __restrict__ wps) {
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nq) return;
-    uint32_t c = 0;
+    uint32_t c = 0, w = 0;
     if (q < nq) {
         uint64_t len = offsets[q + 1] - offsets[q];
         c = slice_len ? (uint32_t)((len + slice_len - 1) / slice_len) : 1u;
         if (c == 0) c = 1;
+        w = 2u * (uint32_t)((len + 31u) >> 5);
     }
     cnt[q] = c;  // cnt[nq] = 0: the scan of nq+1 values leaves the total in first[nq]
+    wps[q] = w;
 }
 
 // items in emission order: per record the forward strand's slices right to left, then the reverse strand's
+// item_pk: word offset of the item's strand block in the packed copy (two zero words lead the buffer); every slice of a
+// strand carries the block's offset, positions stay relative to the strand
 __global__ void __launch_bounds__(256) k_item_fill(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ first,
-                                                   uint32_t nq, uint32_t strands, ItemDesc* __restrict__ items) {
+                                                   const uint64_t* __restrict__ wscan, uint32_t nq, uint32_t strands,
+                                                   ItemDesc* __restrict__ items, uint64_t* __restrict__ item_pk) {
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     uint64_t o0 = offsets[q];
     uint32_t len = (uint32_t)(offsets[q + 1] - o0);
     uint32_t f = first[q], cnt = first[q + 1] - f;
+    uint64_t w0 = wscan ? wscan[q] : 0ull, wps = wscan ? wscan[q + 1] - w0 : 0ull;
     for (uint32_t s = 0; s < strands; s++)
-        for (uint32_t c = 0; c < cnt; c++)
-            items[(uint64_t)strands * f + (uint64_t)s * cnt + (cnt - 1u - c)] = ItemDesc{o0, len, c | (s << 31)};
+        for (uint32_t c = 0; c < cnt; c++) {
+            uint64_t it = (uint64_t)strands * f + (uint64_t)s * cnt + (cnt - 1u - c);
+            items[it] = ItemDesc{o0, len, c | (s << 31)};
+            if (item_pk) item_pk[it] = 2ull + (uint64_t)strands * w0 + (uint64_t)s * wps;
+        }
 }
 
 // public strand blocks: block (q, s) starts where its first item starts
@@ -1029,7 +1267,7 @@ inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_alive, off_workids, off_select, select_bytes, off_itemoff, off_rawkey,
-        off_rawmem, off_inline, off_scan, scan_bytes, max_items, bytes;
+        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, max_items, bytes;
 };
 
 // max_items bounds the work items of ANY batch with this many records and characters
@@ -1061,6 +1299,12 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     (void)scan_sum_exclusive_u32_u64(nullptr, need, nullptr, nullptr, w.max_items, 0);
     w.scan_bytes = need;
     w.off_scan = off;     off = align_up(off + need, 256);
+    // the packed copy of the strands (k_pack_queries): per strand 2 * ceil(len / 32) words <= len / 16 + 2
+    w.off_wps = off;      off = align_up(off + (num_queries + 2) * 4, 256);
+    w.off_wscan = off;    off = align_up(off + (num_queries + 2) * 8, 256);
+    w.off_itempk = off;   off = align_up(off + w.max_items * 8, 256);
+    w.pq_bytes = 8 * (4 + strands * (query_bytes / 16 + 2 * num_queries + 2));
+    w.off_pq = off;       off = align_up(off + w.pq_bytes, 256);
     w.bytes = off;
     return w;
 }
@@ -1090,8 +1334,8 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     const uint32_t strands = both_strands ? 2u : 1u;
     const uint64_t num_blocks = (uint64_t)num_queries * strands;
     WorkspaceLayout w = layout_workspace(num_queries, strands, query_bytes, mems_capacity);
-    if (w.max_items >= 0xFFFFFFFFull) {
-        set_error("slamem_find_mems_device: at most 2^32-2 work items per call");
+    if (w.max_items >= 0xFFF00000ull) {  // (the work cursor runs up to 8192 x 64 past the end of the list)
+        set_error("slamem_find_mems_device: at most 2^32 - 2^20 work items per call");
         return SLAMEM_ERR_ARG;
     }
     if (workspace_bytes < w.bytes) {
@@ -1125,8 +1369,10 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         STEP(hipMemsetAsync(d_total, 0, 64 + SC_COUNT * 8, stream), "memset");
         // ---- work items: one per strand, long records cut into slices (v1 scans whole strands) ----------------
         uint64_t nitems = num_blocks;
+        uint32_t* d_wps = reinterpret_cast<uint32_t*>(ws + w.off_wps);
+        uint64_t* d_wscan = reinterpret_cast<uint64_t*>(ws + w.off_wscan);
         hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
-                           num_queries, kernel_version == 3 ? kSliceLen : 0u, d_cnt);
+                           num_queries, kernel_version == 3 ? kSliceLen : 0u, d_cnt, d_wps);
         STEP(hipGetLastError(), "k_item_counts");
         STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
         uint32_t slices = 0;
@@ -1166,9 +1412,27 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         bool prefiltered = false, timed_k8 = false;
         (void)hipEventRecord(e0, stream);
         if (nitems && kernel_version == 3) {
-            hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first,
-                               num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items));
+            {   // packed strands: offsets of the strand blocks, then the letters (K7q)
+                size_t need3 = w.scan_bytes;
+                STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need3, d_wps, d_wscan, (uint64_t)num_queries, stream), "scan");
+            }
+            uint64_t* d_itempk = reinterpret_cast<uint64_t*>(ws + w.off_itempk);
+            uint64_t* d_pq = reinterpret_cast<uint64_t*>(ws + w.off_pq);
+            hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
+                               num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk);
             STEP(hipGetLastError(), "k_item_fill");
+            A.pq = d_pq;
+            A.pq_out = d_pq;
+            A.item_pk = d_itempk;
+            {   // direct extension of single-row matches: on when the index has the text-ordered sections and the class
+                // threshold can discriminate (min_len >= 8); entry depth = where chance matches stop, log4(n) + 3
+                static const int env_depth = [] { const char* v = getenv("SLAMEM_DIRECT_DEPTH"); return v ? atoi(v) : 0; }();
+                int lg = 0;
+                for (uint64_t v = idx->hdr.n; v > 1; v >>= 2) lg++;
+                A.direct_min_depth = (idx->view.tgrp && depth_class((int)min_len) >= 1u) ? lg + 3 : -1;
+                if (env_depth > 0 && A.direct_min_depth >= 0) A.direct_min_depth = env_depth;
+                if (env_depth < 0) A.direct_min_depth = -1;
+            }
             static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
             if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
                 uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
@@ -1188,7 +1452,13 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                 A.work_ids = d_ids;
                 A.work_count = d_nwork;
             }
-            uint64_t waves = (nitems + A.chunk - 1) / A.chunk;
+            STEP(hipMemsetAsync(d_pq, 0, 16, stream), "memset");  // the two leading zero words
+            hipLaunchKernelGGL(k_pack_queries, dim3(grid_for(nitems * 16)), dim3(256), 0, stream, A);  // K7q (uses item_alive)
+            STEP(hipGetLastError(), "k_pack_queries");
+            // persistent waves: enough to fill the chip twice over (256 CUs x 16 waves), fewer for small batches
+            uint64_t waves = (nitems + kFetch - 1) / kFetch;
+            if (waves > 8192) waves = 8192;
+            A.work_cursor = reinterpret_cast<unsigned int*>(d_total + 5);  // a word of the zeroed scalar block
             (void)hipEventRecord(ek, stream);
             timed_k8 = true;
             if (want_stats) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
@@ -1230,6 +1500,8 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             o.rec_lines_fail = c[SC_REC_FAIL_LINES]; o.rec_lines_pend = c[SC_REC_PEND_LINES]; o.rec_lines_flush = c[SC_REC_FLUSH_LINES];
             o.query_loads = c[SC_QUERY_LOADS]; o.lane_trips = c[SC_LANE_TRIPS]; o.wave_trips = c[SC_WAVE_TRIPS];
             o.positions = c[SC_POSITIONS]; o.enum_jobs = c[SC_ENUM_JOBS];
+            o.dir_sa_lines = c[SC_DIR_SA]; o.dir_group_loads = c[SC_DIR_GROUPS]; o.dir_rec_lines = c[SC_DIR_RECS];
+            o.dir_letters = c[SC_DIR_LETTERS];
             o.prefilter_probes = c[SC_PF_PROBES]; o.prefilter_query_loads = c[SC_PF_QUERY_LOADS]; o.prefilter_items = c[SC_PF_ITEMS];
             o.items = nitems;
             o.survivors = prefiltered ? nwork : nitems;
