@@ -112,7 +112,8 @@ typedef struct {
     uint64_t dir_group_loads;       /* K8 direct extension: text groups (16 letters + classes, 16 B) with 16 B of query */
     uint64_t dir_rec_lines;         /* K8 direct extension: text-ordered records (one per run)                         */
     uint64_t dir_letters;           /* K8 direct extension: query positions consumed by comparing with the text        */
-    uint64_t reserved[2];
+    uint64_t jump_lines;            /* K8: K-mer jump table entries read (one per scan start)                          */
+    uint64_t reserved[1];
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

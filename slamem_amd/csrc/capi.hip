@@ -90,6 +90,10 @@ static int header_ok(const ArenaHeader& h, uint64_t bytes) {
         section(h.off_tgrp, ((R >> 4) + 2) * sizeof(TextGroup), "text groups");
         section(h.off_prec, R * sizeof(TextRec), "text-ordered records");
     }
+    if (h.off_kjump) {
+        if (!bad && (h.kjump_k < 1 || h.kjump_k > 12)) bad = "jump table K";
+        if (!bad) section(h.off_kjump, 8ull << (2u * h.kjump_k), "jump table");
+    }
     if (!bad && h.dollar_row > h.n) bad = "'$' row";
     if (bad) {
         set_error("index arena is corrupt or truncated: bad %s", bad);

@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 8;  // 8: text-ordered groups + parent records (direct extension); 7: pair row records + separate SA
+constexpr uint32_t kArenaVersion = 9;  // 9: K-mer jump table; 8: text-ordered groups + parent records (direct extension)
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -83,7 +83,7 @@ struct ArenaHeader {
     uint64_t off_kfilter; // uint64[1 << kfilter_log2]  k-mer presence filter (0 = absent)
     uint64_t off_tgrp;    // TextGroup[(n >> 4) + 2]  text-ordered: 16 letters + 16 parent-depth classes per 16 bytes
     uint64_t off_prec;    // TextRec[n+1]             text-ordered: row and parent interval of the suffix at each position
-    uint64_t reserved_off;
+    uint64_t off_kjump;   // uint2[4^kjump_k]  K-mer jump table: BWT interval of every K-mer (absent: top > bottom)
     uint32_t kfilter_log2;
     uint32_t kfilter_k;
     uint32_t nblocks;
@@ -92,7 +92,8 @@ struct ArenaHeader {
     uint32_t max_lcp;
     uint32_t sort_rounds;
     uint32_t C[6];        // C[c] = number of characters of text+'$' smaller than c
-    uint32_t reserved[16];
+    uint32_t kjump_k;     // K of the jump table (0 = none)
+    uint32_t reserved[15];
 };
 static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 
@@ -105,6 +106,8 @@ struct IndexView {
     const uint64_t* kfilter;  // nullptr when the index has no presence filter
     const TextGroup* tgrp;    // nullptr when the index has no text-ordered sections
     const TextRec* prec;
+    const uint2* kjump;       // nullptr when the index has no K-mer jump table
+    uint32_t kjump_k;
     uint32_t n;
     uint32_t nblocks;
     uint32_t dollar_row;

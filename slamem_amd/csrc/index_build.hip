@@ -377,6 +377,46 @@ __global__ void k_lcp_sentinels(uint32_t rows, uint32_t* l32, uint32_t* psv, uin
     }
 }
 
+// K-mer jump table (no reference counterpart): the BWT interval of every K-mer over A,C,G,T, so that a scan takes its
+// first K backward steps -- FMI_FollowLetter from the root, slamem.c:110-121, the steps with the widest intervals: two
+// FM lines each -- in ONE read.  Suffixes that share their first K letters are contiguous in suffix order.
+// pass 1: key of every row (2 bits per letter, first letter on top; ~0 = shorter than K or holds N / '$')
+__global__ void __launch_bounds__(256) k_kjump_keys(const uint32_t* __restrict__ sa, const uint64_t* __restrict__ pk,
+                                                    uint32_t n, uint32_t K, uint32_t* __restrict__ keys) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    uint32_t s = sa[r];
+    uint32_t key = 0xFFFFFFFFu;
+    if ((uint64_t)s + K <= n) {
+        uint64_t x = window16(pk, s);
+        uint64_t v = ((x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ull;  // nibble >= 2: one of A,C,G,T
+        const uint64_t topk = ~0ull << (4u * (16u - K));
+        if ((v & topk) == (0x1111111111111111ull & topk)) {
+            x = (x & topk) | (0x2222222222222222ull & ~topk);  // (no borrow may run into the K letters)
+            x = (x - 0x2222222222222222ull) & topk;
+            x = (x & 0x0303030303030303ull) | ((x & 0x3030303030303030ull) >> 2);
+            x = (x & 0x000F000F000F000Full) | ((x & 0x0F000F000F000F00ull) >> 4);
+            x = (x & 0x000000FF000000FFull) | ((x & 0x00FF000000FF0000ull) >> 8);
+            x = (x & 0xFFFFull) | ((x >> 16) & 0xFFFF0000ull);
+            key = (uint32_t)x >> (2u * (16u - K));
+        }
+    }
+    keys[r] = key;
+}
+// pass 2: the first and the last row of every key
+__global__ void __launch_bounds__(256) k_kjump_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint2* __restrict__ table) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    uint32_t k = keys[r];
+    if (k == 0xFFFFFFFFu) return;
+    if (r == 0 || keys[r - 1] != k) table[k].x = (uint32_t)r;
+    if (r == n || keys[r + 1] != k) table[k].y = (uint32_t)r;
+}
+__global__ void __launch_bounds__(256) k_kjump_init(uint2* __restrict__ table, uint64_t entries) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < entries) table[i] = make_uint2(1u, 0u);  // top > bottom: the K-mer does not occur
+}
+
 // text-ordered records (TextRec) and the parent-depth class of every text position (one byte each, packed into the
 // groups by k_text_groups): one random 16-byte read of the row's record per position
 __global__ void __launch_bounds__(256) k_text_records(const uint32_t* __restrict__ isa, const RowRec* __restrict__ rec,
@@ -592,6 +632,8 @@ void make_view(slamem_index* idx) {
     idx->view.kfilter = h.off_kfilter ? reinterpret_cast<const uint64_t*>(base + h.off_kfilter) : nullptr;
     idx->view.tgrp = h.off_tgrp ? reinterpret_cast<const TextGroup*>(base + h.off_tgrp) : nullptr;
     idx->view.prec = h.off_tgrp ? reinterpret_cast<const TextRec*>(base + h.off_prec) : nullptr;
+    idx->view.kjump = h.off_kjump ? reinterpret_cast<const uint2*>(base + h.off_kjump) : nullptr;
+    idx->view.kjump_k = h.off_kjump ? h.kjump_k : 0u;
     idx->view.kfilter_log2 = h.kfilter_log2;
     idx->view.kfilter_k = h.kfilter_k;
     idx->view.n = h.n;
@@ -691,6 +733,18 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         if (!(de && atoi(de) == 0)) {
             hdr.off_tgrp = off; off = align_up(off + ngroups * sizeof(TextGroup), 256);
             hdr.off_prec = off; off = align_up(off + R * sizeof(TextRec), 256);
+        }
+    }
+    {   // K-mer jump table: K = floor(log4 n) - 1, at most 12 (134 MB); SLAMEM_KJUMP=0 builds without
+        const char* kj = getenv("SLAMEM_KJUMP");
+        uint32_t K = 0;
+        for (uint64_t v = n; v >= 4; v >>= 2) K++;
+        K = K > 1 ? K - 1 : 0;
+        if (K > 12) K = 12;
+        if (kj && atoi(kj) >= 0 && (uint32_t)atoi(kj) < K) K = (uint32_t)atoi(kj);
+        if (K > 0) {
+            hdr.kjump_k = K;
+            hdr.off_kjump = off; off = align_up(off + (8ull << (2u * K)), 256);
         }
     }
     hdr.total_bytes = off;
@@ -805,6 +859,13 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     RowRec* d_rec = reinterpret_cast<RowRec*>(base + hdr.off_rec);
     uint32_t* d_nrows = reinterpret_cast<uint32_t*>(base + hdr.off_nrows);
     SLAMEM_HIP(hipMemsetAsync(base, 0, kHeaderBytes, stream));
+    if (hdr.off_kjump) {  // before anything else reuses the sort's scratch: the row keys live in tmp32
+        uint2* d_kj = reinterpret_cast<uint2*>(base + hdr.off_kjump);
+        hipLaunchKernelGGL(k_kjump_init, dim3(grid_for(1ull << (2u * hdr.kjump_k))), dim3(256), 0, stream, d_kj, 1ull << (2u * hdr.kjump_k));
+        hipLaunchKernelGGL(k_kjump_keys, dim3(grid_for(R)), dim3(256), 0, stream, d_sa, pk.as<uint64_t>(), n, hdr.kjump_k, tmp32.as<uint32_t>());
+        hipLaunchKernelGGL(k_kjump_bounds, dim3(grid_for(R)), dim3(256), 0, stream, tmp32.as<uint32_t>(), n, d_kj);
+        SLAMEM_HIP(hipGetLastError());
+    }
     if (hdr.off_kfilter) {
         unsigned long long* d_filter = reinterpret_cast<unsigned long long*>(base + hdr.off_kfilter);
         SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));

@@ -180,7 +180,7 @@ struct SearchArgs {
     const uint64_t* item_pk;    // v3: per work item, the word offset of its strand block in pq
     unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
     int32_t direct_min_depth;   // v3: a single-row match at least this deep is extended by comparing with the text (<0: off)
-    uint32_t pad3;
+    uint32_t use_jump;          // v3: take the first K letters of a scan through the K-mer jump table
 };
 
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
@@ -536,7 +536,7 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
 enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
-    SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_COUNT
+    SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -552,7 +552,11 @@ __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) 
 // the top nibble (the layout of the packed text, so that a query window and a text group compare with one XOR).  Every
 // strand block starts on a 16-byte boundary.  16 lanes per work item, one word each per step; ASCII -> id through a
 // 256-byte table in LDS.
-__global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A) {
+// kLanes lanes per work item.  long_only = false: the items of the work list (the survivors of the prefilter, or all)
+// that are whole strands; long_only = true: every slice of the records that were cut into slices, whether it survived or
+// not -- a neighbouring slice's scan starts in it (warm-up).
+template <uint32_t kLanes>
+__global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A, bool long_only) {
     __shared__ uint8_t lut[512];  // [0,256): id; [256,512): id of the complement
     for (uint32_t i = threadIdx.x; i < 256u; i += 256u) {
         uint32_t c = ascii_code_q(i);
@@ -560,13 +564,14 @@ __global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A) {
         lut[256u + i] = (uint8_t)(c >= 2u ? 7u - c : c);  // A<->T, C<->G; N stays N  (sequence.c:419-426)
     }
     __syncthreads();
-    const uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const uint32_t sub = threadIdx.x & 15u;
-    if (item >= A.num_items) return;
+    const uint32_t sub = threadIdx.x & (kLanes - 1u);
+    const uint64_t count = long_only ? A.num_items : (A.work_ids ? (uint64_t)*A.work_count : A.num_items);
+    const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) / kLanes;
+    // grid-stride over the list (the table above is set up once per block)
+    for (uint64_t e = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kLanes; e < count; e += stride) {
+    const uint64_t item = (!long_only && A.work_ids) ? (uint64_t)A.work_ids[e] : e;
     const ItemDesc d = A.items[item];
-    // strands the prefilter proved empty are never scanned -- but every slice of a long record is packed: a neighbouring
-    // slice's scan starts in it (warm-up)
-    if (A.item_alive && d.len <= kSliceLen && !A.item_alive[item]) return;
+    if (long_only != (d.len > kSliceLen)) continue;
     const uint32_t rev = d.slice_rev >> 31, sl = d.slice_rev & 0x7FFFFFFFu;
     const uint32_t a = sl * kSliceLen;
     const uint32_t b = d.len - a < kSliceLen ? d.len : a + kSliceLen;
@@ -576,7 +581,7 @@ __global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A) {
     const uint32_t w1 = b == d.len ? 2u * ((d.len + 31u) >> 5) : (b >> 4);
     const uint8_t* q = reinterpret_cast<const uint8_t*>(A.qwords);
     const uint8_t* tab = lut + (rev ? 256u : 0u);
-    for (uint32_t w = w0 + sub; w < w1; w += 16u) {
+    for (uint32_t w = w0 + sub; w < w1; w += kLanes) {
         uint32_t whi = 0, wlo = 0;  // the word's two halves: letters 0..7 and 8..15
         const uint32_t p0 = w * 16u;
         if (p0 < d.len) {
@@ -616,6 +621,7 @@ __global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A) {
         }
         out[w] = u64_of(wlo, whi);
     }
+    }
 }
 
 // Letters of one strand from the packed copy (k_pack_queries): a window of 32 letters (one aligned 16-byte load) in
@@ -647,7 +653,8 @@ struct PackedCursor {
 // and -- after a disagreeing letter -- the parent interval on which the letter is retried.  The reference takes these
 // letters one FMI_FollowLetter at a time (slamem.c:121); the output is the same: as long as the letters agree the single
 // row's BWT letter IS the query letter (nothing is left-maximal) and only an ancestor >= min_len could emit.
-enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DEND = 5 };
+// JQ / JT: the first K letters of a scan through the K-mer jump table (query words, then the table entry).
+enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DEND = 5, ST_JQ = 6, ST_JT = 7 };
 
 #ifndef SLAMEM_V3_WAVES
 #define SLAMEM_V3_WAVES 1
@@ -674,10 +681,11 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     const uint64_t k1 = 0x1111111111111111ull;
     const uint64_t cls_add = (uint64_t)(8u - (cL & 7u)) * k1;
     const bool cls_hi = cL >= 8u;
+    const uint32_t jK = (ix.kjump && (int)ix.kjump_k < L && A.use_jump) ? ix.kjump_k : 0u;
 
     // diagnostic instantiation only
     uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_wtrips = 0, n_pos = 0,
-             n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0;
+             n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0, n_jump = 0;
 
     bool active = false, pend = false, dmis = false, dcool = false;
     uint32_t st = ST_EXT;
@@ -731,6 +739,9 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 attempt = 0;
                 j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
                 top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; k = 0; dcool = false;
+                // the first K letters through the jump table: no position that shallow can emit (K < L), and the scan
+                // must have more than K letters before the slice ends
+                if (jK != 0u && j - a_pos > jK) st = ST_JQ;
                 if (d.len == 0) {  // empty record: nothing to scan
                     A.block_counts[g] = 0;
                     A.item_attempt[g] = 0;
@@ -784,6 +795,12 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             } else if (st == ST_DEND) {
                 a1 = reinterpret_cast<const uint4*>(ix.prec + dir_r);
                 if (kStats) n_drec++;
+            } else if (st == ST_JQ) {
+                qs = (int)(j - jK);  // the scan's first K letters: strand positions j-K .. j-1
+                a2 = reinterpret_cast<const uint2*>(reinterpret_cast<const uint64_t*>(qc.p) + (qs >> 4));
+            } else if (st == ST_JT) {
+                a2 = ix.kjump + dir_r;  // (dir_r holds the key between the two trips; one 8-byte entry)
+                if (kStats) n_jump++;
             } else {
                 want_rec = true;  // ST_REC, ST_FLUSH
             }
@@ -794,7 +811,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             }
             if (want_rec) { a1 = R + top; a2 = reinterpret_cast<const uint2*>(R + bot); }
             if (a1) rt = *a1;
-            if (a2) { rb0 = a2[0]; rb1 = a2[1]; }
+            if (a2) { rb0 = a2[0]; if (st != ST_JT) rb1 = a2[1]; }
             if (st == ST_EXT) {
                 if (kStats) n_qloads += qc.would_load(j - 1u);
                 c = qc.at(j - 1u);  // issues the query-window load (if any) behind the ones above
@@ -818,6 +835,29 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 int d = parent_from(rt, rb, top, bot);
                 if (d < 0) { depth = 0; pub = -1; consumed = true; }
                 else { depth = d; pub = d - 1; }
+            } else if (st == ST_JQ) {
+                // K letters, first on top -> 2 bits each (the layout of the table's keys, index_build.hip k_kjump_keys)
+                const uint64_t w0 = u64_of(rb0.x, rb0.y), w1 = u64_of(rb1.x, rb1.y);
+                const uint32_t sh = ((uint32_t)qs & 15u) * 4u;
+                uint64_t x = sh ? (w0 << sh) | (w1 >> (64u - sh)) : w0;
+                const uint64_t v = ((x >> 1) | (x >> 2) | (x >> 3)) & k1;  // nibble >= 2: one of A,C,G,T
+                const uint64_t topk = ~0ull << (4u * (16u - jK));
+                if ((v & topk) == (k1 & topk)) {
+                    x = (x & topk) | (0x2222222222222222ull & ~topk);
+                    x = (x - 0x2222222222222222ull) & topk;
+                    x = (x & 0x0303030303030303ull) | ((x & 0x3030303030303030ull) >> 2);
+                    x = (x & 0x000F000F000F000Full) | ((x & 0x0F000F000F000F00ull) >> 4);
+                    x = (x & 0x000000FF000000FFull) | ((x & 0x00FF000000FF0000ull) >> 8);
+                    x = (x & 0xFFFFull) | ((x >> 16) & 0xFFFF0000ull);
+                    dir_r = (uint32_t)x >> (2u * (16u - jK));
+                    st = ST_JT;
+                } else st = ST_EXT;  // an N among them: letter by letter
+            } else if (st == ST_JT) {
+                st = ST_EXT;
+                if (rb0.x <= rb0.y) {  // the K-mer occurs: K successful extensions from the root (slamem.c:110-129)
+                    top = rb0.x; bot = rb0.y; depth = (int)jK; pub = (int)jK - 1; j -= jK;
+                    if (kStats) n_pos += jK;
+                }
             } else if (st == ST_DSA) {
                 const uint32_t o = top & 3u;
                 dir_r = o == 0u ? rt.x : o == 1u ? rt.y : o == 2u ? rt.z : rt.w;
@@ -992,6 +1032,7 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
         stat_flush<kStats>(A.stats + SC_POSITIONS, n_pos); stat_flush<kStats>(A.stats + SC_ENUM_JOBS, n_enum);
         stat_flush<kStats>(A.stats + SC_DIR_SA, n_dsa); stat_flush<kStats>(A.stats + SC_DIR_GROUPS, n_dgrp);
         stat_flush<kStats>(A.stats + SC_DIR_RECS, n_drec); stat_flush<kStats>(A.stats + SC_DIR_LETTERS, n_dlet);
+        stat_flush<kStats>(A.stats + SC_JUMP_LINES, n_jump);
     }
 }
 
@@ -1432,6 +1473,8 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                 A.direct_min_depth = (idx->view.tgrp && depth_class((int)min_len) >= 1u) ? lg + 3 : -1;
                 if (env_depth > 0 && A.direct_min_depth >= 0) A.direct_min_depth = env_depth;
                 if (env_depth < 0) A.direct_min_depth = -1;
+                static const bool env_jump = [] { const char* v = getenv("SLAMEM_KJUMP_USE"); return !(v && atoi(v) == 0); }();
+                A.use_jump = env_jump ? 1u : 0u;
             }
             static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
             if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
@@ -1453,7 +1496,14 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                 A.work_count = d_nwork;
             }
             STEP(hipMemsetAsync(d_pq, 0, 16, stream), "memset");  // the two leading zero words
-            hipLaunchKernelGGL(k_pack_queries, dim3(grid_for(nitems * 16)), dim3(256), 0, stream, A);  // K7q (uses item_alive)
+            {   // K7q: the strands K8 will scan, packed; then (only if some record was cut into slices) all of those slices
+                uint64_t pb = (nitems * 8 + 255) / 256;
+                hipLaunchKernelGGL(k_pack_queries<8>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, false);
+                if (nitems != num_blocks) {
+                    pb = (nitems * 16 + 255) / 256;
+                    hipLaunchKernelGGL(k_pack_queries<16>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, true);
+                }
+            }
             STEP(hipGetLastError(), "k_pack_queries");
             // persistent waves: enough to fill the chip twice over (256 CUs x 16 waves), fewer for small batches
             uint64_t waves = (nitems + kFetch - 1) / kFetch;
@@ -1501,7 +1551,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             o.query_loads = c[SC_QUERY_LOADS]; o.lane_trips = c[SC_LANE_TRIPS]; o.wave_trips = c[SC_WAVE_TRIPS];
             o.positions = c[SC_POSITIONS]; o.enum_jobs = c[SC_ENUM_JOBS];
             o.dir_sa_lines = c[SC_DIR_SA]; o.dir_group_loads = c[SC_DIR_GROUPS]; o.dir_rec_lines = c[SC_DIR_RECS];
-            o.dir_letters = c[SC_DIR_LETTERS];
+            o.dir_letters = c[SC_DIR_LETTERS]; o.jump_lines = c[SC_JUMP_LINES];
             o.prefilter_probes = c[SC_PF_PROBES]; o.prefilter_query_loads = c[SC_PF_QUERY_LOADS]; o.prefilter_items = c[SC_PF_ITEMS];
             o.items = nitems;
             o.survivors = prefiltered ? nwork : nitems;
