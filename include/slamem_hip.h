@@ -255,6 +255,39 @@ int slamem_find_mams_host(const slamem_index *idx, const char *queries, const ui
                           slamem_mem **mems_out, uint64_t **block_offsets_out, uint64_t *total_out);
 void slamem_host_free(void *p);
 
+/* ---- (b') MEM retrieval, host to host, pipelined -------------------------------
+ * The query loop of GetMatches (slamem.c:90-207) for a front end whose reads live in HOST memory -- the boundary SURVEY.md
+ * 8(d) defines the path's metric on.  A stream is a three-stage pipeline (upload, search, download: one host thread
+ * and one HIP stream each) over `slots` (2..8) sets of device + pinned result buffers: while the search kernels of batch b
+ * run, the copy engines upload batch b+1 and download the MEMs of batch b-1, so the sustained rate is the kernels' rate,
+ * not kernels + PCIe.  Four or five slots keep all three stages busy beside the result the caller is working on.
+ *
+ *   slamem_stream_create   max_batch_chars / max_batch_queries bound every batch; match_type 0 = MEM, 1 = MAM (-mam)
+ *   slamem_stream_submit   record i of the batch is queries[offsets[i] .. offsets[i+1]) -- offsets[0] need not be 0, so
+ *                          a front end passes its whole character buffer and a window of its offsets array.  Returns at
+ *                          once; the characters and offsets must stay unchanged until the batch has been collected.
+ *                          Uploads run at full PCIe rate when `queries` is pinned memory (slamem_pinned_alloc).
+ *                          Never blocks: SLAMEM_ERR_ARG when every slot is in use.
+ *   slamem_stream_next     waits for the OLDEST submitted batch (results come back in submission order) and lends its
+ *                          result: mems grouped by strand block in the reference's emission order and block offsets,
+ *                          laid out as slamem_find_mems_device does, in pinned host memory owned by the stream, valid
+ *                          until the next slamem_stream_next / slamem_stream_destroy call.  A failed batch returns its
+ *                          error code here.  So one thread keeps slots - 1 batches in flight beside the one it works on:
+ *                              submit(0..slots-2);  for b: next(b); submit(b + slots - 1); use result b
+ *   slamem_stream_destroy  waits for the batches in flight, then frees everything.
+ * No CPU fallback: every batch is searched on the GPU. */
+typedef struct slamem_stream slamem_stream;
+int slamem_stream_create(const slamem_index *idx, int slots, uint64_t max_batch_chars, uint32_t max_batch_queries,
+                         int both_strands, int match_type, slamem_stream **out);
+int slamem_stream_submit(slamem_stream *s, const char *queries, const uint64_t *offsets, uint32_t num_queries,
+                         uint32_t min_len);
+int slamem_stream_next(slamem_stream *s, const slamem_mem **mems_out, const uint64_t **block_offsets_out,
+                       uint64_t *total_out, uint32_t *num_queries_out, slamem_timings *timings_out);
+int slamem_stream_destroy(slamem_stream *s);
+/* Page-locked host memory for a front end's read buffers (hipHostMalloc / hipHostFree). */
+int slamem_pinned_alloc(void **out, uint64_t bytes);
+int slamem_pinned_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

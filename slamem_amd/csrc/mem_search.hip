@@ -181,6 +181,8 @@ struct SearchArgs {
     unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
     int32_t direct_min_depth;   // v3: a single-row match at least this deep is extended by comparing with the text (<0: off)
     uint32_t use_jump;          // v3: take the first K letters of a scan through the K-mer jump table
+    uint32_t rows_out;          // v1 / MAM kernels: store rows through the v3 output path (inline slots + overflow list)
+    uint32_t pad4;
 };
 
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
@@ -316,8 +318,15 @@ struct QueryStream {
     }
 };
 
+__device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t tag, uint32_t row,
+                                         uint32_t pos, uint32_t len);
 __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t row, uint32_t j,
                                      uint32_t len) {
+    if (A.rows_out) {  // v3 output path: the BWT row is stored, K9 resolves SA[row]; no returned atomic for the first MEMs
+        emit3_at(A, blockid, k, 0u, row, j, len);
+        k++;
+        return;
+    }
     uint32_t r = A.ix.sa[row];  // FMI_PositionInText
     unsigned long long slot = atomicAdd(A.total, 1ull);  // the compiler aggregates this per wave
     if (slot < A.capacity) {
@@ -674,6 +683,8 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     const uint32_t nitems = A.work_ids ? *A.work_count : (uint32_t)A.num_items;  // (the host refuses batches near 2^32 items)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t next = 0, chunk_first = 0, chunk_end = 0;  // wave-uniform: the piece being handed out
+    uint32_t seen = 0;                                  // wave-uniform: how far this wave has seen the cursor get
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     bool drained = false;                               // wave-uniform: the cursor is past the end of the list
     // direct extension: the class threshold of this launch (flag <=> class >= cL; a parent depth >= L implies it)
     const int dmin = A.direct_min_depth;  // < 0: off
@@ -705,13 +716,19 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
         // ---- hand the next items to idle lanes ----------------------------------------------------------------
         unsigned long long idle = __ballot(!active);
         if (idle != 0ull && next >= chunk_end && !drained) {  // fetch the next piece of the work list
+            // guided self-scheduling: pieces of kFetch items while the list is long, smaller ones (down to 8) towards its
+            // end -- the items a wave has fetched but not yet started are captive to it, and at the end of the list they
+            // are what the other, drained, waves wait for (measured on a 1 M-read batch: +38 % with fixed pieces of 64)
+            uint32_t want = (nitems - seen) / (2u * nwaves) & ~7u;
+            want = want < 8u ? 8u : want > kFetch ? kFetch : want;
             uint32_t base = 0;
-            if (lane == 0u) base = atomicAdd(A.work_cursor, kFetch);
+            if (lane == 0u) base = atomicAdd(A.work_cursor, want);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if (base >= nitems) drained = true;
             else {
                 chunk_first = next = base;
-                chunk_end = nitems - base < kFetch ? nitems : base + kFetch;
+                chunk_end = nitems - base < want ? nitems : base + want;
+                seen = chunk_end;
                 const uint32_t i = chunk_first + lane;
                 if (i < chunk_end) {  // descriptors -> LDS: one coalesced read per wave instead of a round trip per item
                     uint32_t id = A.work_ids ? A.work_ids[i] : (uint32_t)i;
@@ -1505,9 +1522,11 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                 }
             }
             STEP(hipGetLastError(), "k_pack_queries");
-            // persistent waves: enough to fill the chip twice over (256 CUs x 16 waves), fewer for small batches
+            // persistent waves: as many as the chip holds (256 CUs x 16 waves), fewer for small batches
             uint64_t waves = (nitems + kFetch - 1) / kFetch;
-            if (waves > 8192) waves = 8192;
+            static const uint64_t env_waves = [] { const char* v = getenv("SLAMEM_K8_WAVES"); return v ? (uint64_t)atoll(v) : 0ull; }();
+            const uint64_t cap_waves = env_waves ? env_waves : 4096;  // what the chip holds at 4 waves per SIMD: no workgroup waits behind the grid
+            if (waves > cap_waves) waves = cap_waves;
             A.work_cursor = reinterpret_cast<unsigned int*>(d_total + 5);  // a word of the zeroed scalar block
             (void)hipEventRecord(ek, stream);
             timed_k8 = true;
@@ -1515,6 +1534,8 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             else hipLaunchKernelGGL(k_find_mems_v3<false>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
             STEP(hipGetLastError(), "k_find_mems_v3");
         } else if (nitems && match_type == 1) {
+            A.rows_out = 1;  // K9 of the v3 path places the MAMs and resolves their rows
+            STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
             hipLaunchKernelGGL(k_find_mams, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
             STEP(hipGetLastError(), "k_find_mams");
         } else if (nitems) {
@@ -1566,7 +1587,7 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
             set_error("slamem_find_mems_device: %llu MEMs found, output capacity is %llu", (unsigned long long)*total_out,
                       (unsigned long long)mems_capacity);
             rc = SLAMEM_ERR_CAPACITY;
-        } else if (kernel_version == 3) {
+        } else if (kernel_version == 3 || match_type == 1) {
             if (total) {
                 hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
                                    d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);

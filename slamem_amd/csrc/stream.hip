@@ -1,0 +1,332 @@
+// stream.hip -- host-to-host MEM retrieval, pipelined: the form of GetMatches' query loop (slamem.c:90-207) that a
+// front end with its reads in HOST memory calls.  SURVEY.md 8(d) defines the path's metric on exactly this boundary
+// ("reads resident in host memory -> MEM triples in host memory").
+//
+// A slamem_stream is a three-stage pipeline over `slots` (2-8) sets of buffers: an UPLOAD thread copies a batch's
+// characters to the device (straight from the caller's memory: at full PCIe rate when that memory is pinned,
+// slamem_pinned_alloc), a SEARCH thread runs slamem_find_mems_device on it, a DOWNLOAD thread copies the MEMs into pinned
+// host memory -- each stage on its own HIP stream, each taking the batches in submission order.  With enough batches in
+// flight the copy engines move batch b+1 up and batch b-1 down while the search kernels of batch b have the whole GPU,
+// so the sustained rate is the kernels' rate, not kernels + PCIe.  (One thread per SLOT doing upload, search and download
+// in turn was measured first: the slots fall into lockstep -- all upload together, then all search together -- and
+// nothing overlaps: 62 ms where this pipeline takes 37.)  No CPU fallback: every batch is searched on the GPU.
+#include "common.h"
+
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+
+namespace slamem {
+
+namespace {
+
+enum SlotState { FREE = 0, QUEUED = 1, UPLOADED = 2, COMPUTED = 3, DONE = 4, RETURNED = 5 };
+constexpr int kMaxSlots = 8;
+
+struct Slot {
+    int state = FREE;
+    // device
+    void* d_q = nullptr;
+    uint64_t* d_off = nullptr;
+    uint64_t* d_boff = nullptr;
+    slamem_mem* d_mems = nullptr;
+    void* d_ws = nullptr;
+    uint64_t cap = 0, ws_bytes = 0;
+    // pinned host
+    uint64_t* h_boff = nullptr;
+    slamem_mem* h_mems = nullptr;
+    uint64_t h_cap = 0;
+    // the batch
+    uint64_t seq = 0;
+    const char* chars = nullptr;
+    const uint64_t* offs = nullptr;
+    uint32_t nq = 0, min_len = 0;
+    // its result
+    uint64_t total = 0;
+    int rc = SLAMEM_OK;
+    char err[512] = "";
+    slamem_timings tm;
+};
+
+}  // namespace
+
+}  // namespace slamem
+
+using namespace slamem;
+
+struct slamem_stream {
+    const slamem_index* idx = nullptr;
+    int nslots = 0, both = 0, match_type = 0;
+    uint64_t max_chars = 0;
+    uint32_t max_q = 0;
+    Slot slot[kMaxSlots];
+    std::thread th[4];            // upload, search (even batches), search (odd batches), download
+    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t submitted = 0, returned = 0;  // batches handed in / handed back
+    bool stop = false, trace = false;
+    std::chrono::steady_clock::time_point t0;
+};
+
+namespace slamem {
+namespace {
+
+// Buffers are allocated by the stage that uses them, on a slot's first batch (and again if a batch needs more room):
+// setting a stream up costs nothing, the allocations (pinned host memory above all: ~0.1 ms per MB) overlap with the
+// other stages' work, and slots that are never used are never allocated.
+int grow_outputs(slamem_stream* s, Slot& sl, uint64_t need_cap) {  // search stage: device output + workspace
+    if (sl.d_mems) (void)hipFree(sl.d_mems);
+    if (sl.d_ws) (void)hipFree(sl.d_ws);
+    sl.d_mems = nullptr; sl.d_ws = nullptr;
+    sl.cap = need_cap;
+    sl.ws_bytes = find_mems_workspace_bytes(s->max_q, s->both, s->max_chars, sl.cap);
+    SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_mems), sl.cap * sizeof(slamem_mem) + 16));
+    SLAMEM_HIP(hipMalloc(&sl.d_ws, sl.ws_bytes));
+    return SLAMEM_OK;
+}
+
+// stage 0: characters and offsets to the device.  The offsets go up as the caller holds them (absolute): the characters land
+// at d_q + kFront + (base mod 16) and the kernels get the pointer that record offset `base` maps to -- 16-byte aligned like
+// the caller's buffer start, so nothing is rebased on the host (a loop over a million offsets per batch made this stage
+// the pipeline's bottleneck).
+constexpr uint64_t kFront = 32;  // bytes in front of the characters: the kernels read whole aligned words around a record
+inline const char* device_queries(const Slot& sl) {
+    const uint64_t base = sl.offs[0];
+    return static_cast<const char*>(sl.d_q) + kFront + (base & 15u) - base;
+}
+int stage_upload(slamem_stream* s, Slot& sl) {
+    const uint64_t base = sl.offs[0], qbytes = sl.offs[sl.nq] - base;
+    if (!sl.d_q) {
+        const uint64_t nb = (uint64_t)s->max_q * (s->both ? 2 : 1);
+        SLAMEM_HIP(hipMalloc(&sl.d_q, s->max_chars + 2 * kFront + 32));
+        SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_off), ((uint64_t)s->max_q + 1) * 8));
+        SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_boff), (nb + 1) * 8));
+    }
+    if (qbytes)
+        SLAMEM_HIP(hipMemcpyAsync(static_cast<char*>(sl.d_q) + kFront + (base & 15u), sl.chars + base, qbytes, hipMemcpyHostToDevice, s->st[0]));
+    SLAMEM_HIP(hipMemcpyAsync(sl.d_off, sl.offs, ((uint64_t)sl.nq + 1) * 8, hipMemcpyHostToDevice, s->st[0]));
+    SLAMEM_HIP(hipStreamSynchronize(s->st[0]));
+    return SLAMEM_OK;
+}
+
+// stage 1: K8a + K7q + K8 + K9 (synchronous with respect to its stream).  Two threads share this stage, one for the even
+// and one for the odd batches, each on its own stream: the head of batch b+1 (work-item tables, prefilter) fills the GPU
+// while the last waves of batch b's search drain, and the launch gaps of one hide behind the kernels of the other.
+int stage_search(slamem_stream* s, Slot& sl, hipStream_t st) {
+    const uint64_t qbytes = sl.offs[sl.nq] - sl.offs[0];
+    int rc = SLAMEM_OK;
+    if (!sl.d_ws) {  // first guess of the room for MEMs: grown when a batch needs more (SLAMEM_ERR_CAPACITY tells how much)
+        const uint64_t nb = (uint64_t)s->max_q * (s->both ? 2 : 1);
+        rc = grow_outputs(s, sl, s->max_chars / 32 + nb + 1024);
+        if (rc != SLAMEM_OK) return rc;
+    }
+    (void)slamem_reset_timings();
+    for (int attempt = 0; attempt < 3; attempt++) {
+        rc = find_mems_device(s->idx, device_queries(sl), sl.d_off, sl.nq, qbytes, sl.min_len, s->both, s->match_type, sl.d_mems, sl.cap,
+                              sl.d_boff, sl.d_ws, sl.ws_bytes, st, &sl.total);
+        if (rc != SLAMEM_ERR_CAPACITY || sl.total <= sl.cap) break;
+        int g = grow_outputs(s, sl, sl.total + sl.total / 8 + 1024);  // rare: the first guess was too small
+        if (g != SLAMEM_OK) return g;
+    }
+    (void)slamem_get_timings(&sl.tm);
+    return rc;
+}
+
+// stage 2: MEMs and block offsets to pinned host memory
+int stage_download(slamem_stream* s, Slot& sl) {
+    const uint64_t nb = (uint64_t)sl.nq * (s->both ? 2 : 1);
+    if (!sl.h_boff) SLAMEM_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_boff), ((uint64_t)s->max_q * (s->both ? 2 : 1) + 1) * 8, hipHostMallocDefault));
+    if (sl.h_cap < sl.cap || !sl.h_mems) {
+        if (sl.h_mems) (void)hipHostFree(sl.h_mems);
+        sl.h_mems = nullptr;
+        SLAMEM_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_mems), sl.cap * sizeof(slamem_mem) + 16, hipHostMallocDefault));
+        sl.h_cap = sl.cap;
+    }
+    if (sl.total) SLAMEM_HIP(hipMemcpyAsync(sl.h_mems, sl.d_mems, sl.total * sizeof(slamem_mem), hipMemcpyDeviceToHost, s->st[3]));
+    SLAMEM_HIP(hipMemcpyAsync(sl.h_boff, sl.d_boff, (nb + 1) * 8, hipMemcpyDeviceToHost, s->st[3]));
+    SLAMEM_HIP(hipStreamSynchronize(s->st[3]));
+    return SLAMEM_OK;
+}
+
+// thread 0 uploads, threads 1 and 2 search the even / odd batches, thread 3 downloads; each takes its batches in
+// submission order
+void worker(slamem_stream* s, int t) {
+    const int want = t == 0 ? QUEUED : t == 3 ? COMPUTED : UPLOADED;
+    const int done = t == 0 ? UPLOADED : t == 3 ? DONE : COMPUTED;
+    const uint64_t first = t == 2 ? 1 : 0, step = (t == 1 || t == 2) ? 2 : 1;
+    (void)hipSetDevice(s->idx->device);
+    for (uint64_t seq = first;; seq += step) {
+        Slot& sl = s->slot[seq % (uint64_t)s->nslots];
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv.wait(lk, [&] { return s->stop || (sl.state == want && sl.seq == seq && seq < s->submitted); });
+            if (s->stop) return;
+        }
+        int rc = sl.rc;  // a batch that failed in an earlier stage passes through untouched
+        const auto t_begin = std::chrono::steady_clock::now();
+        if (rc == SLAMEM_OK) {
+            rc = t == 0 ? stage_upload(s, sl) : t == 3 ? stage_download(s, sl) : stage_search(s, sl, s->st[t]);
+            if (rc != SLAMEM_OK) snprintf(sl.err, sizeof(sl.err), "%s", slamem_last_error_message());  // the text is per thread
+        }
+        if (s->trace) {  // SLAMEM_STREAM_TRACE=1: when every stage worked on every batch (ms since the stream was created)
+            const auto t_end = std::chrono::steady_clock::now();
+            fprintf(stderr, "[stream] batch %3llu %-8s %9.3f .. %9.3f ms\n", (unsigned long long)seq,
+                    t == 0 ? "upload" : t == 3 ? "download" : "search",
+                    std::chrono::duration<double, std::milli>(t_begin - s->t0).count(),
+                    std::chrono::duration<double, std::milli>(t_end - s->t0).count());
+        }
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            sl.rc = rc;
+            sl.state = done;
+        }
+        s->cv.notify_all();
+    }
+}
+
+void free_slot(Slot& sl) {
+    if (sl.d_q) (void)hipFree(sl.d_q);
+    if (sl.d_off) (void)hipFree(sl.d_off);
+    if (sl.d_boff) (void)hipFree(sl.d_boff);
+    if (sl.d_mems) (void)hipFree(sl.d_mems);
+    if (sl.d_ws) (void)hipFree(sl.d_ws);
+    if (sl.h_boff) (void)hipHostFree(sl.h_boff);
+    if (sl.h_mems) (void)hipHostFree(sl.h_mems);
+}
+
+}  // namespace
+}  // namespace slamem
+
+extern "C" {
+
+int slamem_pinned_alloc(void** out, uint64_t bytes) {
+    if (!out) return SLAMEM_ERR_ARG;
+    *out = nullptr;
+    SLAMEM_HIP(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return SLAMEM_OK;
+}
+
+int slamem_pinned_free(void* p) {
+    if (p) SLAMEM_HIP(hipHostFree(p));
+    return SLAMEM_OK;
+}
+
+int slamem_stream_destroy(slamem_stream* s) {
+    if (!s) return SLAMEM_OK;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        // batches in flight finish first: never tear buffers down under a running kernel
+        s->cv.wait(lk, [&] {
+            for (int k = 0; k < s->nslots; k++)
+                if (s->slot[k].state == QUEUED || s->slot[k].state == UPLOADED || s->slot[k].state == COMPUTED) return false;
+            return true;
+        });
+        s->stop = true;
+    }
+    s->cv.notify_all();
+    for (int k = 0; k < 4; k++)
+        if (s->th[k].joinable()) s->th[k].join();
+    (void)hipSetDevice(s->idx->device);
+    for (int k = 0; k < s->nslots; k++) free_slot(s->slot[k]);
+    for (int k = 0; k < 4; k++)
+        if (s->st[k]) (void)hipStreamDestroy(s->st[k]);
+    delete s;
+    return SLAMEM_OK;
+}
+
+int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_chars, uint32_t max_batch_queries,
+                         int both_strands, int match_type, slamem_stream** out) {
+    if (!idx || !out || slots < 2 || slots > kMaxSlots || max_batch_queries == 0 || (match_type != 0 && match_type != 1)) {
+        set_error("slamem_stream_create: bad argument (2..8 slots, at least one query per batch, match type 0 or 1)");
+        return SLAMEM_ERR_ARG;
+    }
+    *out = nullptr;
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    slamem_stream* s = new (std::nothrow) slamem_stream();
+    if (!s) { set_error("out of host memory"); return SLAMEM_ERR_NOMEM; }
+    s->idx = idx;
+    s->trace = getenv("SLAMEM_STREAM_TRACE") != nullptr;
+    s->t0 = std::chrono::steady_clock::now();
+    s->nslots = slots;
+    s->both = both_strands ? 1 : 0;
+    s->match_type = match_type;
+    s->max_chars = max_batch_chars;
+    s->max_q = max_batch_queries;
+    int rc = SLAMEM_OK;
+    for (int k = 0; k < 4; k++) {
+        hipError_t e = hipStreamCreateWithFlags(&s->st[k], hipStreamNonBlocking);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
+    }
+    if (rc != SLAMEM_OK) {
+        for (int k = 0; k < slots; k++) free_slot(s->slot[k]);
+        for (int k = 0; k < 4; k++)
+            if (s->st[k]) (void)hipStreamDestroy(s->st[k]);
+        delete s;
+        return rc;
+    }
+    for (int k = 0; k < 4; k++) s->th[k] = std::thread(worker, s, k);
+    *out = s;
+    return SLAMEM_OK;
+}
+
+int slamem_stream_submit(slamem_stream* s, const char* queries, const uint64_t* offsets, uint32_t num_queries, uint32_t min_len) {
+    if (!s || !offsets || (num_queries && !queries)) { set_error("slamem_stream_submit: null argument"); return SLAMEM_ERR_ARG; }
+    if (num_queries > s->max_q || offsets[num_queries] - offsets[0] > s->max_chars) {
+        set_error("slamem_stream_submit: batch of %u records / %llu characters exceeds the stream's limits (%u / %llu)", num_queries,
+                  (unsigned long long)(offsets[num_queries] - offsets[0]), s->max_q, (unsigned long long)s->max_chars);
+        return SLAMEM_ERR_ARG;
+    }
+    if (min_len < 1) { set_error("slamem_stream_submit: minimum MEM length must be >= 1"); return SLAMEM_ERR_ARG; }
+    std::unique_lock<std::mutex> lk(s->mu);
+    Slot& sl = s->slot[s->submitted % (uint64_t)s->nslots];
+    if (sl.state != FREE) {
+        // a slot is released by the slamem_stream_next call AFTER the one that handed its result out: at most slots - 1
+        // batches may be in flight beside the result the caller is working on.  Never blocks (a caller that both submits
+        // and collects on one thread would wait for itself).
+        set_error("slamem_stream_submit: all %d slots are in use (collect a result with slamem_stream_next first)", s->nslots);
+        return SLAMEM_ERR_ARG;
+    }
+    sl.seq = s->submitted;
+    sl.chars = queries;
+    sl.offs = offsets;
+    sl.nq = num_queries;
+    sl.min_len = min_len;
+    sl.rc = SLAMEM_OK;
+    sl.err[0] = 0;
+    sl.total = 0;
+    sl.state = QUEUED;
+    s->submitted++;
+    lk.unlock();
+    s->cv.notify_all();
+    return SLAMEM_OK;
+}
+
+int slamem_stream_next(slamem_stream* s, const slamem_mem** mems_out, const uint64_t** block_offsets_out, uint64_t* total_out,
+                       uint32_t* num_queries_out, slamem_timings* timings_out) {
+    if (!s || !mems_out || !block_offsets_out || !total_out) { set_error("slamem_stream_next: null argument"); return SLAMEM_ERR_ARG; }
+    std::unique_lock<std::mutex> lk(s->mu);
+    // the result handed out by the previous call goes back to the pool
+    if (s->returned > 0) {
+        Slot& prev = s->slot[(s->returned - 1) % (uint64_t)s->nslots];
+        if (prev.state == RETURNED) { prev.state = FREE; s->cv.notify_all(); }
+    }
+    if (s->returned == s->submitted) { set_error("slamem_stream_next: no batch is pending"); return SLAMEM_ERR_ARG; }
+    Slot& sl = s->slot[s->returned % (uint64_t)s->nslots];
+    s->cv.wait(lk, [&] { return sl.state == DONE; });
+    sl.state = RETURNED;
+    s->returned++;
+    *mems_out = sl.h_mems;
+    *block_offsets_out = sl.h_boff;
+    *total_out = sl.total;
+    if (num_queries_out) *num_queries_out = sl.nq;
+    if (timings_out) *timings_out = sl.tm;
+    if (sl.rc != SLAMEM_OK) set_error("%s", sl.err);
+    return sl.rc;
+}
+
+}  // extern "C"

@@ -254,6 +254,127 @@ class Matcher:
         return self.last_total
 
 
+class PinnedBuffer:
+    """Page-locked host memory from slamem_pinned_alloc, viewed as a numpy uint8 array (a front end's read buffer)."""
+
+    def __init__(self, nbytes: int):
+        self._p = C.c_void_p()
+        capi.check(capi.lib().slamem_pinned_alloc(C.byref(self._p), int(nbytes)))
+        self.nbytes = int(nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self._p.value))
+
+    def close(self):
+        p, self._p = self._p, None
+        if p:
+            self.array = None
+            capi.lib().slamem_pinned_free(p)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stream:
+    """slamem_stream_*: host-to-host MEM retrieval, pipelined over `slots` lanes (include/slamem_hip.h).  Replaces the
+    query loop of GetMatches (slamem.c:90-207) for reads that live in host memory."""
+
+    def __init__(self, index: Index, slots: int, max_batch_chars: int, max_batch_queries: int, both_strands: bool,
+                 mam: bool = False):
+        self.index = index
+        self.both = bool(both_strands)
+        self._h = C.c_void_p()
+        capi.check(capi.lib().slamem_stream_create(index._h, int(slots), int(max_batch_chars), int(max_batch_queries),
+                                                   int(self.both), int(bool(mam)), C.byref(self._h)))
+        self._keep = []
+
+    def submit(self, chars: np.ndarray, offsets: np.ndarray, min_len: int) -> None:
+        """chars: uint8 array holding the records; offsets: uint64[num+1] into it (offsets[0] need not be 0)."""
+        assert chars.dtype == np.uint8 and offsets.dtype == np.uint64 and offsets.flags.c_contiguous
+        self._keep.append((chars, offsets))  # must stay alive and unchanged until collected
+        capi.check(capi.lib().slamem_stream_submit(self._h, chars.ctypes.data, offsets.ctypes.data, offsets.shape[0] - 1,
+                                                   int(min_len)))
+
+    def next(self, copy: bool = True):
+        """(mems structured array, block_offsets uint64 array, timings dict) of the oldest batch.  copy=False returns
+        views of the stream's pinned buffers, valid until the next call."""
+        mems, boff, total, nq, tm = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint32(), capi.Timings()
+        rc = capi.lib().slamem_stream_next(self._h, C.byref(mems), C.byref(boff), C.byref(total), C.byref(nq), C.byref(tm))
+        if self._keep:
+            self._keep.pop(0)
+        capi.check(rc)
+        nb = nq.value * (2 if self.both else 1)
+        m = np.ctypeslib.as_array((C.c_uint8 * (12 * max(1, total.value))).from_address(mems.value))[: 12 * total.value]
+        m = m.view(MEM_DTYPE)
+        b = np.ctypeslib.as_array((C.c_uint64 * (nb + 1)).from_address(boff.value))
+        if copy:
+            m, b = m.copy(), b.copy()
+        return m, b, tm.as_dict()
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            capi.lib().slamem_stream_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len: int, min_len: int, both: bool,
+                     steps: int = 2, batch_reads: int = 1_000_000, slots: int = 6) -> dict:
+    """SURVEY.md 8(d)'s metric as defined -- reads resident in host memory -> MEM triples in host memory -- through
+    slamem_stream_*: the reads sit in pinned host memory, batches of `batch_reads` are pipelined over `slots` lanes, and
+    the clock runs from the first submit to the last result.  Returns fields for the bench line."""
+    import time
+    L = read_len
+    buf = PinnedBuffer(count * L + 64)
+    buf.array[: count * L] = reads_dev[: count * L].cpu().numpy()
+    offsets = (np.arange(count + 1, dtype=np.uint64) * np.uint64(L))
+    # batch boundaries: two short batches first (the pipeline starts searching after a quarter of a batch is up)
+    cuts, pos = [0], 0
+    for size in (batch_reads // 4, batch_reads // 2):
+        if 0 < size and pos + size < count:
+            pos += size
+            cuts.append(pos)
+    while pos < count:
+        pos = min(count, pos + batch_reads)
+        cuts.append(pos)
+    nb = len(cuts) - 1
+    st = Stream(index, slots, batch_reads * L, batch_reads, both)
+    best, total_mems, kernel_ms = None, 0, 0.0
+    try:
+        for rep in range(steps + 1):  # first pass warms the stream's buffers up
+            t0 = time.perf_counter()
+            got, kms = 0, 0.0
+            for b in range(min(slots - 1, nb)):
+                st.submit(buf.array, offsets[cuts[b]: cuts[b + 1] + 1], min_len)
+            for b in range(nb):
+                m, _, tm = st.next(copy=False)
+                got += len(m)
+                kms += tm["search_kernel_ms"]
+                nxt = b + slots - 1
+                if nxt < nb:
+                    st.submit(buf.array, offsets[cuts[nxt]: cuts[nxt + 1] + 1], min_len)
+            dt = time.perf_counter() - t0
+            if rep and (best is None or dt < best):
+                best = dt
+            total_mems, kernel_ms = got, kms
+    finally:
+        st.close()
+        buf.close()
+    return {"value_host_to_host": total_mems / best, "host_to_host_ms": best * 1e3, "host_to_host_mems": int(total_mems),
+            "host_to_host": {"batches": nb, "batch_reads": batch_reads, "slots": slots, "h2d_bytes": count * L,
+                             "d2h_bytes": 12 * int(total_mems) + 8 * (count * (2 if both else 1) + nb),
+                             "kernel_ms_sum": kernel_ms,
+                             "note": "reads in pinned host memory -> MEMs in pinned host memory through slamem_stream_* "
+                                     "(uploads, kernels and downloads of neighbouring batches overlap); best of "
+                                     f"{steps} passes over the same {count} reads"}}
+
+
 def timings() -> dict:
     t = capi.Timings()
     capi.check(capi.lib().slamem_get_timings(C.byref(t)))

@@ -8,7 +8,8 @@
  *
  * Environment: SLAMEM_DEVICE (default 0) selects the GPU; SLAMEM_VERBOSE=1 prints one line per loaded
  * record and per strand for any number of records, as the reference does (default: first 100 only);
- * SLAMEM_BATCH_MB bounds the query characters sent to the GPU per batch (default 1024).
+ * SLAMEM_BATCH_MB bounds the query characters sent to the GPU per batch (default 256); SLAMEM_FULL_TEARDOWN=1 frees
+ * every buffer and the index before returning (default: the process ends with _exit once the output is written).
  */
 #include <stdio.h>
 #include <unistd.h>
@@ -17,6 +18,7 @@
 #include <time.h>
 
 #include <pthread.h>
+#include <dlfcn.h>
 
 #include "../../include/slamem_hip.h"
 #include "../../include/slamem_rccl.h"
@@ -69,11 +71,34 @@ typedef struct {
     int failed;
 } fmt_job;
 
+/* Text buffers go round: formatter -> writer -> pool -> formatter.  A fresh 20 MB buffer costs its page faults every
+ * time (the output of the reference-sized run is 638 MB); a recycled one is already mapped. */
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static slh_buffer g_pool[64];
+static int g_pool_n = 0;
+static void pool_put(slh_buffer *b) {
+    pthread_mutex_lock(&g_pool_mu);
+    if (b->data && g_pool_n < 64) { b->len = 0; g_pool[g_pool_n++] = *b; b->data = NULL; }
+    pthread_mutex_unlock(&g_pool_mu);
+    if (b->data) slh_buffer_free(b);
+    b->data = NULL; b->len = b->cap = 0;
+}
+static void pool_get(slh_buffer *b, size_t need) {
+    int i, best = -1;
+    pthread_mutex_lock(&g_pool_mu);
+    for (i = 0; i < g_pool_n; i++)
+        if (g_pool[i].cap >= need && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
+    if (best >= 0) { *b = g_pool[best]; g_pool[best] = g_pool[--g_pool_n]; }
+    pthread_mutex_unlock(&g_pool_mu);
+}
+
 static void *fmt_run(void *arg) {
     fmt_job *j = (fmt_job *)arg;
     uint64_t b;
     /* about 36 characters per MEM line and a header per block: reserve once instead of doubling on the way */
-    (void)slh_buffer_reserve(&j->buf, (size_t)(j->boff[j->b1] - j->boff[j->b0]) * 36 + (size_t)(j->b1 - j->b0) * 48 + 4096);
+    const size_t need = (size_t)(j->boff[j->b1] - j->boff[j->b0]) * 36 + (size_t)(j->b1 - j->b0) * 48 + 4096;
+    pool_get(&j->buf, need);
+    (void)slh_buffer_reserve(&j->buf, need);
     for (b = j->b0; b < j->b1; b++) {
         int i = j->first_rec + (int)(b / (uint64_t)j->strands), s = (int)(b % (uint64_t)j->strands);
         uint64_t cnt = j->boff[b + 1] - j->boff[b], sum = 0;
@@ -82,28 +107,6 @@ static void *fmt_run(void *arg) {
         j->matches += (long long)cnt;
         j->sum += (long long)sum;
     }
-    return NULL;
-}
-
-/* one contiguous share of a batch's records, searched on one GPU by one host thread */
-typedef struct {
-    slamem_index *idx;
-    const char *chars;
-    uint64_t *offs;
-    int first, last; /* records [first,last) of the query set */
-    uint32_t min_len;
-    int both, mam;
-    slamem_mem *mems;
-    uint64_t *boff, total;
-    int rc;
-    char err[512];
-} gpu_part;
-
-static void *gpu_part_run(void *arg) {
-    gpu_part *g = (gpu_part *)arg;
-    g->rc = (g->mam ? slamem_find_mams_host : slamem_find_mems_host)(g->idx, g->chars, g->offs, (uint32_t)(g->last - g->first),
-                                                                     g->min_len, g->both, &g->mems, &g->boff, &g->total);
-    if (g->rc != SLAMEM_OK) snprintf(g->err, sizeof(g->err), "%s", slamem_last_error_message()); /* the message is per thread */
     return NULL;
 }
 
@@ -136,60 +139,96 @@ static void *build_run(void *arg) {
     return NULL;
 }
 
-/* One batch of query records: its shares are searched on the GPUs by their own host threads while the main thread
- * formats and writes the batch before it (GPU(b+1) overlaps format(b)). */
+/* The output file is written by its own thread: the main thread hands over formatted buffers in order and goes on
+ * formatting the next ones (GPU(b+1), format(b) and write(b-1) overlap; the reference does everything in one loop,
+ * slamem.c:90-207). */
+typedef struct wnode {
+    slh_buffer buf;
+    struct wnode *next;
+} wnode;
 typedef struct {
-    const slh_seqset *q;
-    int first, last, nparts;
-    gpu_part parts[16];
-    pthread_t tid[16];
-    int threaded[16];
-} batch_t;
+    FILE *out;
+    pthread_t tid;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    wnode *head, *tail;
+    size_t queued; /* bytes waiting */
+    int done, failed, started;
+    double seconds;
+} writer_t;
 
-static batch_t *batch_start(const slh_seqset *q, int first, int last, slamem_index **gpus, int ngpu, uint32_t min_len,
-                            int both, int mam) {
-    batch_t *b = (batch_t *)calloc(1, sizeof(batch_t));
-    uint64_t base = q->offsets[first], tot = q->offsets[last] - base;
-    int part, r0 = first, i;
-    if (!b) return NULL;
-    b->q = q; b->first = first; b->last = last; b->nparts = ngpu;
-    for (part = 0; part < ngpu; part++) { /* contiguous shares with (almost) equal numbers of bases, one per GPU */
-        uint64_t target = base + tot * (uint64_t)(part + 1) / (uint64_t)ngpu;
-        int r1 = r0;
-        gpu_part *g = &b->parts[part];
-        if (part == ngpu - 1) r1 = last;
-        else while (r1 < last && q->offsets[r1 + 1] <= target) r1++;
-        g->idx = gpus[part];
-        g->first = r0;
-        g->last = r1;
-        g->chars = q->chars + q->offsets[r0];
-        g->offs = (uint64_t *)malloc(((size_t)(r1 - r0) + 1) * sizeof(uint64_t));
-        if (!g->offs) return NULL;
-        for (i = r0; i <= r1; i++) g->offs[i - r0] = q->offsets[i] - q->offsets[r0];
-        g->min_len = min_len;
-        g->both = both;
-        g->mam = mam;
-        r0 = r1;
+static void *writer_run(void *arg) {
+    writer_t *w = (writer_t *)arg;
+    for (;;) {
+        wnode *n;
+        double t0;
+        pthread_mutex_lock(&w->mu);
+        while (!w->head && !w->done) pthread_cond_wait(&w->cv, &w->mu);
+        n = w->head;
+        if (n) { w->head = n->next; if (!w->head) w->tail = NULL; }
+        pthread_mutex_unlock(&w->mu);
+        if (!n) return NULL;
+        t0 = now_s();
+        if (n->buf.len && !w->failed && fwrite(n->buf.data, 1, n->buf.len, w->out) != n->buf.len) w->failed = 1;
+        w->seconds += now_s() - t0;
+        pthread_mutex_lock(&w->mu);
+        w->queued -= n->buf.len;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        pool_put(&n->buf);
+        free(n);
     }
-    for (part = 0; part < ngpu; part++) {
-        b->threaded[part] = pthread_create(&b->tid[part], NULL, gpu_part_run, &b->parts[part]) == 0;
-        if (!b->threaded[part]) gpu_part_run(&b->parts[part]);
-    }
-    return b;
 }
 
-static void batch_join(batch_t *b, int device) {
-    int part;
-    for (part = 0; part < b->nparts; part++) {
-        if (b->threaded[part]) pthread_join(b->tid[part], NULL);
-        b->threaded[part] = 0;
+/* takes ownership of *buf (and leaves it empty); waits while more than 1 GiB of text is queued */
+static int writer_push(writer_t *w, slh_buffer *buf) {
+    wnode *n;
+    if (!buf->len) return 0;
+    n = (wnode *)calloc(1, sizeof(wnode));
+    if (!n) return -1;
+    n->buf = *buf;
+    buf->data = NULL; buf->len = buf->cap = 0;
+    if (!w->started) { /* no thread: write here */
+        int bad = fwrite(n->buf.data, 1, n->buf.len, w->out) != n->buf.len;
+        if (bad) w->failed = 1;
+        slh_buffer_free(&n->buf);
+        free(n);
+        return 0;
     }
-    for (part = 0; part < b->nparts; part++)
-        if (b->parts[part].rc != SLAMEM_OK) {
-            printf("\n> ERROR: MEM search on GPU %d failed: %s (%s)\n", device + part, slamem_strerror(b->parts[part].rc),
-                   b->parts[part].err);
-            exit(-1);
-        }
+    pthread_mutex_lock(&w->mu);
+    while (w->queued > ((size_t)1 << 30)) pthread_cond_wait(&w->cv, &w->mu);
+    if (w->tail) w->tail->next = n; else w->head = n;
+    w->tail = n;
+    w->queued += n->buf.len;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+    return 0;
+}
+
+static void writer_finish(writer_t *w) {
+    if (!w->started) return;
+    pthread_mutex_lock(&w->mu);
+    w->done = 1;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+    pthread_join(w->tid, NULL);
+    w->started = 0;
+}
+
+/* every exit after the search has started goes through here: batches in flight finish first (slamem_stream_destroy
+ * waits for them), the writer drains -- never leave the process with kernels running or a thread writing */
+static slamem_stream *g_streams[16];
+static int g_nstreams = 0;
+static writer_t g_writer;
+static void shutdown_pipeline(void) {
+    int g;
+    for (g = 0; g < g_nstreams; g++) { slamem_stream_destroy(g_streams[g]); g_streams[g] = NULL; }
+    g_nstreams = 0;
+    writer_finish(&g_writer);
+}
+static void pipeline_fail(const char *msg) {
+    shutdown_pipeline();
+    exit_message(msg);
 }
 
 static void *warmup_run(void *arg) { /* HIP runtime + context start-up, hidden behind the parsing of the reference file */
@@ -284,9 +323,11 @@ int main(int argc, char **argv) {
         }
     }
     t_load = now_s() - t_start;
+    double t_join0 = now_s();
     if (build_async) pthread_join(build_tid, NULL); /* before any exit: never leave the process with a build in flight */
     else build_run(&bj);
     join_warmup();
+    double t_join = now_s() - t_join0, t_streams = 0;
     if (num_qsets == 0) exit_message("No query files provided"); /* slamem.c:648 */
     printf("> %d reference%s and %d quer%s successfully loaded\n", ref.num, ref.num == 1 ? "" : "s", total_queries,
            total_queries == 1 ? "y" : "ies");
@@ -347,7 +388,18 @@ int main(int argc, char **argv) {
         int devs[16], g;
         double tr = now_s();
         for (g = 0; g < ngpu; g++) devs[g] = device + g;
-        rc = slamem_index_replicate(idx, devs, ngpu, ngpu == 1, gpus);
+        {   /* libslamem_rccl.so (and RCCL behind it, hundreds of MB of code) is loaded only when it is needed: a
+               one-GPU run never pays for it at start-up */
+            typedef int (*replicate_fn)(const slamem_index *, const int *, int, int, slamem_index **);
+            void *h = dlopen("libslamem_rccl.so", RTLD_NOW | RTLD_GLOBAL);
+            replicate_fn fn = h ? (replicate_fn)dlsym(h, "slamem_index_replicate") : NULL;
+            if (!fn) {
+                printf("\n> ERROR: cannot load libslamem_rccl.so (%s)\n", dlerror());
+                join_warmup();
+                exit(-1);
+            }
+            rc = fn(idx, devs, ngpu, ngpu == 1, gpus);
+        }
         if (rc != SLAMEM_OK) gpu_fail("index replication over RCCL", rc);
         if (ngpu == 1) { slamem_index_free(idx); idx = gpus[0]; } /* self-test: search on the broadcast copy */
         printf("> Index replicated to %d GPU%s by RCCL broadcast ... OK (%.3f s)\n", ngpu, ngpu == 1 ? " (self-test copy)" : "s", now_s() - tr);
@@ -361,148 +413,169 @@ int main(int argc, char **argv) {
     {
         int strands = o.both_strands ? 2 : 1;
         long printed = 0;
-        /* the list of batches (records [first,last) of one query file each), then a two-stage pipeline over it */
+        /* the list of batches (records [first,last) of one query file each), then a pipeline over it: the GPUs search
+           batches b+1.. (slamem_stream_*: upload, search and download of neighbouring batches overlap), the main thread
+           formats batch b with all host threads, the writer thread writes batch b-1 */
         typedef struct { int f, first, last; } batch_range;
         batch_range *ranges = NULL;
-        size_t nranges = 0, cap_ranges = 0, bi;
-        batch_t *cur = NULL, *nxt = NULL;
+        size_t nranges = 0, cap_ranges = 0, bi, submitted = 0;
+        uint64_t max_chars = 1;
+        uint32_t max_recs = 1;
+        int inflight[16], g;
+        const int slots = 4;
         for (f = 0; f < num_qsets; f++) {
             slh_seqset *q = &qsets[f];
             int first = 0;
             while (first < q->num) {
                 int last = first;
                 uint64_t base = q->offsets[first];
-                while (last < q->num && (last == first || q->offsets[last + 1] - base <= batch_bytes * (uint64_t)ngpu)) last++;
+                /* the first batches are short, so that the search starts early */
+                uint64_t limit = nranges < (size_t)ngpu ? batch_bytes / 4 : nranges < 2 * (size_t)ngpu ? batch_bytes / 2 : batch_bytes;
+                while (last < q->num && (last == first || q->offsets[last + 1] - base <= limit)) last++;
                 if (nranges == cap_ranges) {
                     cap_ranges = cap_ranges ? cap_ranges * 2 : 16;
                     ranges = (batch_range *)realloc(ranges, cap_ranges * sizeof(batch_range));
                     if (!ranges) exit_message("Out of memory");
                 }
                 ranges[nranges].f = f; ranges[nranges].first = first; ranges[nranges].last = last;
+                if (q->offsets[last] - base > max_chars) max_chars = q->offsets[last] - base;
+                if ((uint32_t)(last - first) > max_recs) max_recs = (uint32_t)(last - first);
                 nranges++;
                 first = last;
             }
         }
-        if (nranges) {
-            cur = batch_start(&qsets[ranges[0].f], ranges[0].first, ranges[0].last, gpus, ngpu, (uint32_t)o.min_mem_len,
-                              o.both_strands, o.match_type == 1);
-            if (!cur) exit_message("Out of memory");
+        memset(&g_writer, 0, sizeof(g_writer));
+        g_writer.out = out;
+        pthread_mutex_init(&g_writer.mu, NULL);
+        pthread_cond_init(&g_writer.cv, NULL);
+        g_writer.started = pthread_create(&g_writer.tid, NULL, writer_run, &g_writer) == 0;
+        double ts0 = now_s();
+        for (g = 0; g < ngpu && nranges; g++) { /* batch b is searched on GPU b mod ngpu: no data-path collective */
+            rc = slamem_stream_create(gpus[g], slots, max_chars, max_recs, o.both_strands, o.match_type == 1 ? 1 : 0, &g_streams[g]);
+            if (rc != SLAMEM_OK) { shutdown_pipeline(); gpu_fail("setting up the search pipeline", rc); }
+            g_nstreams = g + 1;
+            inflight[g] = 0;
         }
+        t_streams = now_s() - ts0;
         for (bi = 0; bi < nranges; bi++) {
             slh_seqset *q = &qsets[ranges[bi].f];
-            gpu_part *parts;
-            int part;
+            const int first = ranges[bi].first, last = ranges[bi].last;
+            const slamem_mem *mems = NULL;
+            const uint64_t *boff = NULL;
+            uint64_t total = 0;
             double tg = now_s();
-            batch_join(cur, device);
-            if (bi + 1 < nranges) { /* the next batch goes to the GPUs while this one is formatted and written */
-                nxt = batch_start(&qsets[ranges[bi + 1].f], ranges[bi + 1].first, ranges[bi + 1].last, gpus, ngpu,
-                                  (uint32_t)o.min_mem_len, o.both_strands, o.match_type == 1);
-                if (!nxt) exit_message("Out of memory");
-            } else nxt = NULL;
-            parts = cur->parts;
-            {
-                t_gpu += now_s() - tg; /* time the main thread waited for the GPUs */
-                tg = now_s();
-                for (part = 0; part < ngpu; part++) {
-                    const int pfirst = parts[part].first, plast = parts[part].last;
-                    slamem_mem *mems = parts[part].mems;
-                    uint64_t *boff = parts[part].boff;
-#define first pfirst
-#define last plast
-                    /* the first strand blocks get their ':: "name" ....' line (slamem.c:97,101,203) and are formatted here;
-                       the rest of the batch is formatted by all host threads and written in order */
-                    uint64_t nblk = (uint64_t)(last - first) * strands, bseq = 0, b;
-                    int nthr = slh_thread_count(), t;
-                    if (log_limit == 0) bseq = nblk;
-                    else if (printed < log_limit) bseq = (uint64_t)(log_limit - printed) < nblk ? (uint64_t)(log_limit - printed) : nblk;
-                    for (b = 0; b < bseq; b++) {
-                        int ri = first + (int)(b / strands), s = (int)(b % strands), d, dots;
-                        uint64_t cnt = boff[b + 1] - boff[b], sum = 0;
-                        if (slh_format_block(&buf, q->recs[ri].name, s, (const uint32_t *)(mems + boff[b]), cnt, ref.recs,
-                                             ref.merged_start, ref.num, &sum))
-                            exit_message("Out of memory");
-                        total_matches += (long long)cnt;
-                        total_sum += (long long)sum;
-                        dots = slh_progress_dots(q->recs[ri].size);
-                        printf(":: \"%s%s\" ", q->recs[ri].name, s ? " Reverse" : "");
-                        for (d = 0; d < dots; d++) putchar('.');
-                        printf(" (%d M%cMs ; avg size = %d bp)\n", (int)cnt, MATCH_TYPE_CHAR[o.match_type], (int)(cnt ? sum / cnt : 0));
-                        printed++;
-                    }
-                    if (buf.len) {
-                        double tw = now_s();
-                        if (fwrite(buf.data, 1, buf.len, out) != buf.len) exit_message("Cannot write output file");
-                        buf.len = 0;
-                        t_write += now_s() - tw;
-                    }
-                    if (bseq < nblk) {
-                        fmt_job *jobs;
-                        pthread_t *tid;
-                        uint64_t per;
-                        if ((nblk - bseq) < 4096 || nthr < 1) nthr = 1;
-                        jobs = (fmt_job *)calloc((size_t)nthr, sizeof(fmt_job));
-                        tid = (pthread_t *)calloc((size_t)nthr, sizeof(pthread_t));
-                        if (!jobs || !tid) exit_message("Out of memory");
-                        per = (nblk - bseq + (uint64_t)nthr - 1) / (uint64_t)nthr;
-                        for (t = 0; t < nthr; t++) {
-                            jobs[t].q = q; jobs[t].ref = &ref; jobs[t].mems = mems; jobs[t].boff = boff;
-                            jobs[t].first_rec = first; jobs[t].strands = strands;
-                            jobs[t].b0 = bseq + per * (uint64_t)t < nblk ? bseq + per * (uint64_t)t : nblk;
-                            jobs[t].b1 = jobs[t].b0 + per < nblk ? jobs[t].b0 + per : nblk;
-                            if (t == nthr - 1 || pthread_create(&tid[t], NULL, fmt_run, &jobs[t]) != 0) { fmt_run(&jobs[t]); tid[t] = 0; }
-                        }
-                        for (t = 0; t < nthr; t++) {
-                            double tw;
-                            if (tid[t]) pthread_join(tid[t], NULL);
-                            if (jobs[t].failed) exit_message("Out of memory");
-                            total_matches += jobs[t].matches;
-                            total_sum += jobs[t].sum;
-                            tw = now_s();
-                            if (jobs[t].buf.len && fwrite(jobs[t].buf.data, 1, jobs[t].buf.len, out) != jobs[t].buf.len)
-                                exit_message("Cannot write output file");
-                            t_write += now_s() - tw;
-                            slh_buffer_free(&jobs[t].buf);
-                        }
-                        free(jobs);
-                        free(tid);
-                    }
-#undef first
-#undef last
-                    slamem_host_free(mems);
-                    slamem_host_free(boff);
-                    free(parts[part].offs);
-                }
-                t_format += now_s() - tg;
+            /* keep every GPU's pipeline full: slots - 1 batches in flight beside the result being formatted */
+            while (submitted < nranges && inflight[submitted % (size_t)ngpu] < slots - 1) {
+                slh_seqset *qs = &qsets[ranges[submitted].f];
+                rc = slamem_stream_submit(g_streams[submitted % (size_t)ngpu], qs->chars, qs->offsets + ranges[submitted].first,
+                                          (uint32_t)(ranges[submitted].last - ranges[submitted].first), (uint32_t)o.min_mem_len);
+                if (rc != SLAMEM_OK) { shutdown_pipeline(); gpu_fail("MEM search on the GPU", rc); }
+                inflight[submitted % (size_t)ngpu]++;
+                submitted++;
             }
-            free(cur);
-            cur = nxt;
+            rc = slamem_stream_next(g_streams[bi % (size_t)ngpu], &mems, &boff, &total, NULL, NULL);
+            if (rc != SLAMEM_OK) {
+                char detail[512];
+                snprintf(detail, sizeof(detail), "%s", slamem_last_error_message());
+                shutdown_pipeline();
+                printf("\n> ERROR: MEM search on GPU %d failed: %s (%s)\n", device + (int)(bi % (size_t)ngpu), slamem_strerror(rc), detail);
+                join_warmup();
+                exit(-1);
+            }
+            inflight[bi % (size_t)ngpu]--;
+            t_gpu += now_s() - tg; /* time the main thread waited for the GPUs */
+            tg = now_s();
+            {
+                /* the first strand blocks get their ':: "name" ....' line (slamem.c:97,101,203) and are formatted here;
+                   the rest of the batch is formatted by all host threads and handed to the writer in order */
+                uint64_t nblk = (uint64_t)(last - first) * strands, bseq = 0, b;
+                int nthr = slh_thread_count(), t;
+                if (log_limit == 0) bseq = nblk;
+                else if (printed < log_limit) bseq = (uint64_t)(log_limit - printed) < nblk ? (uint64_t)(log_limit - printed) : nblk;
+                for (b = 0; b < bseq; b++) {
+                    int ri = first + (int)(b / strands), sidx = (int)(b % strands), d, dots;
+                    uint64_t cnt = boff[b + 1] - boff[b], sum = 0;
+                    if (slh_format_block(&buf, q->recs[ri].name, sidx, (const uint32_t *)(mems + boff[b]), cnt, ref.recs,
+                                         ref.merged_start, ref.num, &sum))
+                        pipeline_fail("Out of memory");
+                    total_matches += (long long)cnt;
+                    total_sum += (long long)sum;
+                    dots = slh_progress_dots(q->recs[ri].size);
+                    printf(":: \"%s%s\" ", q->recs[ri].name, sidx ? " Reverse" : "");
+                    for (d = 0; d < dots; d++) putchar('.');
+                    printf(" (%d M%cMs ; avg size = %d bp)\n", (int)cnt, MATCH_TYPE_CHAR[o.match_type], (int)(cnt ? sum / cnt : 0));
+                    printed++;
+                }
+                if (writer_push(&g_writer, &buf)) pipeline_fail("Out of memory");
+                if (bseq < nblk) {
+                    fmt_job *jobs;
+                    pthread_t *tid;
+                    uint64_t per;
+                    if ((nblk - bseq) < 4096 || nthr < 1) nthr = 1;
+                    jobs = (fmt_job *)calloc((size_t)nthr, sizeof(fmt_job));
+                    tid = (pthread_t *)calloc((size_t)nthr, sizeof(pthread_t));
+                    if (!jobs || !tid) pipeline_fail("Out of memory");
+                    per = (nblk - bseq + (uint64_t)nthr - 1) / (uint64_t)nthr;
+                    for (t = 0; t < nthr; t++) {
+                        jobs[t].q = q; jobs[t].ref = &ref; jobs[t].mems = mems; jobs[t].boff = boff;
+                        jobs[t].first_rec = first; jobs[t].strands = strands;
+                        jobs[t].b0 = bseq + per * (uint64_t)t < nblk ? bseq + per * (uint64_t)t : nblk;
+                        jobs[t].b1 = jobs[t].b0 + per < nblk ? jobs[t].b0 + per : nblk;
+                        if (t == nthr - 1 || pthread_create(&tid[t], NULL, fmt_run, &jobs[t]) != 0) { fmt_run(&jobs[t]); tid[t] = 0; }
+                    }
+                    for (t = 0; t < nthr; t++) {
+                        if (tid[t]) pthread_join(tid[t], NULL);
+                        if (jobs[t].failed) pipeline_fail("Out of memory");
+                        total_matches += jobs[t].matches;
+                        total_sum += jobs[t].sum;
+                        if (writer_push(&g_writer, &jobs[t].buf)) pipeline_fail("Out of memory");
+                    }
+                    free(jobs);
+                    free(tid);
+                }
+                if (g_writer.failed) pipeline_fail("Cannot write output file");
+            }
+            t_format += now_s() - tg;
         }
         free(ranges);
+        writer_finish(&g_writer);
+        t_write = g_writer.seconds;
+        if (g_writer.failed) pipeline_fail("Cannot write output file");
         if (log_limit != 0 && (long)total_queries * strands > log_limit)
             printf(":: ... (%ld more strand blocks matched; set SLAMEM_VERBOSE=1 for a line each)\n",
                    (long)total_queries * strands - log_limit);
     }
-    double t_end0 = now_s(), t_end1, t_end2;
-    for (i = 0; i < ngpu; i++) slamem_index_free(gpus[i]);
-    t_end1 = now_s();
+    double t_end0 = now_s(), t_end1;
     if (total_queries != 1) /* slamem.c:210-212 (the reference divides by zero when nothing matched) */
         printf(":: Average %d M%cMs found per query sequence (total = %lld, avg size = %d bp)\n",
                (int)(total_matches / total_queries), MATCH_TYPE_CHAR[o.match_type], total_matches,
                (int)(total_matches ? total_sum / total_matches : 0));
     fflush(stdout);
     printf("> Saving M%cMs to <%s> ... ", MATCH_TYPE_CHAR[o.match_type], out_name);
-    if (fclose(out) != 0) exit_message("Cannot write output file");
-    t_end2 = now_s();
+    if (fflush(out) != 0 || ferror(out)) exit_message("Cannot write output file");
+    if (getenv("SLAMEM_FULL_TEARDOWN") != NULL && fclose(out) != 0) exit_message("Cannot write output file");
+    t_end1 = now_s();
     printf("OK\n");
+    printf("> Done!\n");
+    if (timing)
+        fprintf(stderr, "[timing] load %.3f s (index build of %.3f s overlapped; %.3f s more waiting for it), pipeline set-up %.3f s, "
+                        "waiting for the GPU (upload + search + download, overlapped with formatting) %.3f s, format %.3f s "
+                        "(writer thread busy %.3f s, overlapped), close %.3f s, total %.3f s\n",
+                t_load, t_build, t_join, t_streams, t_gpu, t_format, t_write, t_end1 - t_end0, now_s() - t_start);
+    fflush(stdout);
+    fflush(stderr);
+    if (getenv("SLAMEM_FULL_TEARDOWN") == NULL) {
+        /* everything is written and nothing runs on the GPU any more: leave without returning gigabytes of buffers and
+           HBM piece by piece (0.15-0.25 s of the reference-sized run); the kernel driver reclaims them with the process */
+        _exit(0);
+    }
+    shutdown_pipeline();
+    for (i = 0; i < ngpu; i++) slamem_index_free(gpus[i]);
     if (o.out_arg == -1) free(out_name);
     slh_buffer_free(&buf);
     slh_free_seqset(&ref);
     for (f = 0; f < num_qsets; f++) slh_free_seqset(&qsets[f]);
     free(qsets);
     slh_free_options(&o);
-    printf("> Done!\n");
-    if (timing)
-        fprintf(stderr, "[timing] load %.3f s (index build of %.3f s overlapped), waiting for the GPU (search + transfers, overlapped with formatting) %.3f s, format %.3f s + write %.3f s, index free %.3f s, close %.3f s, host free %.3f s, total %.3f s\n",
-                t_load, t_build, t_gpu, t_format - t_write, t_write, t_end1 - t_end0, t_end2 - t_end1, now_s() - t_end2, now_s() - t_start);
     return 0;
 }

@@ -269,3 +269,74 @@ def test_capacity_error_reports_the_need_and_retry_succeeds(eng):
     e, eo = idx.find_mems(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64), 20, True)
     assert len(e) == 0 and list(eo) == [0]
     idx.close()
+
+
+def test_stream_host_to_host_matches_device_path(eng):
+    """slamem_stream_* (pinned host buffers, pipelined slots; replaces the query loop at slamem.c:90-207): every batch
+    equals slamem_find_mems_device on the same records and the oracle, in order; offsets windows with a non-zero base;
+    ragged last batch; the busy / empty errors; MAM mode through the same entry point."""
+    from oracle import pyoracle as po
+    from slamem_amd import capi
+    rng = np.random.default_rng(33)
+    text = rand_text(rng, 60000, "ACGT", 40, max_rep=300)
+    qs = make_queries(rng, text, 1000, "ACGTN")
+    q, off = pack(qs)
+    idx = eng.Index.build(text)
+    o = po.OracleIndex(bytes(text))
+    nq = len(qs)
+    per = 137
+    nbatches = (nq + per - 1) // per
+    buf = eng.PinnedBuffer(len(q) + 64)
+    buf.array[: len(q)] = q
+    for mam in (False, True):
+        st = eng.Stream(idx, 3, int(max(np.diff(off[::1]).max() * per, 1 << 16)), per, True, mam=mam)
+        with pytest.raises(capi.SlamemError):
+            st.next()  # nothing pending
+        wins = [off[b * per: min(nq, (b + 1) * per) + 1] for b in range(nbatches)]
+        st.submit(buf.array, wins[0], 11)
+        st.submit(buf.array, wins[1], 11)
+        for b in range(nbatches):
+            m, boff, _ = st.next()
+            if b + 2 < nbatches:
+                st.submit(buf.array, wins[b + 2], 11)
+                if b + 3 < nbatches:
+                    with pytest.raises(capi.SlamemError):  # slots - 1 in flight beside the lent result: full
+                        st.submit(buf.array, wins[b + 3], 11)
+            w = wins[b]
+            sub = q[int(w[0]): int(w[-1])]
+            om, obc = o.match_batch(sub, w - w[0], 11, True, mam=mam)
+            assert np.array_equal(np.diff(boff.astype(np.int64)), obc.astype(np.int64))
+            for f in ("ref_pos", "query_pos", "length"):
+                assert np.array_equal(m[f], om[f]), (mam, b, f)
+        st.close()
+    buf.close()
+    idx.close()
+
+
+def test_mam_long_record_matches_oracle_and_overflows_inline_slots(eng):
+    """-mam on a long record (160 kbp against a 250 kbp text with repeat families): one lane scans the whole strand
+    (the mode's stale fall-back interval, slamem.c:122-123,131,197-198, makes a slice depend on its past), its MAMs
+    leave through the v3 output path (4 inline slots, then the overflow list; rows resolved by K9).  In order against
+    the oracle, both strands."""
+    import time
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(77)
+    text = rand_text(rng, 250_000, "ACGT", 60, max_rep=2000)
+    t = np.frombuffer(text, dtype=np.uint8).copy()
+    q = t[40_000:200_000].copy()
+    mut = rng.random(q.shape[0]) < 0.01
+    q[mut] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(mut.sum()))
+    qs = [q.tobytes(), q[::-1].tobytes()[:5000]]
+    qq, off = pack(qs)
+    o = po.OracleIndex(text)
+    om, obc = o.match_batch(qq, off, 20, True, mam=True)
+    g = eng.Index.build(text)
+    t0 = time.time()
+    gm, goff = g.find_mems(qq, off, 20, True, mam=True)
+    dt = time.time() - t0
+    assert len(om) > 100  # far more than the inline slots of a strand
+    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+    for f in ("ref_pos", "query_pos", "length"):
+        assert np.array_equal(gm[f], om[f]), f
+    assert dt < 20.0
+    g.close()

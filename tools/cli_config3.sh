@@ -1,0 +1,16 @@
+#!/bin/bash
+# BASELINE.json configs[2] end to end through the command line: FASTA files in, *-mems.txt out; three timed runs
+set -e
+D=${1:-/tmp/c3}
+mkdir -p $D
+if [ ! -f $D/qry.fa ]; then python tools/gen_synth.py 100000000 10000000 150 0.02 42 50 $D > $D/gen.log; fi
+for i in 1 2 3; do
+  T0=$(date +%s.%N)
+  SLAMEM_TIMING=1 slamem_amd/host/slaMEM-hip -b -l 20 -o $D/out-mems.txt $D/ref.fa $D/qry.fa > $D/stdout.txt 2> $D/stderr.txt || { tail -5 $D/stdout.txt; cat $D/stderr.txt; exit 1; }
+  T1=$(date +%s.%N)
+  python3 -c "print('process wall %.3f s' % ($T1 - $T0))"
+  grep -h "timing" $D/stderr.txt
+done
+tail -3 $D/stdout.txt
+ls -l $D/out-mems.txt | awk '{print $5, "bytes"}'
+sha256sum $D/out-mems.txt

@@ -1,0 +1,11 @@
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from slamem_amd import engine
+dev = torch.device("cuda:0")
+n, M, L = 100_000_000, 10_000_000, 150
+ref = engine.synth_reference(n, 42, dev)
+idx = engine.Index.build(ref, dev)
+reads = engine.synth_reads(ref, 0, M, L, 0.02, 42, 50)
+r = engine.host_to_host_leg(idx, reads, M, L, 20, True, steps=1, batch_reads=1_000_000, slots=6)
+print(r["host_to_host_ms"], file=sys.stderr)
