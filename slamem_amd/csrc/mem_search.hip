@@ -58,6 +58,14 @@ __device__ __forceinline__ uint32_t occ_lt(const Blk& k, uint32_t c2, uint32_t o
     return cnt + (uint32_t)__popcll(m0 & mlo) + (uint32_t)__popcll(m1 & mhi);
 }
 
+// set bits of the 128-bit mask m1:m0 below bit `off` (off in 0..127)
+__device__ __forceinline__ uint32_t count_lt(uint64_t m0, uint64_t m1, uint32_t off) {
+    uint32_t lo = off < 64u ? off : 64u, hi = off < 64u ? 0u : off - 64u;
+    uint64_t mlo = lo == 64u ? ~0ull : ((1ull << lo) - 1ull);
+    uint64_t mhi = (1ull << hi) - 1ull;  // hi <= 63
+    return (uint32_t)__popcll(m0 & mlo) + (uint32_t)__popcll(m1 & mhi);
+}
+
 // number of N rows strictly below `row`
 __device__ __forceinline__ uint32_t n_rows_lt(const IndexView& ix, uint32_t row) {
     uint32_t lo = 0, hi = ix.num_n;
@@ -941,10 +949,23 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
                 uint32_t nt, nb1;
                 if (c >= 2u) {
-                    nt = occ_lt(kt, c - 2u, top & (kFmRows - 1u));
-                    // (never form a reference to "kb or kt": that forces both blocks into scratch memory)
-                    nb1 = bb == bt ? occ_lt(kt, c - 2u, (bot + 1u) & (kFmRows - 1u))
-                                   : occ_lt(kb, c - 2u, (bot + 1u) & (kFmRows - 1u));
+                    // the rows of each block that hold letter c (two 64-bit masks), once; then two prefix counts.  The
+                    // bottom query takes its masks and its rank sample from top's block when it is the same block
+                    // (picked with selects on values: a reference to "kb or kt" would force both blocks into scratch)
+                    const uint32_t c2 = c - 2u;
+                    const uint64_t f0 = (c2 & 1u) ? ~0ull : 0ull, f1 = (c2 & 2u) ? ~0ull : 0ull;
+                    const uint64_t mt0 = ~(u64_of(kt.b.x, kt.b.y) ^ f0) & ~(u64_of(kt.c.x, kt.c.y) ^ f1) & ~u64_of(kt.d.x, kt.d.y);
+                    const uint64_t mt1 = ~(u64_of(kt.b.z, kt.b.w) ^ f0) & ~(u64_of(kt.c.z, kt.c.w) ^ f1) & ~u64_of(kt.d.z, kt.d.w);
+                    const uint32_t ct = c2 == 0 ? kt.a.x : c2 == 1 ? kt.a.y : c2 == 2 ? kt.a.z : kt.a.w;
+                    uint64_t mb0 = mt0, mb1 = mt1;
+                    uint32_t cb = ct;
+                    if (bb != bt) {
+                        mb0 = ~(u64_of(kb.b.x, kb.b.y) ^ f0) & ~(u64_of(kb.c.x, kb.c.y) ^ f1) & ~u64_of(kb.d.x, kb.d.y);
+                        mb1 = ~(u64_of(kb.b.z, kb.b.w) ^ f0) & ~(u64_of(kb.c.z, kb.c.w) ^ f1) & ~u64_of(kb.d.z, kb.d.w);
+                        cb = c2 == 0 ? kb.a.x : c2 == 1 ? kb.a.y : c2 == 2 ? kb.a.z : kb.a.w;
+                    }
+                    nt = ct + count_lt(mt0, mt1, top & (kFmRows - 1u));
+                    nb1 = cb + count_lt(mb0, mb1, (bot + 1u) & (kFmRows - 1u));
                 } else if (ix.num_n == 0) {
                     nt = nb1 = 1u;
                 } else {
