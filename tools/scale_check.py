@@ -27,18 +27,7 @@ def main():
     L = 150
     dev = torch.device("cuda:0")
     ref = engine.synth_reference(n, 42, dev)
-    planted = 0
-    if repeats:
-        g = np.random.default_rng(7)
-        acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-        while planted < n // 200:
-            ln = int(g.integers(1000, 10001))
-            src, dst = int(g.integers(0, n - ln)), int(g.integers(0, n - ln))
-            seg = ref[src:src + ln].clone()
-            mut = torch.rand(ln, device=dev) < 0.01
-            seg[mut] = acgt[torch.randint(0, 4, (int(mut.sum().item()),), device=dev)]
-            ref[dst:dst + ln] = seg
-            planted += ln
+    planted = engine.synth_plant_repeats(ref, 42) if repeats else 0  # seeded: the same text in every run (csrc/synth.hip)
     torch.cuda.synchronize()
     t0 = time.time()
     idx = engine.Index.build(ref, dev)
@@ -52,7 +41,10 @@ def main():
     m.run(reads, offsets, min_len)
     engine.reset_timings()
     total = m.run(reads, offsets, min_len)
-    kms = engine.timings()["search_kernel_ms"]
+    tm_s = engine.timings()
+    kms = tm_s["search_kernel_ms"]
+    sst = engine.search_stats(m, reads, offsets, min_len) if os.environ.get("SCALE_STATS", "1") != "0" else {}
+    total = m.run(reads, offsets, min_len)
     mems = m.mems[:total].cpu().numpy().view(np.uint32).astype(np.int64)
     boff = m.block_offsets[: 2 * nreads + 1].cpu().numpy()
     blk = np.repeat(np.arange(2 * nreads), np.diff(boff))
@@ -79,7 +71,14 @@ def main():
            "max_lcp": int(idx.info.max_lcp), "index_GB": round(idx.info.arena_bytes / 1e9, 2),
            "samples_pct": round(100.0 * st["num_samples"] / (n + 1), 2), "mean_lcp": st["sum_lcp"] // (n + 1),
            "mems": int(total), "mems_per_read": round(total / nreads, 3), "checked": int(len(sel)), "bad": int(bad),
-           "search_kernel_ms": round(kms, 2), "Mreads_per_s": round(nreads / kms / 1e3, 2)}
+           "search_kernel_ms": round(kms, 2), "k8_ms": round(tm_s["k8_ms"], 2), "k8a_ms": round(tm_s["prefilter_ms"], 2),
+           "Mreads_per_s": round(nreads / kms / 1e3, 2), "counters": sst}
+    if sst:
+        lines = sum(sst[k] for k in ("fm_lines_top", "fm_lines_bottom", "rec_lines_fail", "rec_lines_pend", "rec_lines_flush",
+                                    "dir_sa_lines", "dir_group_loads", "dir_rec_lines", "jump_lines"))
+        out["k8_lines_per_read"] = round(lines / nreads, 1)
+        out["k8_Glines_per_s"] = round(lines / tm_s["k8_ms"] / 1e6, 2)
+        out["ceiling_Glines_per_s"] = round(engine.random_line_ceiling(idx) / 1e9, 2)
     print(json.dumps(out))
     assert bad == 0
 
