@@ -130,6 +130,9 @@ int slamem_reset_timings(void);
  * slower) and slamem_get_search_stats returns the counters of the last one.  No reference counterpart. */
 int slamem_search_stats_enable(int on);
 int slamem_get_search_stats(slamem_search_stats *out);
+/* Timeline of the same diagnostic launch of K8 (device wall clock): microseconds from the first wave's start until the
+ * work list was empty, microseconds from then until the last wave left (the tail), and the sum of all waves' run times. */
+int slamem_get_search_clock(double *us_to_empty_list, double *us_tail, double *us_wave_sum);
 
 /* ---- (a) index construction ------------------------------------------- */
 /* Replaces FMI_BuildIndex(texts,sizes,1,&lcp,verbose) (bwtindex.h:7, call at

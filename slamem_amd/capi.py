@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "slamem_get_timings", "slamem_reset_timings", "slamem_device_warmup",
     "slamem_index_build", "slamem_index_build_device", "slamem_index_free", "slamem_index_get_info",
     "slamem_index_arena", "slamem_index_export", "slamem_index_attach", "slamem_index_adopt_arena", "slamem_index_save", "slamem_index_load",
-    "slamem_index_validate_header", "slamem_search_stats_enable", "slamem_get_search_stats",
+    "slamem_index_validate_header", "slamem_search_stats_enable", "slamem_get_search_stats", "slamem_get_search_clock",
     "slamem_index_download", "slamem_index_sampled_lcp_stats",
     "slamem_follow_letter_batch", "slamem_enclosing_interval_batch", "slamem_position_in_text_batch",
     "slamem_char_at_bwt_pos_batch",
@@ -107,6 +107,7 @@ def _declare(L):
     L.slamem_index_validate_header.argtypes = [vp, u64, u64]
     L.slamem_search_stats_enable.argtypes = [i32]
     L.slamem_get_search_stats.argtypes = [C.POINTER(SearchStats)]
+    L.slamem_get_search_clock.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.slamem_index_download.argtypes = [vp, i32, vp, u64]
     L.slamem_index_sampled_lcp_stats.argtypes = [vp, C.POINTER(SslcpStats)]
     L.slamem_follow_letter_batch.argtypes = [vp, vp, vp, vp, vp, u64, vp]

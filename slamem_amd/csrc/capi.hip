@@ -32,6 +32,8 @@ static thread_local bool g_want_stats = false;
 static thread_local slamem_search_stats g_stats;
 bool search_stats_wanted() { return g_want_stats; }
 slamem_search_stats& last_search_stats() { return g_stats; }
+static thread_local double g_clock[3];
+double* last_search_clock() { return g_clock; }
 
 int download_array(const slamem_index* idx, int which, void* host_dst, uint64_t count);
 int sampled_lcp_stats(const slamem_index* idx, slamem_sslcp_stats* out);
@@ -155,6 +157,13 @@ int slamem_search_stats_enable(int on) {
 int slamem_get_search_stats(slamem_search_stats* out) {
     if (!out) return SLAMEM_ERR_ARG;
     *out = g_stats;
+    return SLAMEM_OK;
+}
+
+int slamem_get_search_clock(double* us_to_empty_list, double* us_tail, double* us_wave_sum) {
+    if (us_to_empty_list) *us_to_empty_list = g_clock[0];
+    if (us_tail) *us_tail = g_clock[1];
+    if (us_wave_sum) *us_wave_sum = g_clock[2];
     return SLAMEM_OK;
 }
 

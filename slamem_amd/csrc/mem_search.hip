@@ -19,6 +19,7 @@
 #include "common.h"
 #include "prims.h"
 
+#include <new>
 #include <stdlib.h>
 #include <string.h>
 
@@ -553,7 +554,8 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
 enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
-    SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES, SC_COUNT
+    SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
+    SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -702,7 +704,10 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     const bool cls_hi = cL >= 8u;
     const uint32_t jK = (ix.kjump && (int)ix.kjump_k < L && A.use_jump) ? ix.kjump_k : 0u;
 
-    // diagnostic instantiation only
+    // diagnostic instantiation only: when the first wave started, when the first wave found the list empty, when the last
+    // wave left (100 MHz wall clock), and the sum over waves of the time they ran
+    const unsigned long long t_wave0 = kStats ? wall_clock64() : 0ull;
+    if (kStats && (threadIdx.x & 63u) == 0u) atomicMin(A.stats + SC_T_FIRST, t_wave0);
     uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_wtrips = 0, n_pos = 0,
              n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0, n_jump = 0;
 
@@ -732,8 +737,10 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             uint32_t base = 0;
             if (lane == 0u) base = atomicAdd(A.work_cursor, want);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base >= nitems) drained = true;
-            else {
+            if (base >= nitems) {
+                drained = true;
+                if (kStats && lane == 0u) atomicMin(A.stats + SC_T_DRAIN, (unsigned long long)wall_clock64());
+            } else {
                 chunk_first = next = base;
                 chunk_end = nitems - base < want ? nitems : base + want;
                 seen = chunk_end;
@@ -1071,6 +1078,11 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
         stat_flush<kStats>(A.stats + SC_DIR_SA, n_dsa); stat_flush<kStats>(A.stats + SC_DIR_GROUPS, n_dgrp);
         stat_flush<kStats>(A.stats + SC_DIR_RECS, n_drec); stat_flush<kStats>(A.stats + SC_DIR_LETTERS, n_dlet);
         stat_flush<kStats>(A.stats + SC_JUMP_LINES, n_jump);
+        if ((threadIdx.x & 63u) == 0u) {
+            const unsigned long long t1 = wall_clock64();
+            atomicMax(A.stats + SC_T_LAST, t1);
+            atomicAdd(A.stats + SC_T_WAVE_SUM, t1 - t_wave0);
+        }
     }
 }
 
@@ -1393,12 +1405,44 @@ uint64_t find_mems_workspace_bytes(uint64_t num_queries, int both_strands, uint6
     return layout_workspace(num_queries, both_strands ? 2 : 1, query_bytes, mems_capacity).bytes;
 }
 
-int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
-                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
-                     slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
-                     uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out) {
-    if (!idx || !offsets_dev || !block_offsets_dev || !workspace_dev || !total_out || (!mems_dev && mems_capacity) ||
-        (!queries_dev && num_queries)) {
+struct SearchJob {
+    const slamem_index* idx = nullptr;
+    const void* queries_dev = nullptr;
+    const uint64_t* offsets_dev = nullptr;
+    uint32_t num_queries = 0, min_len = 0, strands = 1;
+    uint64_t query_bytes = 0, mems_capacity = 0, workspace_bytes = 0, num_blocks = 0, nitems = 0, total = 0;
+    int both_strands = 0, match_type = 0, kernel_version = 3;
+    slamem_mem* mems_dev = nullptr;
+    uint64_t* block_offsets_dev = nullptr;
+    void* workspace_dev = nullptr;
+    WorkspaceLayout w;
+    SearchArgs A;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // before K8a, after K8, after K9, after K8a, before K8
+    bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
+    ~SearchJob();
+    int init(const slamem_index* idx_, const void* queries_dev_, const uint64_t* offsets_dev_, uint32_t num_queries_,
+             uint64_t query_bytes_, uint32_t min_len_, int both_strands_, int match_type_, slamem_mem* mems_dev_,
+             uint64_t mems_capacity_, uint64_t* block_offsets_dev_, void* workspace_dev_, uint64_t workspace_bytes_);
+    int tables(hipStream_t stream);
+    int launch(hipStream_t stream);
+    int finish(hipStream_t stream);
+};
+
+// One batch through the search, in three steps that a caller may issue apart (slamem_stream_* does: tables in the upload
+// stage, launch for batch b+1 BEFORE finish of batch b, so that the kernels of b+1 are queued on the GPU when the last
+// waves of K8(b) drain and nothing waits for a host round trip):
+//   tables()  work-item counts and offsets (one small sync: the number of items sizes the grids)
+//   launch()  K8a prefilter, work-list compaction, K7q packing, K8 search -- asynchronous
+//   finish()  per-item counts -> offsets, capacity check, K9 placement; synchronous with respect to the stream
+// find_mems_device() runs the three in a row.
+int SearchJob::init(const slamem_index* idx_, const void* queries_dev_, const uint64_t* offsets_dev_, uint32_t num_queries_,
+                    uint64_t query_bytes_, uint32_t min_len_, int both_strands_, int match_type_, slamem_mem* mems_dev_,
+                    uint64_t mems_capacity_, uint64_t* block_offsets_dev_, void* workspace_dev_, uint64_t workspace_bytes_) {
+    idx = idx_; queries_dev = queries_dev_; offsets_dev = offsets_dev_; num_queries = num_queries_; query_bytes = query_bytes_;
+    min_len = min_len_; both_strands = both_strands_; match_type = match_type_; mems_dev = mems_dev_; mems_capacity = mems_capacity_;
+    block_offsets_dev = block_offsets_dev_; workspace_dev = workspace_dev_; workspace_bytes = workspace_bytes_;
+    total = 0; nitems = 0; prefiltered = false; timed_k8 = false; launched = false;
+    if (!idx || !offsets_dev || !block_offsets_dev || !workspace_dev || (!mems_dev && mems_capacity) || (!queries_dev && num_queries)) {
         set_error("slamem_find_mems_device: null argument");
         return SLAMEM_ERR_ARG;
     }
@@ -1410,10 +1454,10 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         set_error("slamem_find_mems_device: queries_dev must be 16-byte aligned");
         return SLAMEM_ERR_ARG;
     }
-    const uint32_t strands = both_strands ? 2u : 1u;
-    const uint64_t num_blocks = (uint64_t)num_queries * strands;
-    WorkspaceLayout w = layout_workspace(num_queries, strands, query_bytes, mems_capacity);
-    if (w.max_items >= 0xFFF00000ull) {  // (the work cursor runs up to 8192 x 64 past the end of the list)
+    strands = both_strands ? 2u : 1u;
+    num_blocks = (uint64_t)num_queries * strands;
+    w = layout_workspace(num_queries, strands, query_bytes, mems_capacity);
+    if (w.max_items >= 0xFFF00000ull) {  // (the work cursor runs up to 4096 x 64 past the end of the list)
         set_error("slamem_find_mems_device: at most 2^32 - 2^20 work items per call");
         return SLAMEM_ERR_ARG;
     }
@@ -1422,232 +1466,270 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                   (unsigned long long)workspace_bytes, (unsigned long long)w.bytes);
         return SLAMEM_ERR_ARG;
     }
+    static const int env_kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
+    // MAM mode scans whole strands with k_find_mams (one lane per strand); its MAMs leave through the v3 output path
+    kernel_version = match_type == 1 ? 1 : env_kernel_version;
+    want_stats = search_stats_wanted();
+    for (int i = 0; i < 5; i++)
+        if (!ev[i]) SLAMEM_HIP(hipEventCreate(&ev[i]));
+    return SLAMEM_OK;
+}
+
+SearchJob::~SearchJob() {
+    for (int i = 0; i < 5; i++)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+}
+
+#define STEP(call, what) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_fail(e__, what, __FILE__, __LINE__); } while (0)
+
+int SearchJob::tables(hipStream_t stream) {
     SLAMEM_HIP(hipSetDevice(idx->device));
     char* ws = static_cast<char*>(workspace_dev);
     unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
     uint32_t* d_cnt = reinterpret_cast<uint32_t*>(ws + w.off_cnt);
     uint32_t* d_first = reinterpret_cast<uint32_t*>(ws + w.off_first);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
-    uint64_t* d_itemoff = reinterpret_cast<uint64_t*>(ws + w.off_itemoff);
-    static const int env_kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
-    // MAM mode scans whole strands with k_find_mams and shares the v1 output path (atomic list + scatter)
-    const int kernel_version = match_type == 1 ? 1 : env_kernel_version;
+    STEP(hipMemsetAsync(d_total, 0, 64 + SC_COUNT * 8, stream), "memset");
+    if (want_stats) STEP(hipMemsetAsync(d_total + 8 + SC_T_FIRST, 0xFF, 16, stream), "memset");  // the two minima
+    // ---- work items: one per strand, long records cut into slices (v1 scans whole strands) ----------------
+    uint32_t* d_wps = reinterpret_cast<uint32_t*>(ws + w.off_wps);
+    uint64_t* d_wscan = reinterpret_cast<uint64_t*>(ws + w.off_wscan);
+    hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
+                       num_queries, kernel_version == 3 ? kSliceLen : 0u, d_cnt, d_wps);
+    STEP(hipGetLastError(), "k_item_counts");
+    STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
+    uint32_t slices = 0;
+    STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
+    if (kernel_version == 3) {  // packed strands: offsets of the strand blocks
+        size_t need3 = w.scan_bytes;
+        STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need3, d_wps, d_wscan, (uint64_t)num_queries, stream), "scan");
+    }
+    STEP(hipStreamSynchronize(stream), "item count (sync)");
+    nitems = (uint64_t)slices * strands;
+    if (nitems > w.max_items) { set_error("slamem_find_mems_device: query_bytes is smaller than the offsets say"); return SLAMEM_ERR_ARG; }
+    STEP(hipMemsetAsync(d_counts + nitems, 0, 4, stream), "memset");
+    memset(&A, 0, sizeof(A));
+    A.ix = idx->view;
+    A.qwords = static_cast<const uint64_t*>(queries_dev);
+    A.offsets = offsets_dev;
+    A.num_queries = num_queries;
+    A.strands = strands;
+    A.min_len = min_len;
+    A.capacity = mems_capacity;
+    A.total = d_total;
+    A.raw_key = reinterpret_cast<RawKey*>(ws + w.off_rawkey);
+    A.raw_mem = reinterpret_cast<slamem_mem*>(ws + w.off_rawmem);
+    A.block_counts = d_counts;
+    A.inline_rows = reinterpret_cast<RawRow*>(ws + w.off_inline);
+    A.items = reinterpret_cast<const ItemDesc*>(ws + w.off_items);
+    A.num_items = nitems;
+    A.item_attempt = reinterpret_cast<uint8_t*>(ws + w.off_attempt);
+    A.query_words = (query_bytes + 7) / 8;
+    A.stats = d_total + 8;  // behind the 64 bytes of scalars
+    A.spec_depth = -1;
+    A.chunk = kChunkMax;
+    if (nitems && kernel_version == 3) {
+        uint64_t* d_itempk = reinterpret_cast<uint64_t*>(ws + w.off_itempk);
+        uint64_t* d_pq = reinterpret_cast<uint64_t*>(ws + w.off_pq);
+        hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
+                           num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk);
+        STEP(hipGetLastError(), "k_item_fill");
+        STEP(hipMemsetAsync(d_pq, 0, 16, stream), "memset");  // the two leading zero words
+        A.pq = d_pq;
+        A.pq_out = d_pq;
+        A.item_pk = d_itempk;
+        // direct extension of single-row matches: on when the index has the text-ordered sections and the class
+        // threshold can discriminate (min_len >= 8); entry depth = where chance matches stop, log4(n) + 3
+        static const int env_depth = [] { const char* v = getenv("SLAMEM_DIRECT_DEPTH"); return v ? atoi(v) : 0; }();
+        int lg = 0;
+        for (uint64_t v = idx->hdr.n; v > 1; v >>= 2) lg++;
+        A.direct_min_depth = (idx->view.tgrp && depth_class((int)min_len) >= 1u) ? lg + 3 : -1;
+        if (env_depth > 0 && A.direct_min_depth >= 0) A.direct_min_depth = env_depth;
+        if (env_depth < 0) A.direct_min_depth = -1;
+        static const bool env_jump = [] { const char* v = getenv("SLAMEM_KJUMP_USE"); return !(v && atoi(v) == 0); }();
+        A.use_jump = env_jump ? 1u : 0u;
+    }
+    return SLAMEM_OK;
+}
 
-    Timings& tm = thread_timings();
-    const bool want_stats = search_stats_wanted();
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, ep = nullptr, ek = nullptr;
-    int rc = SLAMEM_OK;
-    do {
-        hipError_t e;
-#define STEP(call, what) if ((e = (call)) != hipSuccess) { rc = hip_fail(e, what, __FILE__, __LINE__); break; }
-        STEP(hipEventCreate(&e0), "hipEventCreate");
-        STEP(hipEventCreate(&e1), "hipEventCreate");
-        STEP(hipEventCreate(&e2), "hipEventCreate");
-        STEP(hipEventCreate(&ep), "hipEventCreate");
-        STEP(hipEventCreate(&ek), "hipEventCreate");
-        STEP(hipMemsetAsync(d_total, 0, 64 + SC_COUNT * 8, stream), "memset");
-        // ---- work items: one per strand, long records cut into slices (v1 scans whole strands) ----------------
-        uint64_t nitems = num_blocks;
-        uint32_t* d_wps = reinterpret_cast<uint32_t*>(ws + w.off_wps);
-        uint64_t* d_wscan = reinterpret_cast<uint64_t*>(ws + w.off_wscan);
-        hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
-                           num_queries, kernel_version == 3 ? kSliceLen : 0u, d_cnt, d_wps);
-        STEP(hipGetLastError(), "k_item_counts");
-        STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
-        uint32_t slices = 0;
-        STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
-        STEP(hipStreamSynchronize(stream), "item count (sync)");
-        nitems = (uint64_t)slices * strands;
-        if (nitems > w.max_items) { set_error("slamem_find_mems_device: query_bytes is smaller than the offsets say"); rc = SLAMEM_ERR_ARG; break; }
-        STEP(hipMemsetAsync(d_counts + nitems, 0, 4, stream), "memset");
-        SearchArgs A;
-        memset(&A, 0, sizeof(A));
-        A.ix = idx->view;
-        A.qwords = static_cast<const uint64_t*>(queries_dev);
-        A.offsets = offsets_dev;
-        A.num_queries = num_queries;
-        A.strands = strands;
-        A.min_len = min_len;
-        A.capacity = mems_capacity;
-        A.total = d_total;
-        A.raw_key = reinterpret_cast<RawKey*>(ws + w.off_rawkey);
-        A.raw_mem = reinterpret_cast<slamem_mem*>(ws + w.off_rawmem);
-        A.block_counts = d_counts;
-        A.inline_rows = reinterpret_cast<RawRow*>(ws + w.off_inline);
-        A.items = reinterpret_cast<const ItemDesc*>(ws + w.off_items);
-        A.num_items = nitems;
-        A.item_attempt = reinterpret_cast<uint8_t*>(ws + w.off_attempt);
-        A.query_words = (query_bytes + 7) / 8;
-        A.stats = d_total + 8;  // behind the 64 bytes of scalars
-        {
-            A.spec_depth = -1;  // measured: fetching the records speculatively costs more lines than the trips it saves
-            const char* e1 = getenv("SLAMEM_SPEC_DEPTH");
-            if (e1) A.spec_depth = atoi(e1);
-            A.chunk = kChunkMax;
-            const char* e2 = getenv("SLAMEM_CHUNK");
-            if (e2 && atoi(e2) > 0) A.chunk = (uint32_t)atoi(e2);
-            if (A.chunk > kChunkMax) A.chunk = kChunkMax;
-        }
-        bool prefiltered = false, timed_k8 = false;
-        (void)hipEventRecord(e0, stream);
-        if (nitems && kernel_version == 3) {
-            {   // packed strands: offsets of the strand blocks, then the letters (K7q)
-                size_t need3 = w.scan_bytes;
-                STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need3, d_wps, d_wscan, (uint64_t)num_queries, stream), "scan");
-            }
-            uint64_t* d_itempk = reinterpret_cast<uint64_t*>(ws + w.off_itempk);
-            uint64_t* d_pq = reinterpret_cast<uint64_t*>(ws + w.off_pq);
-            hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
-                               num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk);
-            STEP(hipGetLastError(), "k_item_fill");
-            A.pq = d_pq;
-            A.pq_out = d_pq;
-            A.item_pk = d_itempk;
-            {   // direct extension of single-row matches: on when the index has the text-ordered sections and the class
-                // threshold can discriminate (min_len >= 8); entry depth = where chance matches stop, log4(n) + 3
-                static const int env_depth = [] { const char* v = getenv("SLAMEM_DIRECT_DEPTH"); return v ? atoi(v) : 0; }();
-                int lg = 0;
-                for (uint64_t v = idx->hdr.n; v > 1; v >>= 2) lg++;
-                A.direct_min_depth = (idx->view.tgrp && depth_class((int)min_len) >= 1u) ? lg + 3 : -1;
-                if (env_depth > 0 && A.direct_min_depth >= 0) A.direct_min_depth = env_depth;
-                if (env_depth < 0) A.direct_min_depth = -1;
-                static const bool env_jump = [] { const char* v = getenv("SLAMEM_KJUMP_USE"); return !(v && atoi(v) == 0); }();
-                A.use_jump = env_jump ? 1u : 0u;
-            }
-            static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
-            if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
-                uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
-                if (want_stats) hipLaunchKernelGGL(k_prefilter<true>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
-                else hipLaunchKernelGGL(k_prefilter<false>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
-                STEP(hipGetLastError(), "k_prefilter");
-                (void)hipEventRecord(ep, stream);
-                prefiltered = true;
-                A.item_alive = d_alive;
-                // dead items emit nothing: their counts are zero; the survivors become a dense work list
-                STEP(hipMemsetAsync(d_counts, 0, nitems * 4, stream), "memset");
-                STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
-                uint32_t* d_ids = reinterpret_cast<uint32_t*>(ws + w.off_workids);
-                uint32_t* d_nwork = reinterpret_cast<uint32_t*>(d_total) + 8;  // a word of the zeroed scalar block
-                size_t need2 = w.select_bytes;
-                STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
-                A.work_ids = d_ids;
-                A.work_count = d_nwork;
-            }
-            STEP(hipMemsetAsync(d_pq, 0, 16, stream), "memset");  // the two leading zero words
-            {   // K7q: the strands K8 will scan, packed; then (only if some record was cut into slices) all of those slices
-                uint64_t pb = (nitems * 8 + 255) / 256;
-                hipLaunchKernelGGL(k_pack_queries<8>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, false);
-                if (nitems != num_blocks) {
-                    pb = (nitems * 16 + 255) / 256;
-                    hipLaunchKernelGGL(k_pack_queries<16>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, true);
-                }
-            }
-            STEP(hipGetLastError(), "k_pack_queries");
-            // persistent waves: as many as the chip holds (256 CUs x 16 waves), fewer for small batches
-            uint64_t waves = (nitems + kFetch - 1) / kFetch;
-            static const uint64_t env_waves = [] { const char* v = getenv("SLAMEM_K8_WAVES"); return v ? (uint64_t)atoll(v) : 0ull; }();
-            const uint64_t cap_waves = env_waves ? env_waves : 4096;  // what the chip holds at 4 waves per SIMD: no workgroup waits behind the grid
-            if (waves > cap_waves) waves = cap_waves;
-            A.work_cursor = reinterpret_cast<unsigned int*>(d_total + 5);  // a word of the zeroed scalar block
-            (void)hipEventRecord(ek, stream);
-            timed_k8 = true;
-            if (want_stats) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL(k_find_mems_v3<false>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
-            STEP(hipGetLastError(), "k_find_mems_v3");
-        } else if (nitems && match_type == 1) {
-            A.rows_out = 1;  // K9 of the v3 path places the MAMs and resolves their rows
+int SearchJob::launch(hipStream_t stream) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    char* ws = static_cast<char*>(workspace_dev);
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
+    prefiltered = false; timed_k8 = false; launched = true;
+    (void)hipEventRecord(ev[0], stream);
+    if (nitems && kernel_version == 3) {
+        static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
+        if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
+            uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
+            if (want_stats) hipLaunchKernelGGL(k_prefilter<true>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
+            else hipLaunchKernelGGL(k_prefilter<false>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
+            STEP(hipGetLastError(), "k_prefilter");
+            (void)hipEventRecord(ev[3], stream);
+            prefiltered = true;
+            A.item_alive = d_alive;
+            // dead items emit nothing: their counts are zero; the survivors become a dense work list
+            STEP(hipMemsetAsync(d_counts, 0, nitems * 4, stream), "memset");
             STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
-            hipLaunchKernelGGL(k_find_mams, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
-            STEP(hipGetLastError(), "k_find_mams");
-        } else if (nitems) {
-            hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
-            STEP(hipGetLastError(), "k_find_mems");
+            uint32_t* d_ids = reinterpret_cast<uint32_t*>(ws + w.off_workids);
+            uint32_t* d_nwork = reinterpret_cast<uint32_t*>(d_total) + 8;  // a word of the zeroed scalar block
+            size_t need2 = w.select_bytes;
+            STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
+            A.work_ids = d_ids;
+            A.work_count = d_nwork;
         }
-        (void)hipEventRecord(e1, stream);
-        size_t need = w.scan_bytes;
-        STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need, d_counts, d_itemoff, nitems, stream), "scan");
-        hipLaunchKernelGGL(k_block_offsets, dim3(grid_for(num_blocks + 1)), dim3(256), 0, stream, d_first, d_itemoff,
-                           num_queries, strands, nitems, block_offsets_dev);
-        STEP(hipGetLastError(), "k_block_offsets");
-        unsigned long long listed = 0, total = 0;  // listed: records in the atomic list; total: all MEMs
-        unsigned long long scal[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] listed; u32 word 8: survivors of K8a, word 9: ordinal overflow flag
-        STEP(hipMemcpyAsync(scal, d_total, sizeof(scal), hipMemcpyDeviceToHost, stream), "memcpy");
-        STEP(hipMemcpyAsync(&total, d_itemoff + nitems, 8, hipMemcpyDeviceToHost, stream), "memcpy");
-        STEP(hipStreamSynchronize(stream), "k_find_mems (sync)");
-        listed = scal[0];
-        if ((uint32_t)(scal[4] >> 32) != 0u) {
-            set_error("slamem_find_mems_device: one work item emits 2^28 or more MEMs (a 4096-position slice against a highly "
-                      "repetitive text with a small minimum length); raise min_len");
-            rc = SLAMEM_ERR_CAPACITY;
-            *total_out = total;
-            break;
-        }
-        if (want_stats) {
-            unsigned long long c[SC_COUNT];
-            const uint32_t nwork = (uint32_t)scal[4];
-            STEP(hipMemcpy(c, A.stats, sizeof(c), hipMemcpyDeviceToHost), "memcpy(stats)");
-            slamem_search_stats& o = last_search_stats();
-            memset(&o, 0, sizeof(o));
-            o.fm_lines_top = c[SC_FM_TOP]; o.fm_lines_bottom = c[SC_FM_BOT];
-            o.rec_lines_fail = c[SC_REC_FAIL_LINES]; o.rec_lines_pend = c[SC_REC_PEND_LINES]; o.rec_lines_flush = c[SC_REC_FLUSH_LINES];
-            o.query_loads = c[SC_QUERY_LOADS]; o.lane_trips = c[SC_LANE_TRIPS]; o.wave_trips = c[SC_WAVE_TRIPS];
-            o.positions = c[SC_POSITIONS]; o.enum_jobs = c[SC_ENUM_JOBS];
-            o.dir_sa_lines = c[SC_DIR_SA]; o.dir_group_loads = c[SC_DIR_GROUPS]; o.dir_rec_lines = c[SC_DIR_RECS];
-            o.dir_letters = c[SC_DIR_LETTERS]; o.jump_lines = c[SC_JUMP_LINES];
-            o.prefilter_probes = c[SC_PF_PROBES]; o.prefilter_query_loads = c[SC_PF_QUERY_LOADS]; o.prefilter_items = c[SC_PF_ITEMS];
-            o.items = nitems;
-            o.survivors = prefiltered ? nwork : nitems;
-            o.mems = total;
-            o.overflow_records = listed;
-            o.valid = kernel_version == 3 ? 1 : 0;
-        }
-        *total_out = total;
-        if (total > mems_capacity || listed > mems_capacity) {
-            // the atomic list also holds the records of abandoned slice attempts: ask for room for those too
-            if (listed > total) *total_out = listed;
-            set_error("slamem_find_mems_device: %llu MEMs found, output capacity is %llu", (unsigned long long)*total_out,
-                      (unsigned long long)mems_capacity);
-            rc = SLAMEM_ERR_CAPACITY;
-        } else if (kernel_version == 3 || match_type == 1) {
-            if (total) {
-                hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
-                                   d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);
-                STEP(hipGetLastError(), "k_place_inline");
+        {   // K7q: the strands K8 will scan, packed; then (only if some record was cut into slices) all of those slices
+            uint64_t pb = (nitems * 8 + 255) / 256;
+            hipLaunchKernelGGL(k_pack_queries<8>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, false);
+            if (nitems != num_blocks) {
+                pb = (nitems * 16 + 255) / 256;
+                hipLaunchKernelGGL(k_pack_queries<16>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, true);
             }
-            if (listed) {
-                hipLaunchKernelGGL(k_place_overflow, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                                   (uint64_t)listed, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev);
-                STEP(hipGetLastError(), "k_place_overflow");
-            }
-        } else if (listed) {
-            hipLaunchKernelGGL(k_scatter_mems, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                               (uint64_t)listed, d_itemoff, mems_dev);
-            STEP(hipGetLastError(), "k_scatter_mems");
         }
-        (void)hipEventRecord(e2, stream);
-        STEP(hipStreamSynchronize(stream), "K9 (sync)");
+        STEP(hipGetLastError(), "k_pack_queries");
+        // persistent waves: as many as the chip holds (256 CUs x 16 waves), fewer for small batches
+        uint64_t waves = (nitems + kFetch - 1) / kFetch;
+        static const uint64_t env_waves = [] { const char* v = getenv("SLAMEM_K8_WAVES"); return v ? (uint64_t)atoll(v) : 0ull; }();
+        const uint64_t cap_waves = env_waves ? env_waves : 4096;  // what the chip holds at 4 waves per SIMD: no workgroup waits behind the grid
+        if (waves > cap_waves) waves = cap_waves;
+        A.work_cursor = reinterpret_cast<unsigned int*>(d_total + 5);  // a word of the zeroed scalar block
+        (void)hipEventRecord(ev[4], stream);
+        timed_k8 = true;
+        if (want_stats) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL(k_find_mems_v3<false>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
+        STEP(hipGetLastError(), "k_find_mems_v3");
+    } else if (nitems && match_type == 1) {
+        A.rows_out = 1;  // K9 of the v3 path places the MAMs and resolves their rows
+        STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
+        hipLaunchKernelGGL(k_find_mams, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
+        STEP(hipGetLastError(), "k_find_mams");
+    } else if (nitems) {
+        hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
+        STEP(hipGetLastError(), "k_find_mems");
+    }
+    (void)hipEventRecord(ev[1], stream);
+    return SLAMEM_OK;
+}
+
+int SearchJob::finish(hipStream_t stream) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    char* ws = static_cast<char*>(workspace_dev);
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
+    uint32_t* d_first = reinterpret_cast<uint32_t*>(ws + w.off_first);
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
+    uint64_t* d_itemoff = reinterpret_cast<uint64_t*>(ws + w.off_itemoff);
+    Timings& tm = thread_timings();
+    size_t need = w.scan_bytes;
+    STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need, d_counts, d_itemoff, nitems, stream), "scan");
+    hipLaunchKernelGGL(k_block_offsets, dim3(grid_for(num_blocks + 1)), dim3(256), 0, stream, d_first, d_itemoff,
+                       num_queries, strands, nitems, block_offsets_dev);
+    STEP(hipGetLastError(), "k_block_offsets");
+    unsigned long long listed = 0, tot = 0;  // listed: records in the atomic list; tot: all MEMs
+    unsigned long long scal[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] listed; u32 word 8: survivors of K8a, word 9: ordinal overflow flag
+    STEP(hipMemcpyAsync(scal, d_total, sizeof(scal), hipMemcpyDeviceToHost, stream), "memcpy");
+    STEP(hipMemcpyAsync(&tot, d_itemoff + nitems, 8, hipMemcpyDeviceToHost, stream), "memcpy");
+    STEP(hipStreamSynchronize(stream), "k_find_mems (sync)");
+    listed = scal[0];
+    total = tot;
+    if ((uint32_t)(scal[4] >> 32) != 0u) {
+        set_error("slamem_find_mems_device: one work item emits 2^28 or more MEMs (a 4096-position slice against a highly "
+                  "repetitive text with a small minimum length); raise min_len");
+        return SLAMEM_ERR_CAPACITY;
+    }
+    if (want_stats) {
+        unsigned long long c[SC_COUNT];
+        const uint32_t nwork = (uint32_t)scal[4];
+        STEP(hipMemcpy(c, A.stats, sizeof(c), hipMemcpyDeviceToHost), "memcpy(stats)");
+        slamem_search_stats& o = last_search_stats();
+        memset(&o, 0, sizeof(o));
+        o.fm_lines_top = c[SC_FM_TOP]; o.fm_lines_bottom = c[SC_FM_BOT];
+        o.rec_lines_fail = c[SC_REC_FAIL_LINES]; o.rec_lines_pend = c[SC_REC_PEND_LINES]; o.rec_lines_flush = c[SC_REC_FLUSH_LINES];
+        o.query_loads = c[SC_QUERY_LOADS]; o.lane_trips = c[SC_LANE_TRIPS]; o.wave_trips = c[SC_WAVE_TRIPS];
+        o.positions = c[SC_POSITIONS]; o.enum_jobs = c[SC_ENUM_JOBS];
+        o.dir_sa_lines = c[SC_DIR_SA]; o.dir_group_loads = c[SC_DIR_GROUPS]; o.dir_rec_lines = c[SC_DIR_RECS];
+        o.dir_letters = c[SC_DIR_LETTERS]; o.jump_lines = c[SC_JUMP_LINES];
+        // 100 MHz clock -> microseconds
+        last_search_clock()[0] = (c[SC_T_DRAIN] - c[SC_T_FIRST]) / 100.0;
+        last_search_clock()[1] = (c[SC_T_LAST] - c[SC_T_DRAIN]) / 100.0;
+        last_search_clock()[2] = c[SC_T_WAVE_SUM] / 100.0;
+        o.prefilter_probes = c[SC_PF_PROBES]; o.prefilter_query_loads = c[SC_PF_QUERY_LOADS]; o.prefilter_items = c[SC_PF_ITEMS];
+        o.items = nitems;
+        o.survivors = prefiltered ? nwork : nitems;
+        o.mems = total;
+        o.overflow_records = listed;
+        o.valid = kernel_version == 3 ? 1 : 0;
+    }
+    if (total > mems_capacity || listed > mems_capacity) {
+        // the atomic list also holds the records of abandoned slice attempts: ask for room for those too
+        if (listed > total) total = listed;
+        set_error("slamem_find_mems_device: %llu MEMs found, output capacity is %llu", (unsigned long long)total,
+                  (unsigned long long)mems_capacity);
+        return SLAMEM_ERR_CAPACITY;
+    }
+    if (kernel_version == 3 || match_type == 1) {
+        if (total) {
+            hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
+                               d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);
+            STEP(hipGetLastError(), "k_place_inline");
+        }
+        if (listed) {
+            hipLaunchKernelGGL(k_place_overflow, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
+                               (uint64_t)listed, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev);
+            STEP(hipGetLastError(), "k_place_overflow");
+        }
+    } else if (listed) {
+        hipLaunchKernelGGL(k_scatter_mems, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
+                           (uint64_t)listed, d_itemoff, mems_dev);
+        STEP(hipGetLastError(), "k_scatter_mems");
+    }
+    (void)hipEventRecord(ev[2], stream);
+    STEP(hipStreamSynchronize(stream), "K9 (sync)");
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
+        tm.t.search_kernel_ms = ms;
+        tm.t.search_kernel_ms_sum += ms;
+        tm.t.search_launches++;
+    }
+    if (prefiltered && hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) {  // K8a
+        tm.t.prefilter_ms = ms;
+        tm.t.prefilter_ms_sum += ms;
+    }
+    if (timed_k8 && hipEventElapsedTime(&ms, ev[4], ev[1]) == hipSuccess) {    // K8 alone
+        tm.t.k8_ms = ms;
+        tm.t.k8_ms_sum += ms;
+    }
+    if (hipEventElapsedTime(&ms, ev[0], ev[2]) == hipSuccess) tm.t.search_total_ms = ms;
+    return SLAMEM_OK;
+}
 #undef STEP
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
-            tm.t.search_kernel_ms = ms;
-            tm.t.search_kernel_ms_sum += ms;
-            tm.t.search_launches++;
-        }
-        if (prefiltered && hipEventElapsedTime(&ms, e0, ep) == hipSuccess) {  // work-item fill + K8a
-            tm.t.prefilter_ms = ms;
-            tm.t.prefilter_ms_sum += ms;
-        }
-        if (timed_k8 && hipEventElapsedTime(&ms, ek, e1) == hipSuccess) {    // K8 alone
-            tm.t.k8_ms = ms;
-            tm.t.k8_ms_sum += ms;
-        }
-        if (hipEventElapsedTime(&ms, e0, e2) == hipSuccess) tm.t.search_total_ms = ms;
-    } while (0);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (e2) (void)hipEventDestroy(e2);
-    if (ep) (void)hipEventDestroy(ep);
-    if (ek) (void)hipEventDestroy(ek);
+
+// the same steps behind an opaque pointer, for stream.hip
+SearchJob* search_job_new() { return new (std::nothrow) SearchJob(); }
+void search_job_delete(SearchJob* j) { delete j; }
+int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev, uint32_t num_queries,
+                    uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type, slamem_mem* mems_dev,
+                    uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev, uint64_t workspace_bytes) {
+    return j->init(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev, mems_capacity,
+                   block_offsets_dev, workspace_dev, workspace_bytes);
+}
+int search_job_tables(SearchJob* j, hipStream_t stream) { return j->tables(stream); }
+int search_job_launch(SearchJob* j, hipStream_t stream) { return j->launch(stream); }
+int search_job_finish(SearchJob* j, hipStream_t stream) { return j->finish(stream); }
+uint64_t search_job_total(const SearchJob* j) { return j->total; }
+int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
+                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
+                     slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
+                     uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out) {
+    if (!total_out) { set_error("slamem_find_mems_device: null argument"); return SLAMEM_ERR_ARG; }
+    SearchJob job;
+    int rc = job.init(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev,
+                      mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes);
+    if (rc == SLAMEM_OK) rc = job.tables(stream);
+    if (rc == SLAMEM_OK) rc = job.launch(stream);
+    if (rc == SLAMEM_OK) rc = job.finish(stream);
+    else if (job.launched) (void)hipStreamSynchronize(stream);  // never return with kernels of this call in flight
+    *total_out = job.total;
     return rc;
 }
 

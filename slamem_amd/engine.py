@@ -396,7 +396,11 @@ def search_stats(matcher: "Matcher", queries_dev: torch.Tensor, offsets_dev: tor
         L.slamem_search_stats_enable(0)
     st = capi.SearchStats()
     capi.check(L.slamem_get_search_stats(C.byref(st)))
-    return st.as_dict()
+    out = st.as_dict()
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    L.slamem_get_search_clock(C.byref(a), C.byref(b), C.byref(c))
+    out["k8_us_until_list_empty"], out["k8_us_tail"], out["k8_wave_us_sum"] = a.value, b.value, c.value
+    return out
 
 
 def random_line_ceiling(index: "Index", lanes: int = 256 * 32 * 64 * 4, iters: int = 64) -> float:

@@ -25,7 +25,7 @@ m.run(reads, offsets, 20); engine.reset_timings()
 t0 = time.perf_counter(); tot = m.run(reads, offsets, 20); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({"device_resident_ms": dt * 1e3, "mems": tot, "kernel_ms": engine.timings()["search_kernel_ms"]}), flush=True)
 del m
-for batch, slots in ((500_000, 6), (1_000_000, 5), (1_000_000, 6), (1_500_000, 6), (2_000_000, 5)):
+for batch, slots in ((500_000, 6), (1_000_000, 6), (1_000_000, 8), (1_500_000, 6), (2_000_000, 6)):
     r = engine.host_to_host_leg(idx, reads, M, L, 20, True, steps=2, batch_reads=batch, slots=slots)
     print(json.dumps({"batch_reads": batch, "slots": slots, "ms": r["host_to_host_ms"], "MEMs_per_s": r["value_host_to_host"],
                       "kernel_ms_sum": r["host_to_host"]["kernel_ms_sum"]}), flush=True)
