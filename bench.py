@@ -317,10 +317,11 @@ def main():
                                  "dir_sa_lines", "dir_group_loads", "dir_rec_lines")}
         k8_lines = (st["fm_lines_top"] + st["fm_lines_bottom"] + st["rec_lines_fail"] + st["rec_lines_pend"]
                     + st["rec_lines_flush"] + st.get("dir_sa_lines", 0) + st.get("dir_group_loads", 0)
-                    + st.get("dir_rec_lines", 0) + st.get("jump_lines", 0))
+                    + st.get("dir_rec_lines", 0) + st.get("jump_lines", 0) + st.get("skip_group_loads", 0)
+                    + st.get("skip_probe_lines", 0) + st.get("skip_attempts", 0))
         # 64 B per random line; the packed query windows (16 B, 32 letters) and the 16 B of query beside a text group are
         # sequential within a strand's 80 bytes
-        k8_bytes = 64 * k8_lines + 16 * (st["query_loads"] + st.get("dir_group_loads", 0))
+        k8_bytes = 64 * k8_lines + 16 * (st["query_loads"] + st.get("dir_group_loads", 0) + st.get("skip_group_loads", 0))
         k8a_bytes = 64 * st["prefilter_probes"] + 16 * st["prefilter_query_loads"]
         k8_s = r["k8_ms"] * 1e-3
         ceiling = engine.random_line_ceiling(index) if hasattr(engine, "random_line_ceiling") else None

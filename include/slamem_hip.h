@@ -113,7 +113,10 @@ typedef struct {
     uint64_t dir_rec_lines;         /* K8 direct extension: text-ordered records (one per run)                         */
     uint64_t dir_letters;           /* K8 direct extension: query positions consumed by comparing with the text        */
     uint64_t jump_lines;            /* K8: K-mer jump table entries read (one per scan start)                          */
-    uint64_t reserved[1];
+    uint64_t skip_group_loads;      /* K8 skipping: text groups read to verify the diagonal behind a disagreeing letter */
+    uint64_t skip_probe_lines;      /* K8 skipping: words of the k-mer occurrence bitmap read                          */
+    uint64_t skip_attempts;         /* K8 skipping: diagonals verified (probes follow)                                 */
+    uint64_t skips;                 /* K8 skipping: stretches skipped (min_len positions each)                         */
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

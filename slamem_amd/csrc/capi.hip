@@ -96,6 +96,10 @@ static int header_ok(const ArenaHeader& h, uint64_t bytes) {
         if (!bad && (h.kjump_k < 1 || h.kjump_k > 12)) bad = "jump table K";
         if (!bad) section(h.off_kjump, 8ull << (2u * h.kjump_k), "jump table");
     }
+    if (h.off_kbits) {
+        if (!bad && (h.kbits_k < 8 || h.kbits_k > 16)) bad = "occurrence bitmap k";
+        if (!bad) section(h.off_kbits, (1ull << (2u * h.kbits_k)) >> 3, "occurrence bitmap");
+    }
     if (!bad && h.dollar_row > h.n) bad = "'$' row";
     if (bad) {
         set_error("index arena is corrupt or truncated: bad %s", bad);

@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 9;  // 9: K-mer jump table; 8: text-ordered groups + parent records (direct extension)
+constexpr uint32_t kArenaVersion = 10;  // 10: k-mer occurrence bitmap; 9: K-mer jump table; 8: text-ordered groups + parent records
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -93,7 +93,10 @@ struct ArenaHeader {
     uint32_t sort_rounds;
     uint32_t C[6];        // C[c] = number of characters of text+'$' smaller than c
     uint32_t kjump_k;     // K of the jump table (0 = none)
-    uint32_t reserved[15];
+    uint32_t kbits_k;     // k of the occurrence bitmap (0 = none)
+    uint32_t reserved0;
+    uint64_t off_kbits;   // uint64[4^kbits_k / 64]  one bit per k-mer over A,C,G,T: does it occur in the text?
+    uint32_t reserved[11];
 };
 static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 
@@ -108,6 +111,8 @@ struct IndexView {
     const TextRec* prec;
     const uint2* kjump;       // nullptr when the index has no K-mer jump table
     uint32_t kjump_k;
+    uint32_t kbits_k;
+    const uint64_t* kbits;    // nullptr when the index has no k-mer occurrence bitmap
     uint32_t n;
     uint32_t nblocks;
     uint32_t dollar_row;

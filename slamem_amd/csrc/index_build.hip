@@ -417,6 +417,27 @@ __global__ void __launch_bounds__(256) k_kjump_init(uint2* __restrict__ table, u
     if (i < entries) table[i] = make_uint2(1u, 0u);  // top > bottom: the K-mer does not occur
 }
 
+// k-mer occurrence bitmap (no reference counterpart): bit x of the bitmap = the k-mer with value x (2 bits per letter,
+// first letter on top) occurs in the text.  Directly addressed -- no hash -- so that K8 can test a handful of windows
+// around a substituted letter in one trip (mem_search.hip, states SKV / SKQ / SKP).
+__global__ void __launch_bounds__(256) k_kbits_build(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
+                                                     unsigned long long* __restrict__ bits) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + k > n) return;
+    uint64_t x = window16(pk, i);
+    const uint64_t v = ((x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ull;  // nibble >= 2: one of A,C,G,T
+    const uint64_t topk = ~0ull << (4u * (16u - k));
+    if ((v & topk) != (0x1111111111111111ull & topk)) return;
+    x = (x & topk) | (0x2222222222222222ull & ~topk);
+    x = (x - 0x2222222222222222ull) & topk;
+    x = (x & 0x0303030303030303ull) | ((x & 0x3030303030303030ull) >> 2);
+    x = (x & 0x000F000F000F000Full) | ((x & 0x0F000F000F000F00ull) >> 4);
+    x = (x & 0x000000FF000000FFull) | ((x & 0x00FF000000FF0000ull) >> 8);
+    x = (x & 0xFFFFull) | ((x >> 16) & 0xFFFF0000ull);
+    const uint32_t key = (uint32_t)x >> (2u * (16u - k));
+    atomicOr(&bits[key >> 6], 1ull << (key & 63u));
+}
+
 // text-ordered records (TextRec) and the parent-depth class of every text position (one byte each, packed into the
 // groups by k_text_groups): one random 16-byte read of the row's record per position
 __global__ void __launch_bounds__(256) k_text_records(const uint32_t* __restrict__ isa, const RowRec* __restrict__ rec,
@@ -634,6 +655,8 @@ void make_view(slamem_index* idx) {
     idx->view.prec = h.off_tgrp ? reinterpret_cast<const TextRec*>(base + h.off_prec) : nullptr;
     idx->view.kjump = h.off_kjump ? reinterpret_cast<const uint2*>(base + h.off_kjump) : nullptr;
     idx->view.kjump_k = h.off_kjump ? h.kjump_k : 0u;
+    idx->view.kbits = h.off_kbits ? reinterpret_cast<const uint64_t*>(base + h.off_kbits) : nullptr;
+    idx->view.kbits_k = h.off_kbits ? h.kbits_k : 0u;
     idx->view.kfilter_log2 = h.kfilter_log2;
     idx->view.kfilter_k = h.kfilter_k;
     idx->view.n = h.n;
@@ -745,6 +768,18 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         if (K > 0) {
             hdr.kjump_k = K;
             hdr.off_kjump = off; off = align_up(off + (8ull << (2u * K)), 256);
+        }
+    }
+    {   // k-mer occurrence bitmap: k = ceil(log4 n) + 2 (at most 16: the value fits 32 bits, the bitmap 512 MB), only while
+        // fewer than a tenth of all k-mers occur -- a denser bitmap proves nothing absent; SLAMEM_KBITS=0 builds without
+        const char* kb = getenv("SLAMEM_KBITS");
+        uint32_t k = 2;
+        for (uint64_t v = 1; v < (uint64_t)n; v <<= 2) k++;
+        if (k < 8) k = 8;
+        if (k > 16) k = 16;
+        if (!(kb && atoi(kb) == 0) && n >= k && (uint64_t)n * 10ull <= (1ull << (2u * k))) {
+            hdr.kbits_k = k;
+            hdr.off_kbits = off; off = align_up(off + ((1ull << (2u * k)) >> 3), 256);
         }
     }
     hdr.total_bytes = off;
@@ -864,6 +899,13 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         hipLaunchKernelGGL(k_kjump_init, dim3(grid_for(1ull << (2u * hdr.kjump_k))), dim3(256), 0, stream, d_kj, 1ull << (2u * hdr.kjump_k));
         hipLaunchKernelGGL(k_kjump_keys, dim3(grid_for(R)), dim3(256), 0, stream, d_sa, pk.as<uint64_t>(), n, hdr.kjump_k, tmp32.as<uint32_t>());
         hipLaunchKernelGGL(k_kjump_bounds, dim3(grid_for(R)), dim3(256), 0, stream, tmp32.as<uint32_t>(), n, d_kj);
+        SLAMEM_HIP(hipGetLastError());
+    }
+    if (hdr.off_kbits) {
+        unsigned long long* d_bits = reinterpret_cast<unsigned long long*>(base + hdr.off_kbits);
+        SLAMEM_HIP(hipMemsetAsync(d_bits, 0, (1ull << (2u * hdr.kbits_k)) >> 3, stream));
+        hipLaunchKernelGGL(k_kbits_build, dim3(grid_for((uint64_t)n - hdr.kbits_k + 1)), dim3(256), 0, stream, pk.as<uint64_t>(), n,
+                           hdr.kbits_k, d_bits);
         SLAMEM_HIP(hipGetLastError());
     }
     if (hdr.off_kfilter) {

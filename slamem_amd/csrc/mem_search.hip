@@ -191,6 +191,11 @@ struct SearchArgs {
     int32_t direct_min_depth;   // v3: a single-row match at least this deep is extended by comparing with the text (<0: off)
     uint32_t use_jump;          // v3: take the first K letters of a scan through the K-mer jump table
     uint32_t rows_out;          // v1 / MAM kernels: store rows through the v3 output path (inline slots + overflow list)
+    uint32_t skip_w;            // v3: letters verified on the diagonal behind a disagreeing letter (min_len - 1); 0 = no skipping
+    const uint64_t* pq2;        // v3: the strands at 2 bits per letter (32 letters per word), at half the offsets of pq
+    uint64_t* pq2_out;
+    uint8_t* item_flags;        // v3: 1 = the strand holds a letter that is not A,C,G,T (or is a slice): no skipping
+    uint32_t skip_s1;           // v3: stride of the probed k-mers, min_len - k + 1
     uint32_t pad4;
 };
 
@@ -555,7 +560,7 @@ enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
     SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
-    SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_COUNT
+    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -595,6 +600,7 @@ __global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A, bool long_on
     const uint32_t a = sl * kSliceLen;
     const uint32_t b = d.len - a < kSliceLen ? d.len : a + kSliceLen;
     uint64_t* out = A.pq_out + A.item_pk[item];
+    uint32_t* out2 = A.pq2_out ? reinterpret_cast<uint32_t*>(A.pq2_out + (A.item_pk[item] >> 1)) : nullptr;
     const uint32_t w0 = a >> 4;
     // the last slice also writes the zero padding up to the strand's 16-byte-aligned end
     const uint32_t w1 = b == d.len ? 2u * ((d.len + 31u) >> 5) : (b >> 4);
@@ -639,6 +645,18 @@ __global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A, bool long_on
             }
         }
         out[w] = u64_of(wlo, whi);
+        if (out2) {
+            // the same 16 letters at 2 bits each ((id - 2) & 3) in the half of the 64-bit word they belong to -- letters
+            // 0..15 of a 32-letter word are its high half -- and a flag for the item if one of them is not A,C,G,T
+            uint32_t c = (whi + 0x66666666u) & 0x33333333u, e = (wlo + 0x66666666u) & 0x33333333u;
+            c = (c | (c >> 2)) & 0x0F0F0F0Fu; c = (c | (c >> 4)) & 0x00FF00FFu; c = (c | (c >> 8)) & 0x0000FFFFu;
+            e = (e | (e >> 2)) & 0x0F0F0F0Fu; e = (e | (e >> 4)) & 0x00FF00FFu; e = (e | (e >> 8)) & 0x0000FFFFu;
+            out2[2u * (w >> 1) + ((w & 1u) ^ 1u)] = (c << 16) | e;
+            const uint32_t cntw = p0 < d.len ? (d.len - p0 < 16u ? d.len - p0 : 16u) : 0u;
+            const uint32_t vhi = ((whi >> 1) | (whi >> 2) | (whi >> 3)) & 0x11111111u, vlo = ((wlo >> 1) | (wlo >> 2) | (wlo >> 3)) & 0x11111111u;
+            const uint32_t nvalid = (uint32_t)__popc(vhi) + (uint32_t)__popc(vlo);
+            if (nvalid != cntw || long_only) A.item_flags[item] = 1;  // (slices of long records: no skipping, for now)
+        }
     }
     }
 }
@@ -673,16 +691,34 @@ struct PackedCursor {
 // letters one FMI_FollowLetter at a time (slamem.c:121); the output is the same: as long as the letters agree the single
 // row's BWT letter IS the query letter (nothing is left-maximal) and only an ancestor >= min_len could emit.
 // JQ / JT: the first K letters of a scan through the K-mer jump table (query words, then the table entry).
-enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DEND = 5, ST_JQ = 6, ST_JT = 7 };
+// SKV / SKQ / SKP: skipping the stretch of chance matches behind a disagreeing letter.  A direct run that ends on a
+// disagreeing letter at strand position p (text position s) is followed, in the reference's scan, by ~log4(n) positions
+// whose longest matches are chance k-mers (1.9 failed extensions each: most of the kernel's lines).  They cannot emit
+// anything, and the scan is back on the same diagonal afterwards, IF (SKV) the next w = min_len-1 letters of the diagonal
+// agree, Q[p-w..p) = T[s-w..s), and the suffix at s-w shares fewer than w letters with its neighbours in suffix order
+// (parent-depth class), and (SKQ, SKP) no min_len-mer window of the strand that covers p occurs in the text -- every such
+// window contains one of the k-mers that start at multiples of s1 = min_len-k+1 in [p-min_len+1, p+s1-1], and the
+// occurrence bitmap says that none of them occurs.  Then every position j in [p-w, p] has a longest match shorter than
+// min_len (it would be such a window), so nothing is emitted there; and at j = p-w the longest match is exactly the
+// diagonal's w letters, in ONE row: the direct run goes on from (j, text position s-w, depth w) without touching the
+// index.  Anything else (a second disagreeing letter, a present k-mer, an N, a deep class, too little room) takes the
+// normal route (DEND, then the index walk).
+enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DEND = 5, ST_JQ = 6, ST_JT = 7,
+                  ST_SKV = 8, ST_SKQ = 9, ST_SKP = 10 };
 
 #ifndef SLAMEM_V3_WAVES
 #define SLAMEM_V3_WAVES 1
 #endif
-template <bool kStats>
-__global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
+// kSkip: the instantiation that carries the skipping states (SKV / SKQ / SKP).  Measured (profiles/r02_skip_experiment.txt):
+// exact, 27 % fewer lines and 32 % fewer lane trips, but the same time -- the kernel is bound by instruction issue and
+// every trip pays for the union of the states its lanes are in -- so the default kernel is the one without them
+// (SLAMEM_SKIP=1 selects this one).
+template <bool kStats, bool kSkip>
+__global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
     __shared__ ItemDesc lds_item[4][kFetch];
     __shared__ uint64_t lds_pk[4][kFetch];
     __shared__ uint32_t lds_id[4][kFetch];
+    __shared__ uint32_t lds_q2[kSkip ? 6 : 1][kSkip ? 256 : 1];  // skipping: the lane's three 2-bit strand words as six 32-bit halves
     const IndexView& ix = A.ix;
     const int L = (int)A.min_len;
     const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
@@ -703,13 +739,19 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
     const uint64_t cls_add = (uint64_t)(8u - (cL & 7u)) * k1;
     const bool cls_hi = cL >= 8u;
     const uint32_t jK = (ix.kjump && (int)ix.kjump_k < L && A.use_jump) ? ix.kjump_k : 0u;
+    const uint32_t skw = kSkip ? A.skip_w : 0u, sks1 = A.skip_s1, kd = ix.kbits_k;  // skipping (skw = 0: off)
+    const uint32_t sknp = skw ? (kd - 1u + sks1 - 1u) / sks1 + 1u : 0u;  // probes per disagreeing letter
+    const uint32_t cW = depth_class((int)skw);
+    const uint64_t clsw_add = (uint64_t)(8u - (cW & 7u)) * k1;
+    const bool clsw_hi = cW >= 8u;
 
     // diagnostic instantiation only: when the first wave started, when the first wave found the list empty, when the last
     // wave left (100 MHz wall clock), and the sum over waves of the time they ran
     const unsigned long long t_wave0 = kStats ? wall_clock64() : 0ull;
     if (kStats && (threadIdx.x & 63u) == 0u) atomicMin(A.stats + SC_T_FIRST, t_wave0);
     uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_wtrips = 0, n_pos = 0,
-             n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0, n_jump = 0;
+             n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0, n_jump = 0, n_skv = 0, n_skq = 0,
+             n_skp = 0, n_skok = 0;
 
     bool active = false, pend = false, dmis = false, dcool = false;
     uint32_t st = ST_EXT;
@@ -799,6 +841,9 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             // quad of `top`; or a text group and the query words that face it; or the text-ordered record
             const uint4* a1 = nullptr;
             const uint2* a2 = nullptr;
+            const uint2* a3 = nullptr;    // (SKQ only: a third 8-byte word)
+            const uint8_t* a4 = nullptr;  // (SKQ only: the item's flag)
+            uint32_t pk_bits = 0, pk_bit5 = 0, pk_mask = 0, flag8 = 0;  // (SKP only: bit positions of the probes, which exist)
             uint4 rt = make_uint4(0, 0, 0, 0);
             uint2 rb0 = make_uint2(0, 0), rb1 = rb0;
             bool want_rec = false;
@@ -817,13 +862,17 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             } else if (st == ST_DSA) {
                 a1 = reinterpret_cast<const uint4*>(ix.sa + (top & ~3u));  // the aligned quad that holds SA[top]
                 if (kStats) n_dsa++;
-            } else if (st == ST_DIR) {
-                const uint32_t gi = (dir_r - 1u) >> 4;  // dir_r >= 1 here
-                dm = dir_r - (gi << 4);                 // letters of the group below dir_r: 1..16
+            } else if (st == ST_DIR || (kSkip && st == ST_SKV)) {
+                // DIR: the letters below text position dir_r face the strand positions below j.  SKV: the same comparison one
+                // letter further down (behind the disagreeing letter), `pub` letters of the diagonal already looked at
+                const uint32_t back = (kSkip && st == ST_SKV) ? 1u + (uint32_t)pub : 0u;
+                const uint32_t dirp = dir_r - back, jp = j - back;
+                const uint32_t gi = (dirp - 1u) >> 4;  // dirp >= 1 here
+                dm = dirp - (gi << 4);                 // letters of the group below dirp: 1..16
                 a1 = reinterpret_cast<const uint4*>(ix.tgrp + gi);
-                qs = (int)j - (int)dm;                  // strand position that faces the group's first letter (may be < 0)
+                qs = (int)jp - (int)dm;                // strand position that faces the group's first letter (may be < 0)
                 a2 = reinterpret_cast<const uint2*>(reinterpret_cast<const uint64_t*>(qc.p) + (qs >> 4));
-                if (kStats) n_dgrp++;
+                if (kStats) { if (st == ST_SKV) n_skv++; else n_dgrp++; }
             } else if (st == ST_DEND) {
                 a1 = reinterpret_cast<const uint4*>(ix.prec + dir_r);
                 if (kStats) n_drec++;
@@ -833,6 +882,41 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             } else if (st == ST_JT) {
                 a2 = ix.kjump + dir_r;  // (dir_r holds the key between the two trips; one 8-byte entry)
                 if (kStats) n_jump++;
+            } else if (kSkip && st == ST_SKQ) {
+                // the strand at 2 bits per letter around p = j-1: the probed k-mers all contain p, so they lie in
+                // [p-k+1, p+k): at most 62 letters from the start of the word that holds p-k+1 -- two words, a third for safety
+                const uint32_t y0 = j - kd;  // = p - (k-1)
+                const uint64_t* p2 = A.pq2 + ((reinterpret_cast<const uint64_t*>(qc.p) - A.pq) >> 1) + (y0 >> 5);
+                a2 = reinterpret_cast<const uint2*>(p2);
+                a3 = reinterpret_cast<const uint2*>(p2 + 2);
+                a4 = A.item_flags + g;
+                if (kStats) n_skq++;
+            } else if (kSkip && st == ST_SKP) {
+                // the probed k-mers: starts p-(k-1), p-(k-1)+s1, ... and p itself -- every one contains p, consecutive starts
+                // are at most s1 = min_len-k+1 apart, so every min_len-mer window that covers p contains one of them
+                // (the lane's 2-bit words wait in LDS since the last trip: a k-mer of 16 letters or fewer lies in two
+                //  consecutive 32-bit halves)
+                const uint32_t y0 = j - kd;
+                const uint32_t o0 = y0 & 31u;
+#pragma unroll
+                for (uint32_t i = 0; i < 6u; i++) {
+                    if (i < sknp) {
+                        uint32_t d = i * sks1;
+                        if (d > kd - 1u) d = kd - 1u;
+                        const uint32_t o = o0 + d;  // letter offset from the start of the first word (< 32 + k)
+                        const uint32_t h0 = lds_q2[o >> 4][threadIdx.x], h1 = lds_q2[(o >> 4) + 1u][threadIdx.x];
+                        const uint32_t sh = 2u * (o & 15u);
+                        const uint32_t v32 = sh ? (h0 << sh) | (h1 >> (32u - sh)) : h0;
+                        const uint32_t key = v32 >> (32u - 2u * kd);
+                        if (i < 5u) pk_bits |= (key & 63u) << (6u * i); else pk_bit5 = key & 63u;
+                        pk_mask |= 1u << i;
+                        const uint2 wv = *reinterpret_cast<const uint2*>(ix.kbits + (key >> 6));
+                        if (i == 0) { kb.a.x = wv.x; kb.a.y = wv.y; } else if (i == 1) { kb.a.z = wv.x; kb.a.w = wv.y; }
+                        else if (i == 2) { kb.b.x = wv.x; kb.b.y = wv.y; } else if (i == 3) { kb.b.z = wv.x; kb.b.w = wv.y; }
+                        else if (i == 4) { kb.c.x = wv.x; kb.c.y = wv.y; } else { kb.c.z = wv.x; kb.c.w = wv.y; }
+                        if (kStats) n_skp++;
+                    }
+                }
             } else {
                 want_rec = true;  // ST_REC, ST_FLUSH
             }
@@ -844,6 +928,8 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
             if (want_rec) { a1 = R + top; a2 = reinterpret_cast<const uint2*>(R + bot); }
             if (a1) rt = *a1;
             if (a2) { rb0 = a2[0]; if (st != ST_JT) rb1 = a2[1]; }
+            if (a3) { const uint2 t3 = a3[0]; rt.x = t3.x; rt.y = t3.y; }
+            if (a4) flag8 = *a4;
             if (st == ST_EXT) {
                 if (kStats) n_qloads += qc.would_load(j - 1u);
                 c = qc.at(j - 1u);  // issues the query-window load (if any) behind the ones above
@@ -890,14 +976,43 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                     top = rb0.x; bot = rb0.y; depth = (int)jK; pub = (int)jK - 1; j -= jK;
                     if (kStats) n_pos += jK;
                 }
+            } else if (kSkip && st == ST_SKQ) {
+                if (flag8) { dmis = true; st = ST_DEND; }  // a letter that is not A,C,G,T somewhere in the strand
+                else {  // (a 64-bit word holds its first 16 letters in its high half)
+                    lds_q2[0][threadIdx.x] = rb0.y; lds_q2[1][threadIdx.x] = rb0.x;
+                    lds_q2[2][threadIdx.x] = rb1.y; lds_q2[3][threadIdx.x] = rb1.x;
+                    lds_q2[4][threadIdx.x] = rt.y; lds_q2[5][threadIdx.x] = rt.x;
+                    st = ST_SKP;
+                }
+            } else if (kSkip && st == ST_SKP) {
+                uint32_t present = 0;
+                present |= (pk_mask >> 0) & (uint32_t)(u64_of(kb.a.x, kb.a.y) >> ((pk_bits >> 0) & 63u));
+                present |= (pk_mask >> 1) & (uint32_t)(u64_of(kb.a.z, kb.a.w) >> ((pk_bits >> 6) & 63u));
+                present |= (pk_mask >> 2) & (uint32_t)(u64_of(kb.b.x, kb.b.y) >> ((pk_bits >> 12) & 63u));
+                present |= (pk_mask >> 3) & (uint32_t)(u64_of(kb.b.z, kb.b.w) >> ((pk_bits >> 18) & 63u));
+                present |= (pk_mask >> 4) & (uint32_t)(u64_of(kb.c.x, kb.c.y) >> ((pk_bits >> 24) & 63u));
+                // (a sixth probe's bit position does not fit pk_bits: kept apart)
+                present |= (pk_mask >> 5) & (uint32_t)(u64_of(kb.c.z, kb.c.w) >> (pk_bit5 & 63u));
+                if (present & 1u) { dmis = true; st = ST_DEND; }  // one of the k-mers occurs: the normal route
+                else {
+                    // certified.  The position in front of the disagreeing letter is left-maximal: its one row (text position
+                    // dir_r) is emitted if it is long enough (no ancestor can qualify: its class was checked when the run stopped)
+                    const bool in_slice = j >= a_pos && j < b_pos;
+                    if (depth >= L && in_slice) { emit3_at(A, g, k, attempt << 28, dir_r, j, (uint32_t)depth | 0x80000000u); k++; }
+                    j -= skw + 1u; dir_r -= skw + 1u; depth = (int)skw;
+                    pend = false;
+                    st = ST_DIR;
+                    if (kStats) { n_skok++; n_pos += skw + 1u; n_dlet += skw + 1u; }
+                }
             } else if (st == ST_DSA) {
                 const uint32_t o = top & 3u;
                 dir_r = o == 0u ? rt.x : o == 1u ? rt.y : o == 2u ? rt.z : rt.w;
                 dmis = true;  // read only when the text begins here: '$' on the left never equals a query letter
                 st = dir_r == 0u ? ST_DEND : ST_DIR;
-            } else if (st == ST_DIR) {
-                // the group's letters face strand positions qs .. qs+15, letter i in nibble 15-i.  Letters dm-1, dm-2, ...
-                // (text positions dir_r-1 downwards) are compared with strand positions j-1, j-2, ...
+            } else if (st == ST_DIR || (kSkip && st == ST_SKV)) {
+                // the group's letters face strand positions qs .. qs+15, letter i in nibble 15-i.  Letters dm-1, dm-2, ... are
+                // compared with the strand positions below
+                const bool ver = kSkip && st == ST_SKV;
                 const uint64_t T = u64_of(rt.x, rt.y), C = u64_of(rt.z, rt.w);
                 const uint64_t w0 = u64_of(rb0.x, rb0.y), w1 = u64_of(rb1.x, rb1.y);
                 const uint32_t sh = ((uint32_t)qs & 15u) * 4u;
@@ -906,32 +1021,55 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
                 x |= x >> 1; x |= x >> 2;
                 const uint64_t mis = x & k1;                                   // nibble LSB set: the letters differ
                 const uint64_t lo3 = C & (7ull * k1), h8 = (C >> 3) & k1;
-                const uint64_t ge = ((lo3 + cls_add) >> 3) & k1;
-                const uint64_t flag = cls_hi ? (h8 & ge) : (h8 | ge);          // class >= cL: an ancestor may qualify
-                const uint32_t W = j - a_pos;                                   // letters this item may still consume (>= 1)
-                const uint32_t take = dm < W ? dm : W;
-                const uint32_t nlo = 16u - dm, nhi = nlo + take;                // nibbles of the letters in play
-                uint64_t mask = nhi >= 16u ? ~0ull : ((1ull << (4u * nhi)) - 1ull);
-                mask &= ~((1ull << (4u * nlo)) - 1ull);
-                const uint64_t stop = (mis | flag) & mask;
-                uint32_t kc;
-                const bool hit = stop != 0ull;
-                if (hit) {
-                    const uint32_t nib = (uint32_t)__builtin_ctzll(stop) >> 2;
-                    kc = nib - nlo;
-                    dmis = ((mis >> (4u * nib)) & 1ull) != 0ull;
-                    dcool = !dmis;  // stopped by a class flag: the index walk takes over until the interval changes
+                const uint64_t ge = ((lo3 + (ver ? clsw_add : cls_add)) >> 3) & k1;
+                // DIR: class >= class(min_len): an ancestor may qualify.  SKV: class >= class(w): maybe >= w letters shared
+                const uint64_t flag = (ver ? clsw_hi : cls_hi) ? (h8 & ge) : (h8 | ge);
+                const uint32_t nlo = 16u - dm;
+                if (!ver) {
+                    const uint32_t W = j - a_pos;                               // letters this item may still consume (>= 1)
+                    const uint32_t take = dm < W ? dm : W;
+                    const uint32_t nhi = nlo + take;                            // nibbles of the letters in play
+                    uint64_t mask = nhi >= 16u ? ~0ull : ((1ull << (4u * nhi)) - 1ull);
+                    mask &= ~((1ull << (4u * nlo)) - 1ull);
+                    const uint64_t stop = (mis | flag) & mask;
+                    uint32_t kc, flagged_stop = 0;
+                    const bool hit = stop != 0ull;
+                    if (hit) {
+                        const uint32_t nib = (uint32_t)__builtin_ctzll(stop) >> 2;
+                        kc = nib - nlo;
+                        dmis = ((mis >> (4u * nib)) & 1ull) != 0ull;
+                        flagged_stop = (uint32_t)((flag >> (4u * nib)) & 1ull);
+                        dcool = !dmis;  // stopped by a class flag: the index walk takes over until the interval changes
+                    } else {
+                        kc = take;
+                        dmis = false;
+                    }
+                    j -= kc; depth += (int)kc; dir_r -= kc;
+                    if (kStats) { n_dlet += kc; n_pos += kc; }
+                    if (!hit && j != a_pos) {
+                        if (dir_r == 0u) { dmis = true; st = ST_DEND; }  // the text begins: the next letter cannot match
+                        else st = ST_DIR;                               // the whole group agreed: next group
+                    } else if (kSkip && hit && dmis && skw != 0u && flagged_stop == 0u && j - a_pos >= skw + 1u && dir_r >= skw + 2u &&
+                               j - 1u + kd <= qlen) {  // (j >= k follows from the room on the left: w + 1 = min_len >= k)
+                        pub = 0;       // a disagreeing letter, nothing pending can have ancestors, room on both sides: try to
+                        st = ST_SKV;   // skip the chance matches behind it
+                    } else {
+                        st = ST_DEND;
+                    }
                 } else {
-                    kc = take;
-                    dmis = false;
-                }
-                j -= kc; depth += (int)kc; dir_r -= kc;
-                if (kStats) { n_dlet += kc; n_pos += kc; }
-                if (!hit && j != a_pos) {
-                    if (dir_r == 0u) { dmis = true; st = ST_DEND; }  // the text begins: the next letter cannot match
-                    else st = ST_DIR;                               // the whole group agreed: next group
-                } else {
-                    st = ST_DEND;
+                    const uint32_t v = (uint32_t)pub, need = skw + 1u - v;      // w letters to agree, then one for its class
+                    const uint32_t take = dm < need ? dm : need;
+                    const uint32_t must = v + take <= skw ? take : take - 1u;   // how many of them must agree
+                    const uint32_t nhm = nlo + must;
+                    uint64_t maskm = nhm >= 16u ? ~0ull : ((1ull << (4u * nhm)) - 1ull);
+                    maskm &= ~((1ull << (4u * nlo)) - 1ull);
+                    bool bad = (mis & maskm) != 0ull;
+                    if (must != take) bad = bad || ((flag >> (4u * (nlo + take - 1u))) & 1ull) != 0ull;
+                    if (bad) { dmis = true; st = ST_DEND; }   // the normal route
+                    else {
+                        pub = (int)(v + take);
+                        st = v + take == skw + 1u ? ST_SKQ : ST_SKV;
+                    }
                 }
             } else if (st == ST_DEND) {
                 // rt = {row, parent top, parent bottom, parent depth + 1} of the suffix that starts at dir_r
@@ -1078,6 +1216,8 @@ __global__ void __launch_bounds__(256, SLAMEM_V3_WAVES) k_find_mems_v3(SearchArg
         stat_flush<kStats>(A.stats + SC_DIR_SA, n_dsa); stat_flush<kStats>(A.stats + SC_DIR_GROUPS, n_dgrp);
         stat_flush<kStats>(A.stats + SC_DIR_RECS, n_drec); stat_flush<kStats>(A.stats + SC_DIR_LETTERS, n_dlet);
         stat_flush<kStats>(A.stats + SC_JUMP_LINES, n_jump);
+        stat_flush<kStats>(A.stats + SC_SKIP_GROUPS, n_skv); stat_flush<kStats>(A.stats + SC_SKIP_QLOADS, n_skq);
+        stat_flush<kStats>(A.stats + SC_SKIP_PROBES, n_skp); stat_flush<kStats>(A.stats + SC_SKIP_OK, n_skok);
         if ((threadIdx.x & 63u) == 0u) {
             const unsigned long long t1 = wall_clock64();
             atomicMax(A.stats + SC_T_LAST, t1);
@@ -1226,7 +1366,8 @@ __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__
     for (uint32_t i = 0; i < cnt; i++) {
         if (off + i >= capacity) return;
         RawRow r = inl[g * kInlineMems + i];
-        out[off + i] = slamem_mem{sa[r.row], r.pos, r.len};
+        // bit 31 of the length: `row` already is the text position (a MEM emitted from a direct run)
+        out[off + i] = slamem_mem{(r.len >> 31) ? r.row : sa[r.row], r.pos, r.len & 0x7FFFFFFFu};
     }
 }
 
@@ -1242,7 +1383,8 @@ __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict
     slamem_mem m = raw[i];
     uint64_t pos = item_off[kk.block] + (kk.k & 0x0FFFFFFFu);
     if (pos >= capacity) return;
-    m.ref_pos = sa[m.ref_pos];
+    if (m.length >> 31) m.length &= 0x7FFFFFFFu;  // ref_pos already is the text position
+    else m.ref_pos = sa[m.ref_pos];
     out[pos] = m;
 }
 
@@ -1358,7 +1500,7 @@ inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_alive, off_workids, off_select, select_bytes, off_itemoff, off_rawkey,
-        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, max_items, bytes;
+        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, max_items, bytes;
 };
 
 // max_items bounds the work items of ANY batch with this many records and characters
@@ -1396,6 +1538,8 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     w.off_itempk = off;   off = align_up(off + w.max_items * 8, 256);
     w.pq_bytes = 8 * (4 + strands * (query_bytes / 16 + 2 * num_queries + 2));
     w.off_pq = off;       off = align_up(off + w.pq_bytes, 256);
+    w.off_pq2 = off;      off = align_up(off + w.pq_bytes / 2 + 64, 256);
+    w.off_itemflags = off; off = align_up(off + w.max_items, 256);
     w.bytes = off;
     return w;
 }
@@ -1548,6 +1692,23 @@ int SearchJob::tables(hipStream_t stream) {
         if (env_depth < 0) A.direct_min_depth = -1;
         static const bool env_jump = [] { const char* v = getenv("SLAMEM_KJUMP_USE"); return !(v && atoi(v) == 0); }();
         A.use_jump = env_jump ? 1u : 0u;
+        {   // skipping the chance matches behind a disagreeing letter (K8 states SKV / SKQ / SKP): needs the occurrence
+            // bitmap, min_len >= its k, at most 6 probes per letter, and a class that can vouch for a depth of min_len - 1
+            static const bool env_skip = [] { const char* v = getenv("SLAMEM_SKIP"); return v && atoi(v) != 0; }();  // off unless asked for
+            const uint32_t kd = idx->view.kbits ? idx->view.kbits_k : 0u;
+            A.skip_w = 0;
+            if (env_skip && kd && min_len >= kd && min_len >= 9u && min_len < 0x10000u && A.direct_min_depth >= 0) {
+                const uint32_t s1 = min_len - kd + 1u;
+                const uint32_t nprobes = (kd - 1u + s1 - 1u) / s1 + 1u;  // starts p-(k-1), +s1, ..., p
+                if (nprobes <= 6u && depth_class((int)min_len - 1) >= 1u) {
+                    A.skip_w = min_len - 1u;
+                    A.skip_s1 = s1;
+                    A.pq2 = reinterpret_cast<const uint64_t*>(ws + w.off_pq2);
+                    A.pq2_out = reinterpret_cast<uint64_t*>(ws + w.off_pq2);
+                    A.item_flags = reinterpret_cast<uint8_t*>(ws + w.off_itemflags);
+                }
+            }
+        }
     }
     return SLAMEM_OK;
 }
@@ -1579,6 +1740,7 @@ int SearchJob::launch(hipStream_t stream) {
             A.work_ids = d_ids;
             A.work_count = d_nwork;
         }
+        if (A.item_flags) STEP(hipMemsetAsync(A.item_flags, 0, nitems, stream), "memset");
         {   // K7q: the strands K8 will scan, packed; then (only if some record was cut into slices) all of those slices
             uint64_t pb = (nitems * 8 + 255) / 256;
             hipLaunchKernelGGL(k_pack_queries<8>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, false);
@@ -1596,8 +1758,14 @@ int SearchJob::launch(hipStream_t stream) {
         A.work_cursor = reinterpret_cast<unsigned int*>(d_total + 5);  // a word of the zeroed scalar block
         (void)hipEventRecord(ev[4], stream);
         timed_k8 = true;
-        if (want_stats) hipLaunchKernelGGL(k_find_mems_v3<true>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
-        else hipLaunchKernelGGL(k_find_mems_v3<false>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, A);
+        const dim3 grid8(grid_for(waves * 64));
+        if (A.skip_w) {
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, true>), grid8, dim3(256), 0, stream, A);
+        } else {
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false>), grid8, dim3(256), 0, stream, A);
+        }
         STEP(hipGetLastError(), "k_find_mems_v3");
     } else if (nitems && match_type == 1) {
         A.rows_out = 1;  // K9 of the v3 path places the MAMs and resolves their rows
@@ -1649,6 +1817,8 @@ int SearchJob::finish(hipStream_t stream) {
         o.positions = c[SC_POSITIONS]; o.enum_jobs = c[SC_ENUM_JOBS];
         o.dir_sa_lines = c[SC_DIR_SA]; o.dir_group_loads = c[SC_DIR_GROUPS]; o.dir_rec_lines = c[SC_DIR_RECS];
         o.dir_letters = c[SC_DIR_LETTERS]; o.jump_lines = c[SC_JUMP_LINES];
+        o.skip_group_loads = c[SC_SKIP_GROUPS]; o.skip_probe_lines = c[SC_SKIP_PROBES]; o.skips = c[SC_SKIP_OK];
+        o.skip_attempts = c[SC_SKIP_QLOADS];
         // 100 MHz clock -> microseconds
         last_search_clock()[0] = (c[SC_T_DRAIN] - c[SC_T_FIRST]) / 100.0;
         last_search_clock()[1] = (c[SC_T_LAST] - c[SC_T_DRAIN]) / 100.0;

@@ -340,3 +340,22 @@ def test_mam_long_record_matches_oracle_and_overflows_inline_slots(eng):
         assert np.array_equal(gm[f], om[f]), f
     assert dt < 20.0
     g.close()
+
+
+def test_skip_variant_is_exact(eng):
+    """The K8 instantiation with the skipping states (SLAMEM_SKIP=1; measured and not the default) must give
+    the same MEMs in the same order: tests/skip_variant_check.py in a child process (the switch is read once per process),
+    four read sets against the oracle and the full-size digest of the REAL reference; the skips must actually happen."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SLAMEM_SKIP="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip_variant_check.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-3000:]
+    out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert out["config3_digest_equal"]
+    assert all(out[c]["equal_in_order"] for c in ("random", "repeats", "dense_subs", "l30"))
+    assert out["random"]["skips"] > 1000 and out["l30"]["skips"] > 100
