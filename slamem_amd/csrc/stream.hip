@@ -26,6 +26,8 @@ namespace {
 
 enum SlotState { FREE = 0, QUEUED = 1, UPLOADED = 2, COMPUTED = 3, DONE = 4, RETURNED = 5 };
 constexpr int kMaxSlots = 8;
+constexpr int kMaxSearch = 4;
+constexpr int kMaxThreads = kMaxSearch + 2;
 
 struct Slot {
     int state = FREE;
@@ -64,8 +66,10 @@ struct slamem_stream {
     uint64_t max_chars = 0;
     uint32_t max_q = 0;
     Slot slot[kMaxSlots];
-    std::thread th[4];            // upload, search (even batches), search (odd batches), download
-    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+    // thread 0 uploads, threads 1..nsearch search (batch b on thread 1 + b mod nsearch), the last one downloads
+    std::thread th[kMaxThreads];
+    hipStream_t st[kMaxThreads] = {};
+    int nsearch = 2, nthreads = 4;
     std::mutex mu;
     std::condition_variable cv;
     uint64_t submitted = 0, returned = 0;  // batches handed in / handed back
@@ -147,18 +151,20 @@ int stage_download(slamem_stream* s, Slot& sl) {
         SLAMEM_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_mems), sl.cap * sizeof(slamem_mem) + 16, hipHostMallocDefault));
         sl.h_cap = sl.cap;
     }
-    if (sl.total) SLAMEM_HIP(hipMemcpyAsync(sl.h_mems, sl.d_mems, sl.total * sizeof(slamem_mem), hipMemcpyDeviceToHost, s->st[3]));
-    SLAMEM_HIP(hipMemcpyAsync(sl.h_boff, sl.d_boff, (nb + 1) * 8, hipMemcpyDeviceToHost, s->st[3]));
-    SLAMEM_HIP(hipStreamSynchronize(s->st[3]));
+    hipStream_t st = s->st[s->nthreads - 1];
+    if (sl.total) SLAMEM_HIP(hipMemcpyAsync(sl.h_mems, sl.d_mems, sl.total * sizeof(slamem_mem), hipMemcpyDeviceToHost, st));
+    SLAMEM_HIP(hipMemcpyAsync(sl.h_boff, sl.d_boff, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
+    SLAMEM_HIP(hipStreamSynchronize(st));
     return SLAMEM_OK;
 }
 
 // thread 0 uploads, threads 1 and 2 search the even / odd batches, thread 3 downloads; each takes its batches in
 // submission order
 void worker(slamem_stream* s, int t) {
-    const int want = t == 0 ? QUEUED : t == 3 ? COMPUTED : UPLOADED;
-    const int done = t == 0 ? UPLOADED : t == 3 ? DONE : COMPUTED;
-    const uint64_t first = t == 2 ? 1 : 0, step = (t == 1 || t == 2) ? 2 : 1;
+    const bool up = t == 0, down = t == s->nthreads - 1;
+    const int want = up ? QUEUED : down ? COMPUTED : UPLOADED;
+    const int done = up ? UPLOADED : down ? DONE : COMPUTED;
+    const uint64_t first = (up || down) ? 0 : (uint64_t)(t - 1), step = (up || down) ? 1 : (uint64_t)s->nsearch;
     (void)hipSetDevice(s->idx->device);
     for (uint64_t seq = first;; seq += step) {
         Slot& sl = s->slot[seq % (uint64_t)s->nslots];
@@ -170,13 +176,13 @@ void worker(slamem_stream* s, int t) {
         int rc = sl.rc;  // a batch that failed in an earlier stage passes through untouched
         const auto t_begin = std::chrono::steady_clock::now();
         if (rc == SLAMEM_OK) {
-            rc = t == 0 ? stage_upload(s, sl) : t == 3 ? stage_download(s, sl) : stage_search(s, sl, s->st[t]);
+            rc = up ? stage_upload(s, sl) : down ? stage_download(s, sl) : stage_search(s, sl, s->st[t]);
             if (rc != SLAMEM_OK) snprintf(sl.err, sizeof(sl.err), "%s", slamem_last_error_message());  // the text is per thread
         }
         if (s->trace) {  // SLAMEM_STREAM_TRACE=1: when every stage worked on every batch (ms since the stream was created)
             const auto t_end = std::chrono::steady_clock::now();
             fprintf(stderr, "[stream] batch %3llu %-8s %9.3f .. %9.3f ms\n", (unsigned long long)seq,
-                    t == 0 ? "upload" : t == 3 ? "download" : "search",
+                    up ? "upload" : down ? "download" : "search",
                     std::chrono::duration<double, std::milli>(t_begin - s->t0).count(),
                     std::chrono::duration<double, std::milli>(t_end - s->t0).count());
         }
@@ -229,11 +235,11 @@ int slamem_stream_destroy(slamem_stream* s) {
         s->stop = true;
     }
     s->cv.notify_all();
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < s->nthreads; k++)
         if (s->th[k].joinable()) s->th[k].join();
     (void)hipSetDevice(s->idx->device);
     for (int k = 0; k < s->nslots; k++) free_slot(s->slot[k]);
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < kMaxThreads; k++)
         if (s->st[k]) (void)hipStreamDestroy(s->st[k]);
     delete s;
     return SLAMEM_OK;
@@ -258,18 +264,23 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
     s->max_chars = max_batch_chars;
     s->max_q = max_batch_queries;
     int rc = SLAMEM_OK;
-    for (int k = 0; k < 4; k++) {
+    {   // SLAMEM_STREAM_SEARCH=1..4 search threads (default 2)
+        const char* v = getenv("SLAMEM_STREAM_SEARCH");
+        if (v && atoi(v) >= 1 && atoi(v) <= kMaxSearch) s->nsearch = atoi(v);
+        s->nthreads = s->nsearch + 2;
+    }
+    for (int k = 0; k < s->nthreads; k++) {
         hipError_t e = hipStreamCreateWithFlags(&s->st[k], hipStreamNonBlocking);
         if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
     }
     if (rc != SLAMEM_OK) {
         for (int k = 0; k < slots; k++) free_slot(s->slot[k]);
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < kMaxThreads; k++)
             if (s->st[k]) (void)hipStreamDestroy(s->st[k]);
         delete s;
         return rc;
     }
-    for (int k = 0; k < 4; k++) s->th[k] = std::thread(worker, s, k);
+    for (int k = 0; k < s->nthreads; k++) s->th[k] = std::thread(worker, s, k);
     *out = s;
     return SLAMEM_OK;
 }
