@@ -271,7 +271,8 @@ void slamem_host_free(void *p);
  * run, the copy engines upload batch b+1 and download the MEMs of batch b-1, so the sustained rate is the kernels' rate,
  * not kernels + PCIe.  Four or five slots keep all three stages busy beside the result the caller is working on.
  *
- *   slamem_stream_create   max_batch_chars / max_batch_queries bound every batch; match_type 0 = MEM, 1 = MAM (-mam)
+ *   slamem_stream_create   max_batch_chars / max_batch_queries: what to reserve per slot (a larger batch makes its slot
+ *                          grow); match_type 0 = MEM, 1 = MAM (-mam)
  *   slamem_stream_submit   record i of the batch is queries[offsets[i] .. offsets[i+1]) -- offsets[0] need not be 0, so
  *                          a front end passes its whole character buffer and a window of its offsets array.  Returns at
  *                          once; the characters and offsets must stay unchanged until the batch has been collected.

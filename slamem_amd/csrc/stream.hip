@@ -38,10 +38,12 @@ struct Slot {
     slamem_mem* d_mems = nullptr;
     void* d_ws = nullptr;
     uint64_t cap = 0, ws_bytes = 0;
+    uint64_t cap_chars = 0;   // room of d_q (characters), of d_off / d_boff / h_boff (records): grown when a batch needs more
+    uint32_t cap_q = 0;
     // pinned host
     uint64_t* h_boff = nullptr;
     slamem_mem* h_mems = nullptr;
-    uint64_t h_cap = 0;
+    uint64_t h_cap = 0, h_boff_cap = 0;
     // the batch
     uint64_t seq = 0;
     const char* chars = nullptr;
@@ -88,7 +90,7 @@ int grow_outputs(slamem_stream* s, Slot& sl, uint64_t need_cap) {  // search sta
     if (sl.d_ws) (void)hipFree(sl.d_ws);
     sl.d_mems = nullptr; sl.d_ws = nullptr;
     sl.cap = need_cap;
-    sl.ws_bytes = find_mems_workspace_bytes(s->max_q, s->both, s->max_chars, sl.cap);
+    sl.ws_bytes = find_mems_workspace_bytes(sl.cap_q, s->both, sl.cap_chars, sl.cap);
     SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_mems), sl.cap * sizeof(slamem_mem) + 16));
     SLAMEM_HIP(hipMalloc(&sl.d_ws, sl.ws_bytes));
     return SLAMEM_OK;
@@ -105,11 +107,22 @@ inline const char* device_queries(const Slot& sl) {
 }
 int stage_upload(slamem_stream* s, Slot& sl) {
     const uint64_t base = sl.offs[0], qbytes = sl.offs[sl.nq] - base;
-    if (!sl.d_q) {
-        const uint64_t nb = (uint64_t)s->max_q * (s->both ? 2 : 1);
-        SLAMEM_HIP(hipMalloc(&sl.d_q, s->max_chars + 2 * kFront + 32));
-        SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_off), ((uint64_t)s->max_q + 1) * 8));
+    if (!sl.d_q || qbytes > sl.cap_chars || sl.nq > sl.cap_q) {
+        // first batch of this slot, or a batch larger than the reservation (max_batch_* of slamem_stream_create are a hint)
+        const uint64_t nchars = qbytes > s->max_chars ? qbytes : s->max_chars;
+        const uint32_t nrec = sl.nq > s->max_q ? sl.nq : s->max_q;
+        const uint64_t nb = (uint64_t)nrec * (s->both ? 2 : 1);
+        if (sl.d_q) (void)hipFree(sl.d_q);
+        if (sl.d_off) (void)hipFree(sl.d_off);
+        if (sl.d_boff) (void)hipFree(sl.d_boff);
+        if (sl.d_mems) (void)hipFree(sl.d_mems);
+        if (sl.d_ws) (void)hipFree(sl.d_ws);
+        sl.d_q = nullptr; sl.d_off = nullptr; sl.d_boff = nullptr; sl.d_mems = nullptr; sl.d_ws = nullptr;  // (the search stage sizes its own)
+        SLAMEM_HIP(hipMalloc(&sl.d_q, nchars + 2 * kFront + 32));
+        SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_off), ((uint64_t)nrec + 1) * 8));
         SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_boff), (nb + 1) * 8));
+        sl.cap_chars = nchars;
+        sl.cap_q = nrec;
     }
     if (qbytes)
         SLAMEM_HIP(hipMemcpyAsync(static_cast<char*>(sl.d_q) + kFront + (base & 15u), sl.chars + base, qbytes, hipMemcpyHostToDevice, s->st[0]));
@@ -125,8 +138,8 @@ int stage_search(slamem_stream* s, Slot& sl, hipStream_t st) {
     const uint64_t qbytes = sl.offs[sl.nq] - sl.offs[0];
     int rc = SLAMEM_OK;
     if (!sl.d_ws) {  // first guess of the room for MEMs: grown when a batch needs more (SLAMEM_ERR_CAPACITY tells how much)
-        const uint64_t nb = (uint64_t)s->max_q * (s->both ? 2 : 1);
-        rc = grow_outputs(s, sl, s->max_chars / 32 + nb + 1024);
+        const uint64_t nb = (uint64_t)sl.cap_q * (s->both ? 2 : 1);
+        rc = grow_outputs(s, sl, sl.cap_chars / 32 + nb + 1024);
         if (rc != SLAMEM_OK) return rc;
     }
     (void)slamem_reset_timings();
@@ -144,7 +157,13 @@ int stage_search(slamem_stream* s, Slot& sl, hipStream_t st) {
 // stage 2: MEMs and block offsets to pinned host memory
 int stage_download(slamem_stream* s, Slot& sl) {
     const uint64_t nb = (uint64_t)sl.nq * (s->both ? 2 : 1);
-    if (!sl.h_boff) SLAMEM_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_boff), ((uint64_t)s->max_q * (s->both ? 2 : 1) + 1) * 8, hipHostMallocDefault));
+    if (!sl.h_boff || sl.h_boff_cap < nb + 1) {
+        if (sl.h_boff) (void)hipHostFree(sl.h_boff);
+        sl.h_boff = nullptr;
+        const uint64_t want = (uint64_t)sl.cap_q * (s->both ? 2 : 1) + 1;
+        sl.h_boff_cap = want > nb + 1 ? want : nb + 1;
+        SLAMEM_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_boff), sl.h_boff_cap * 8, hipHostMallocDefault));
+    }
     if (sl.h_cap < sl.cap || !sl.h_mems) {
         if (sl.h_mems) (void)hipHostFree(sl.h_mems);
         sl.h_mems = nullptr;
@@ -287,11 +306,6 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
 
 int slamem_stream_submit(slamem_stream* s, const char* queries, const uint64_t* offsets, uint32_t num_queries, uint32_t min_len) {
     if (!s || !offsets || (num_queries && !queries)) { set_error("slamem_stream_submit: null argument"); return SLAMEM_ERR_ARG; }
-    if (num_queries > s->max_q || offsets[num_queries] - offsets[0] > s->max_chars) {
-        set_error("slamem_stream_submit: batch of %u records / %llu characters exceeds the stream's limits (%u / %llu)", num_queries,
-                  (unsigned long long)(offsets[num_queries] - offsets[0]), s->max_q, (unsigned long long)s->max_chars);
-        return SLAMEM_ERR_ARG;
-    }
     if (min_len < 1) { set_error("slamem_stream_submit: minimum MEM length must be >= 1"); return SLAMEM_ERR_ARG; }
     std::unique_lock<std::mutex> lk(s->mu);
     Slot& sl = s->slot[s->submitted % (uint64_t)s->nslots];

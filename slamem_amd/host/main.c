@@ -34,28 +34,109 @@ static void join_warmup(void) {
     if (g_warm_started) { g_warm_started = 0; pthread_join(g_warm_tid, NULL); }
 }
 
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* Large query files are parsed in pieces by their own thread while the main thread already searches the first pieces
+ * (slh_pieces_*): the FASTA parse (0.2 s for the reference-sized run) no longer stands in front of the search. */
+typedef struct {
+    char **argv;
+    const int *file_args;
+    int first_file, num_files, acgt_only, numbering;
+    uint32_t min_len;
+    long log_limit, piece_bytes;
+    slh_seqset *sets;  /* room for every piece */
+    int cap;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int ready, done, total_queries;
+    double seconds;
+} loader_t;
+
+static void *loader_run(void *arg) {
+    loader_t *ld = (loader_t *)arg;
+    double t0 = now_s();
+    int f;
+    for (f = ld->first_file; f < ld->num_files; f++) {
+        slh_pieces *p = slh_pieces_open(ld->argv[ld->file_args[f]], ld->acgt_only, ld->min_len, ld->numbering, ld->log_limit,
+                                        ld->piece_bytes, stdout);
+        if (!p) continue;
+        for (;;) {
+            slh_seqset s;
+            int n = slh_pieces_next(p, &s);
+            if (n <= 0) break;
+            pthread_mutex_lock(&ld->mu);
+            if (ld->ready < ld->cap) {
+                ld->sets[ld->ready++] = s;
+                ld->total_queries += n;
+                ld->numbering += n;
+            }
+            pthread_cond_broadcast(&ld->cv);
+            pthread_mutex_unlock(&ld->mu);
+        }
+        slh_pieces_close(p);
+    }
+    pthread_mutex_lock(&ld->mu);
+    ld->done = 1;
+    ld->seconds = now_s() - t0;
+    pthread_cond_broadcast(&ld->cv);
+    pthread_mutex_unlock(&ld->mu);
+    return NULL;
+}
+
+/* While the loader thread still parses query files (and prints its "# NN [name]" lines), the main thread's lines are held
+ * back in memory; release_stdout joins the loader, prints the reference's "successfully loaded" line and then the held
+ * text, so that stdout reads as if everything had been loaded first (slamem.c:635-651 before :37-218).  Every exit path
+ * calls it first. */
+static loader_t g_ld;
+static pthread_t g_ld_tid;
+static int g_ld_started = 0;
+static FILE *g_mo = NULL; /* the memory stream, NULL: print directly */
+static char *g_mo_buf = NULL;
+static size_t g_mo_len = 0;
+static int g_num_refs = 0;
+#define say(...) fprintf(g_mo ? g_mo : stdout, __VA_ARGS__)
+static void release_stdout(void) {
+    if (g_ld_started) {
+        g_ld_started = 0;
+        pthread_join(g_ld_tid, NULL);
+        if (g_ld.ready > 0)
+            printf("> %d reference%s and %d quer%s successfully loaded\n", g_num_refs, g_num_refs == 1 ? "" : "s", g_ld.total_queries,
+                   g_ld.total_queries == 1 ? "y" : "ies");
+    }
+    if (g_mo) {
+        FILE *m = g_mo;
+        g_mo = NULL;
+        fclose(m);
+        if (g_mo_buf && g_mo_len) fwrite(g_mo_buf, 1, g_mo_len, stdout);
+        free(g_mo_buf);
+        g_mo_buf = NULL;
+    }
+}
+
+
 static void exit_message(const char *msg) { /* tools.c:21-25 */
+    release_stdout();
     printf("> ERROR: %s\n", msg);
     join_warmup();
     exit(-1);
 }
 
 static void gpu_fail(const char *what, int rc) {
+    release_stdout();
     printf("\n> ERROR: %s failed: %s (%s)\n", what, slamem_strerror(rc), slamem_last_error_message());
     join_warmup();
     exit(-1);
 }
 
 static void gpu_fail_msg(const char *what, int rc, const char *detail) { /* the detail was captured on another thread */
+    release_stdout();
     printf("\n> ERROR: %s failed: %s (%s)\n", what, slamem_strerror(rc), detail);
     join_warmup();
     exit(-1);
-}
-
-static double now_s(void) {
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
 /* formatting of a range of strand blocks of one batch, one range per thread */
@@ -255,9 +336,10 @@ static void usage(const char *prog) { /* slamem.c:533-553 */
 int main(int argc, char **argv) {
     slh_options o;
     slh_seqset ref, *qsets;
-    int i, f, num_qsets = 0, total_queries = 0, device = 0, numbering = 1;
+    int i, f, total_queries = 0, device = 0, numbering = 1;
     long log_limit = 100;
     uint64_t batch_bytes = 256ull << 20; /* query characters per batch and GPU */
+    long piece_bytes = 128L << 20;       /* bytes of a query file per piece of the loader thread */
     const char *env;
     char *out_name;
     FILE *out;
@@ -295,32 +377,72 @@ int main(int argc, char **argv) {
         warm_device = device;
         g_warm_started = pthread_create(&g_warm_tid, NULL, warmup_run, &warm_device) == 0;
     }
-    double t_start = now_s(), t_load = 0, t_build = 0, t_gpu = 0, t_format = 0, t_write = 0;
+    double t_start = now_s(), t_load = 0, t_build = 0, t_gpu = 0, t_format = 0, t_write = 0, t_wait_load = 0;
     int timing = getenv("SLAMEM_TIMING") != NULL;
-    /* load everything (slamem.c:635-651) */
+    /* load everything (slamem.c:635-651).  Query files above SLAMEM_OVERLAP_MB (default 256) in total are parsed in pieces by
+       a loader thread while the search already runs; stdout keeps the reference's order: what the main thread prints meanwhile
+       is held back until the "successfully loaded" line can be printed */
     memset(&ref, 0, sizeof(ref));
     memset(&bj, 0, sizeof(bj));
-    qsets = (slh_seqset *)calloc((size_t)o.num_files, sizeof(slh_seqset));
-    if (!qsets) exit_message("Out of memory");
+    loader_t *const ld = &g_ld;
+    int overlap = 0, ref_file = -1;
     {
-        int have_ref = 0;
-        for (f = 0; f < o.num_files; f++) {
-            const char *path = argv[o.file_args[f]];
-            if (!have_ref) {
-                int n = slh_load_file(path, 1, o.no_ns, (uint32_t)o.min_seq_len, o.ref_name, numbering, log_limit, &ref, stdout);
-                if (n == 0) exit_message("No valid sequences found in reference file");
-                have_ref = 1;
-                numbering += n;
-                o.file_args[0] = o.file_args[f]; /* remember which argument was the reference */
-                bj.text = ref.chars;
-                bj.n = (uint32_t)ref.total;
-                bj.device = device;
-                build_async = pthread_create(&build_tid, NULL, build_run, &bj) == 0;
-            } else {
-                int n = slh_load_file(path, 0, o.no_ns, (uint32_t)o.min_seq_len, NULL, numbering, log_limit, &qsets[num_qsets], stdout);
-                if (n != 0) { numbering += n; total_queries += n; num_qsets++; }
+        uint64_t qbytes_total = 0, pieces_cap = 0;
+        long thr_mb = 256;
+        if ((env = getenv("SLAMEM_OVERLAP_MB")) != NULL) thr_mb = atol(env);
+        if ((env = getenv("SLAMEM_PIECE_MB")) != NULL && atol(env) > 0) piece_bytes = atol(env) << 20;
+        for (f = 1; f < o.num_files; f++) {
+            FILE *qf = fopen(argv[o.file_args[f]], "rb");
+            if (qf) {
+                long sz;
+                fseek(qf, 0L, SEEK_END);
+                sz = ftell(qf);
+                fclose(qf);
+                if (sz > 0) { qbytes_total += (uint64_t)sz; pieces_cap += (uint64_t)sz / (uint64_t)piece_bytes + 2; }
             }
         }
+        overlap = thr_mb >= 0 && qbytes_total > ((uint64_t)thr_mb << 20);
+        memset(ld, 0, sizeof(*ld));
+        ld->cap = (int)(overlap ? pieces_cap + (uint64_t)o.num_files : (uint64_t)o.num_files);
+        qsets = (slh_seqset *)calloc((size_t)ld->cap + 1, sizeof(slh_seqset));
+        if (!qsets) exit_message("Out of memory");
+        ld->sets = qsets;
+        pthread_mutex_init(&ld->mu, NULL);
+        pthread_cond_init(&ld->cv, NULL);
+    }
+    for (f = 0; f < o.num_files; f++) {
+        const char *path = argv[o.file_args[f]];
+        if (ref_file < 0) {
+            int n = slh_load_file(path, 1, o.no_ns, (uint32_t)o.min_seq_len, o.ref_name, numbering, log_limit, &ref, stdout);
+            if (n == 0) exit_message("No valid sequences found in reference file");
+            ref_file = f;
+            numbering += n;
+            g_num_refs = ref.num;
+            o.file_args[0] = o.file_args[f]; /* remember which argument was the reference */
+            bj.text = ref.chars;
+            bj.n = (uint32_t)ref.total;
+            bj.device = device;
+            build_async = pthread_create(&build_tid, NULL, build_run, &bj) == 0;
+            if (overlap) break;
+        } else {
+            int n = slh_load_file(path, 0, o.no_ns, (uint32_t)o.min_seq_len, NULL, numbering, log_limit, &qsets[ld->ready], stdout);
+            if (n != 0) { numbering += n; ld->total_queries += n; ld->ready++; }
+        }
+    }
+    if (overlap) {
+        ld->argv = argv; ld->file_args = o.file_args; ld->first_file = ref_file + 1; ld->num_files = o.num_files;
+        ld->acgt_only = o.no_ns; ld->min_len = (uint32_t)o.min_seq_len; ld->numbering = numbering; ld->log_limit = log_limit;
+        ld->piece_bytes = piece_bytes;
+        fflush(stdout);
+        g_mo = open_memstream(&g_mo_buf, &g_mo_len);
+        g_ld_started = g_mo != NULL && pthread_create(&g_ld_tid, NULL, loader_run, ld) == 0;
+        if (!g_ld_started) { /* no thread: load here, as for small inputs */
+            if (g_mo) release_stdout();
+            overlap = 0;
+            loader_run(ld);
+        }
+    } else {
+        ld->done = 1;
     }
     t_load = now_s() - t_start;
     double t_join0 = now_s();
@@ -328,48 +450,52 @@ int main(int argc, char **argv) {
     else build_run(&bj);
     join_warmup();
     double t_join = now_s() - t_join0, t_streams = 0;
-    if (num_qsets == 0) exit_message("No query files provided"); /* slamem.c:648 */
-    printf("> %d reference%s and %d quer%s successfully loaded\n", ref.num, ref.num == 1 ? "" : "s", total_queries,
-           total_queries == 1 ? "y" : "ies");
+    if (!overlap) {
+        if (ld->ready == 0) exit_message("No query files provided"); /* slamem.c:648 */
+        printf("> %d reference%s and %d quer%s successfully loaded\n", ref.num, ref.num == 1 ? "" : "s", ld->total_queries,
+               ld->total_queries == 1 ? "y" : "ies");
+    }
     if (o.min_mem_len < 1) exit_message("Minimum match length must be at least 1");
 
     if (o.out_arg == -1) out_name = slh_append_to_basename(argv[o.file_args[0]], "-mems.txt");
     else out_name = argv[o.out_arg];
 
     /* GetMatches (slamem.c:37-218) */
-    printf("> Using options: minimum M%cM length = %d ; strand = %s\n", MATCH_TYPE_CHAR[o.match_type], o.min_mem_len,
+    say("> Using options: minimum M%cM length = %d ; strand = %s\n", MATCH_TYPE_CHAR[o.match_type], o.min_mem_len,
            o.both_strands == 0 ? "forward only" : "forward + reverse");
     out = fopen(out_name, "w");
     if (!out) {
+        release_stdout();
         printf("\n> ERROR: Cannot create output file <%s>\n", out_name);
+        join_warmup();
         exit(-1);
     }
-    printf("> Building index for reference sequence");
-    if (ref.num == 1) printf(" \"%s\"", ref.recs[0].name);
-    else printf("s");
-    printf(" (%u Mbp) ...\n", (unsigned)(ref.total / 1000000U));
-    fflush(stdout);
+    say("> Building index for reference sequence");
+    if (ref.num == 1) say(" \"%s\"", ref.recs[0].name);
+    else say("s");
+    say(" (%u Mbp) ...\n", (unsigned)(ref.total / 1000000U));
+    if (!g_mo) fflush(stdout);
     t0 = now_s();
     idx = bj.idx;
     if (bj.rc != SLAMEM_OK) gpu_fail_msg("index construction on the GPU", bj.rc, bj.err);
     {
         slamem_index_info info = bj.info;
         slamem_timings tm = bj.tm;
-        printf("> Suffix sort + BWT + LCP + parent links on GPU %d ... OK (%.3f s, overlapped with the loading of the queries; device %.1f ms: sort %.1f, BWT %.1f, LCP %.1f, links %.1f; %u doubling rounds)\n",
+        say("> Suffix sort + BWT + LCP + parent links on GPU %d ... OK (%.3f s, overlapped with the loading of the queries; device %.1f ms: sort %.1f, BWT %.1f, LCP %.1f, links %.1f; %u doubling rounds)\n",
                device, bj.seconds, tm.build_total_ms, tm.build_sort_ms, tm.build_bwt_ms, tm.build_lcp_ms, tm.build_links_ms,
                info.sort_rounds);
-        printf(":: Index size = %.1f MB in HBM (FM blocks + 16 B per row)\n", (double)info.arena_bytes / 1e6);
+        say(":: Index size = %.1f MB in HBM (FM blocks + 16 B per row)\n", (double)info.arena_bytes / 1e6);
         {   /* the statistics lines of BuildSampledLCPArray (lcparray.c:709-711, 999-1000), from the per-row records */
             slamem_sslcp_stats st = bj.st;
             unsigned bwt_len = info.bwt_size;
             if (bj.rc_stats != SLAMEM_OK) gpu_fail_msg("LCP sampling statistics", bj.rc_stats, bj.err);
-            printf(":: %.2lf%% samples (%u of %u)\n", ((double)st.num_samples / (double)bwt_len) * 100.0, (unsigned)st.num_samples, bwt_len);
-            printf(":: %.2lf%% oversized samples (%d of %u)\n", ((double)st.num_oversized_lcp / (double)st.num_samples) * 100.0,
+            say(":: %.2lf%% samples (%u of %u)\n", ((double)st.num_samples / (double)bwt_len) * 100.0, (unsigned)st.num_samples, bwt_len);
+            say(":: %.2lf%% oversized samples (%d of %u)\n", ((double)st.num_oversized_lcp / (double)st.num_samples) * 100.0,
                    (int)st.num_oversized_lcp, (unsigned)st.num_samples);
-            printf(":: Average LCP value = %d (max=%lld)\n", (int)(st.sum_lcp / (long long)bwt_len), (long long)st.max_lcp);
-            printf(":: %.2lf%% oversized values (%d of %u)\n", ((double)st.num_oversized_links / (double)st.num_samples) * 100.0,
+            say(":: Average LCP value = %d (max=%lld)\n", (int)(st.sum_lcp / (long long)bwt_len), (long long)st.max_lcp);
+            say(":: %.2lf%% oversized values (%d of %u)\n", ((double)st.num_oversized_links / (double)st.num_samples) * 100.0,
                    (int)st.num_oversized_links, (unsigned)st.num_samples);
-            printf(":: Average SV distance = %.2lf (max=%lld)\n", (double)st.sum_link_distance / (double)st.num_samples,
+            say(":: Average SV distance = %.2lf (max=%lld)\n", (double)st.sum_link_distance / (double)st.num_samples,
                    (long long)st.max_link_distance);
         }
     }
@@ -394,6 +520,7 @@ int main(int argc, char **argv) {
             void *h = dlopen("libslamem_rccl.so", RTLD_NOW | RTLD_GLOBAL);
             replicate_fn fn = h ? (replicate_fn)dlsym(h, "slamem_index_replicate") : NULL;
             if (!fn) {
+                release_stdout();
                 printf("\n> ERROR: cannot load libslamem_rccl.so (%s)\n", dlerror());
                 join_warmup();
                 exit(-1);
@@ -402,13 +529,13 @@ int main(int argc, char **argv) {
         }
         if (rc != SLAMEM_OK) gpu_fail("index replication over RCCL", rc);
         if (ngpu == 1) { slamem_index_free(idx); idx = gpus[0]; } /* self-test: search on the broadcast copy */
-        printf("> Index replicated to %d GPU%s by RCCL broadcast ... OK (%.3f s)\n", ngpu, ngpu == 1 ? " (self-test copy)" : "s", now_s() - tr);
+        say("> Index replicated to %d GPU%s by RCCL broadcast ... OK (%.3f s)\n", ngpu, ngpu == 1 ? " (self-test copy)" : "s", now_s() - tr);
     }
     t_build = bj.seconds + (now_s() - t0);
     free(ref.chars); /* the reference frees the text here too (slamem.c:75-77) */
     ref.chars = NULL;
-    printf("> Matching query sequences against index ...\n");
-    fflush(stdout);
+    say("> Matching query sequences against index ...\n");
+    if (!g_mo) fflush(stdout);
 
     {
         int strands = o.both_strands ? 2 : 1;
@@ -423,26 +550,34 @@ int main(int argc, char **argv) {
         uint32_t max_recs = 1;
         int inflight[16], g;
         const int slots = 4;
-        for (f = 0; f < num_qsets; f++) {
-            slh_seqset *q = &qsets[f];
-            int first = 0;
-            while (first < q->num) {
-                int last = first;
-                uint64_t base = q->offsets[first];
-                /* the first batches are short, so that the search starts early */
-                uint64_t limit = nranges < (size_t)ngpu ? batch_bytes / 4 : nranges < 2 * (size_t)ngpu ? batch_bytes / 2 : batch_bytes;
-                while (last < q->num && (last == first || q->offsets[last + 1] - base <= limit)) last++;
-                if (nranges == cap_ranges) {
-                    cap_ranges = cap_ranges ? cap_ranges * 2 : 16;
-                    ranges = (batch_range *)realloc(ranges, cap_ranges * sizeof(batch_range));
-                    if (!ranges) exit_message("Out of memory");
-                }
-                ranges[nranges].f = f; ranges[nranges].first = first; ranges[nranges].last = last;
-                if (q->offsets[last] - base > max_chars) max_chars = q->offsets[last] - base;
-                if ((uint32_t)(last - first) > max_recs) max_recs = (uint32_t)(last - first);
-                nranges++;
-                first = last;
-            }
+        int sets_seen = 0, sets_ready = ld->ready; /* !overlap: everything is there */
+#define ADD_RANGES_OF_NEW_SETS()                                                                                              \
+        for (; sets_seen < sets_ready; sets_seen++) {                                                                          \
+            slh_seqset *q = &qsets[sets_seen];                                                                                 \
+            int first = 0;                                                                                                     \
+            while (first < q->num) {                                                                                           \
+                int last = first;                                                                                              \
+                uint64_t base = q->offsets[first];                                                                             \
+                /* the first batches are short, so that the search starts early */                                             \
+                uint64_t limit = nranges < (size_t)ngpu ? batch_bytes / 4 : nranges < 2 * (size_t)ngpu ? batch_bytes / 2 : batch_bytes; \
+                while (last < q->num && (last == first || q->offsets[last + 1] - base <= limit)) last++;                       \
+                if (nranges == cap_ranges) {                                                                                   \
+                    cap_ranges = cap_ranges ? cap_ranges * 2 : 16;                                                             \
+                    ranges = (batch_range *)realloc(ranges, cap_ranges * sizeof(batch_range));                                 \
+                    if (!ranges) pipeline_fail("Out of memory");                                                               \
+                }                                                                                                              \
+                ranges[nranges].f = sets_seen; ranges[nranges].first = first; ranges[nranges].last = last;                     \
+                if (q->offsets[last] - base > max_chars) max_chars = q->offsets[last] - base;                                  \
+                if ((uint32_t)(last - first) > max_recs) max_recs = (uint32_t)(last - first);                                  \
+                nranges++;                                                                                                     \
+                first = last;                                                                                                  \
+            }                                                                                                                  \
+        }
+        ADD_RANGES_OF_NEW_SETS();
+        if (overlap) { /* the batches are not known yet: reserve for a piece's worth, the slots grow on demand */
+            uint64_t guess = batch_bytes < (uint64_t)piece_bytes ? batch_bytes : (uint64_t)piece_bytes;
+            if (max_chars < guess) max_chars = guess;
+            if (max_recs < max_chars / 64) max_recs = (uint32_t)(max_chars / 64);
         }
         memset(&g_writer, 0, sizeof(g_writer));
         g_writer.out = out;
@@ -450,14 +585,32 @@ int main(int argc, char **argv) {
         pthread_cond_init(&g_writer.cv, NULL);
         g_writer.started = pthread_create(&g_writer.tid, NULL, writer_run, &g_writer) == 0;
         double ts0 = now_s();
-        for (g = 0; g < ngpu && nranges; g++) { /* batch b is searched on GPU b mod ngpu: no data-path collective */
+        for (g = 0; g < ngpu && (nranges || overlap); g++) { /* batch b is searched on GPU b mod ngpu: no data-path collective */
             rc = slamem_stream_create(gpus[g], slots, max_chars, max_recs, o.both_strands, o.match_type == 1 ? 1 : 0, &g_streams[g]);
             if (rc != SLAMEM_OK) { shutdown_pipeline(); gpu_fail("setting up the search pipeline", rc); }
             g_nstreams = g + 1;
             inflight[g] = 0;
         }
         t_streams = now_s() - ts0;
-        for (bi = 0; bi < nranges; bi++) {
+        for (bi = 0;; bi++) {
+            if (overlap) { /* take in the pieces parsed meanwhile; wait for one only when there is nothing else to do */
+                double tw = now_s();
+                pthread_mutex_lock(&ld->mu);
+                while (bi >= nranges && sets_seen == ld->ready && !ld->done) pthread_cond_wait(&ld->cv, &ld->mu);
+                sets_ready = ld->ready;
+                pthread_mutex_unlock(&ld->mu);
+                ADD_RANGES_OF_NEW_SETS();
+                t_wait_load += now_s() - tw;
+                if (bi >= nranges) { /* nothing new: either the loader is done or a piece without batches came in */
+                    int finished;
+                    pthread_mutex_lock(&ld->mu);
+                    finished = ld->done && sets_seen == ld->ready;
+                    pthread_mutex_unlock(&ld->mu);
+                    if (finished) break;
+                    bi--;
+                    continue;
+                }
+            } else if (bi >= nranges) break;
             slh_seqset *q = &qsets[ranges[bi].f];
             const int first = ranges[bi].first, last = ranges[bi].last;
             const slamem_mem *mems = NULL;
@@ -478,6 +631,7 @@ int main(int argc, char **argv) {
                 char detail[512];
                 snprintf(detail, sizeof(detail), "%s", slamem_last_error_message());
                 shutdown_pipeline();
+                release_stdout();
                 printf("\n> ERROR: MEM search on GPU %d failed: %s (%s)\n", device + (int)(bi % (size_t)ngpu), slamem_strerror(rc), detail);
                 join_warmup();
                 exit(-1);
@@ -501,9 +655,9 @@ int main(int argc, char **argv) {
                     total_matches += (long long)cnt;
                     total_sum += (long long)sum;
                     dots = slh_progress_dots(q->recs[ri].size);
-                    printf(":: \"%s%s\" ", q->recs[ri].name, sidx ? " Reverse" : "");
-                    for (d = 0; d < dots; d++) putchar('.');
-                    printf(" (%d M%cMs ; avg size = %d bp)\n", (int)cnt, MATCH_TYPE_CHAR[o.match_type], (int)(cnt ? sum / cnt : 0));
+                    say(":: \"%s%s\" ", q->recs[ri].name, sidx ? " Reverse" : "");
+                    for (d = 0; d < dots; d++) fputc('.', g_mo ? g_mo : stdout);
+                    say(" (%d M%cMs ; avg size = %d bp)\n", (int)cnt, MATCH_TYPE_CHAR[o.match_type], (int)(cnt ? sum / cnt : 0));
                     printed++;
                 }
                 if (writer_push(&g_writer, &buf)) pipeline_fail("Out of memory");
@@ -537,12 +691,21 @@ int main(int argc, char **argv) {
             }
             t_format += now_s() - tg;
         }
+#undef ADD_RANGES_OF_NEW_SETS
         free(ranges);
+        release_stdout(); /* the loader is done: the "successfully loaded" line, then what was held back */
+        total_queries = ld->total_queries;
+        if (ld->ready == 0) { /* slamem.c:648 (an overlapped run only knows it now) */
+            shutdown_pipeline();
+            fclose(out);
+            remove(out_name);
+            exit_message("No query files provided");
+        }
         writer_finish(&g_writer);
         t_write = g_writer.seconds;
         if (g_writer.failed) pipeline_fail("Cannot write output file");
         if (log_limit != 0 && (long)total_queries * strands > log_limit)
-            printf(":: ... (%ld more strand blocks matched; set SLAMEM_VERBOSE=1 for a line each)\n",
+            say(":: ... (%ld more strand blocks matched; set SLAMEM_VERBOSE=1 for a line each)\n",
                    (long)total_queries * strands - log_limit);
     }
     double t_end0 = now_s(), t_end1;
@@ -557,11 +720,14 @@ int main(int argc, char **argv) {
     t_end1 = now_s();
     printf("OK\n");
     printf("> Done!\n");
+    char overlap_note[96] = "";
+    if (g_ld.seconds > 0)
+        snprintf(overlap_note, sizeof(overlap_note), " + queries parsed in pieces beside the search in %.3f s (%.3f s waited for)", g_ld.seconds, t_wait_load);
     if (timing)
-        fprintf(stderr, "[timing] load %.3f s (index build of %.3f s overlapped; %.3f s more waiting for it), pipeline set-up %.3f s, "
+        fprintf(stderr, "[timing] load %.3f s%s (index build of %.3f s overlapped; %.3f s more waiting for it), pipeline set-up %.3f s, "
                         "waiting for the GPU (upload + search + download, overlapped with formatting) %.3f s, format %.3f s "
                         "(writer thread busy %.3f s, overlapped), close %.3f s, total %.3f s\n",
-                t_load, t_build, t_join, t_streams, t_gpu, t_format, t_write, t_end1 - t_end0, now_s() - t_start);
+                t_load, overlap_note, t_build, t_join, t_streams, t_gpu, t_format, t_write, t_end1 - t_end0, now_s() - t_start);
     fflush(stdout);
     fflush(stderr);
     if (getenv("SLAMEM_FULL_TEARDOWN") == NULL) {
@@ -574,7 +740,7 @@ int main(int argc, char **argv) {
     if (o.out_arg == -1) free(out_name);
     slh_buffer_free(&buf);
     slh_free_seqset(&ref);
-    for (f = 0; f < num_qsets; f++) slh_free_seqset(&qsets[f]);
+    for (f = 0; f < g_ld.ready; f++) slh_free_seqset(&qsets[f]);
     free(qsets);
     slh_free_options(&o);
     return 0;

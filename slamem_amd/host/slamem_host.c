@@ -427,6 +427,99 @@ int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, 
     return n;
 }
 
+/* ---- a query file in pieces ----------------------------------------------------------------------------------
+ * The same records as slh_load_file(path, 0, ...), handed out as consecutive sequence sets of about piece_bytes of the
+ * file each (cut at "newline + '>'"), so that a front end can search the first reads while the rest is still parsed.
+ * Every piece is parsed by all host threads (load_parallel).  The "> Loading ..." line and the per-record lines (first
+ * piece only; they are limited to the first log_limit records anyway) go to `log` as with slh_load_file. */
+struct slh_pieces {
+    unsigned char *data;
+    long fsize, pos, piece_bytes;
+    int mapped, acgt_only, first_number, threads, first;
+    uint32_t min_len;
+    long log_limit;
+    FILE *log;
+};
+
+slh_pieces *slh_pieces_open(const char *path, int acgt_only, uint32_t min_len, int first_number, long log_limit,
+                            long piece_bytes, FILE *log) {
+    slh_pieces *p = (slh_pieces *)calloc(1, sizeof(slh_pieces));
+    FILE *f;
+    if (!p) return NULL;
+    if (log) fprintf(log, "> Loading sequences from file <%s> ... ", path);
+    f = fopen(path, "rb");
+    if (!f) {
+        if (log) fprintf(log, "\n> WARNING: Sequence file not found\n");
+        free(p);
+        return NULL;
+    }
+    fseek(f, 0L, SEEK_END);
+    p->fsize = ftell(f);
+    rewind(f);
+    if (log) fprintf(log, "(%ld bytes)\n", p->fsize);
+    if (p->fsize > 0) {
+        void *m = mmap(NULL, (size_t)p->fsize, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+        if (m != MAP_FAILED) { p->data = (unsigned char *)m; p->mapped = 1; }
+    }
+    if (!p->mapped) {
+        p->data = (unsigned char *)malloc(p->fsize > 0 ? (size_t)p->fsize : 1);
+        if (!p->data || (p->fsize > 0 && fread(p->data, 1, (size_t)p->fsize, f) != (size_t)p->fsize)) {
+            if (log) fprintf(log, "> WARNING: Cannot read file\n");
+            free(p->data);
+            free(p);
+            fclose(f);
+            return NULL;
+        }
+    }
+    fclose(f);
+    p->piece_bytes = piece_bytes > (1L << 20) ? piece_bytes : (1L << 20);
+    p->acgt_only = acgt_only;
+    p->min_len = min_len;
+    p->first_number = first_number;
+    p->log_limit = log_limit;
+    p->log = log;
+    p->threads = slh_thread_count();
+    p->first = 1;
+    return p;
+}
+
+/* the next piece: number of records (> 0), 0 at the end of the file (or when the file holds no record at all) */
+int slh_pieces_next(slh_pieces *p, slh_seqset *out) {
+    memset(out, 0, sizeof(*out));
+    while (p->pos < p->fsize) {
+        long start = p->pos, end = start + p->piece_bytes;
+        int n;
+        if (end >= p->fsize) end = p->fsize;
+        else {
+            while (end < p->fsize && !(p->data[end] == '>' && (p->data[end - 1] == '\n' || p->data[end - 1] == '\r'))) end++;
+        }
+        p->pos = end;
+        if (p->first && p->data[start] != '>') {  /* as load_mem: a file that does not start with '>' is not FASTA */
+            if (p->log) fprintf(p->log, "> WARNING: Invalid FASTA file\n");
+            p->pos = p->fsize;
+            return 0;
+        }
+        if (p->threads > 1 && end - start > (16L << 20) && p->log_limit > 0)
+            n = load_parallel(p->data + start, end - start, p->acgt_only, p->min_len, p->first_number, p->log_limit, out,
+                              p->first ? p->log : NULL, p->threads);
+        else n = -1;
+        if (n < 0)
+            n = load_mem(p->data + start, end - start, 0, p->acgt_only, p->min_len, NULL, p->first_number, p->log_limit, out,
+                         p->first ? p->log : NULL);
+        p->first = 0;
+        if (n > 0) { p->first_number += n; return n; }
+        /* a piece without an accepted record (all too short / empty): go on */
+    }
+    return 0;
+}
+
+void slh_pieces_close(slh_pieces *p) {
+    if (!p) return;
+    if (p->mapped) munmap(p->data, (size_t)p->fsize);
+    else free(p->data);
+    free(p);
+}
+
 int slh_seq_id_from_merged_pos(const uint32_t *starts, int num, uint32_t *pos) {
     int lo = 0, hi = num - 1;
     while (lo != hi) { /* binary search for the last start <= pos */

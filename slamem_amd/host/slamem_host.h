@@ -40,6 +40,13 @@ typedef struct {
 int slh_load_file(const char *path, int merge, int acgt_only, uint32_t min_len, const char *name_filter,
                   int first_number, long log_limit, slh_seqset *out, FILE *log);
 void slh_free_seqset(slh_seqset *s);
+/* A query file handed out in consecutive pieces of about piece_bytes of the file each (the same records as
+ * slh_load_file(path, 0, ...) would give in one set): a front end searches the first reads while the rest is parsed. */
+typedef struct slh_pieces slh_pieces;
+slh_pieces *slh_pieces_open(const char *path, int acgt_only, uint32_t min_len, int first_number, long log_limit,
+                            long piece_bytes, FILE *log);
+int slh_pieces_next(slh_pieces *p, slh_seqset *out); /* records in the piece; 0 at the end */
+void slh_pieces_close(slh_pieces *p);
 /* malloc for buffers of tens of MB and more: 2 MB aligned, marked for transparent huge pages; release with free() */
 void *slh_big_malloc(size_t bytes);
 /* host threads used for loading / formatting: SLAMEM_THREADS or the online CPUs, at most 32 */

@@ -28,6 +28,31 @@ def test_cli_output_file_is_byte_identical(case, tmp_path):
     assert b"> Done!" in r.stdout and b"> Saving " + kind + b" to <" in r.stdout
 
 
+def _stable_stdout(raw):
+    """stdout without the figures that differ from run to run (seconds, milliseconds)"""
+    import re
+    return re.sub(rb"[0-9]+\.[0-9]+ (s|ms)|(sort|BWT|LCP|links) [0-9.]+", b"T", raw).split(b"\n")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cli_overlapped_loading_changes_nothing(case, tmp_path):
+    """SLAMEM_OVERLAP_MB=0 sends every run through the loader thread (query files parsed in pieces beside the search,
+    the main thread's lines held back meanwhile): the output file and stdout must be those of the sequential run."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    ref_fa, q_fa, exp_mems, _ = case_paths(case)
+    out = str(tmp_path / "out-mems.txt")
+    cmd = [exe] + MANIFEST[case]["opts"] + ["-o", out, ref_fa, q_fa] + MANIFEST[case].get("tail", [])
+    plain = subprocess.run(cmd, stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB="-1"))
+    assert plain.returncode == 0
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB="0"))
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    assert open(out, "rb").read() == open(exp_mems, "rb").read()
+    assert _stable_stdout(r.stdout) == _stable_stdout(plain.stdout)
+
+
 def test_cli_default_output_name_and_batches(tmp_path):
     import shutil
     import torch
@@ -92,6 +117,16 @@ def test_cli_config2_full_size_output_hash(tmp_path):
             h.update(chunk)
     assert os.path.getsize(os.path.join(d, "out.txt")) == 44_723_866
     assert h.hexdigest().startswith("8f711ed6cd088ee1")
+    # the same with the query file parsed in 16 MB pieces by the loader thread while the search runs
+    r2 = subprocess.run([exe, "-l", "20", "-o", os.path.join(d, "out2.txt"), os.path.join(d, "ref.fa"), os.path.join(d, "qry.fa")],
+                        stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB="0", SLAMEM_PIECE_MB="16"))
+    assert r2.returncode == 0
+    h2 = hashlib.sha256()
+    with open(os.path.join(d, "out2.txt"), "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h2.update(chunk)
+    assert h2.hexdigest() == h.hexdigest()
+    assert _stable_stdout(r2.stdout.replace(b"out2.txt", b"out.txt")) == _stable_stdout(r.stdout)
 
 
 def test_cli_rccl_replication_selftest(tmp_path):

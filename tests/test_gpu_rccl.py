@@ -27,6 +27,15 @@ def test_rccl_single_rank_rehearsal(tmp_path):
         arena = idx.export_arena()
         got = shard.broadcast_arena(arena.clone(), dev, src=0, force=True)
         assert torch.equal(got, arena)
+        # what bench.py does at N > 1: the broadcast reads straight from the index arena (zero-copy view), in pieces
+        view = idx.arena_view()
+        assert view.data_ptr() != arena.data_ptr() and view.numel() == arena.numel()
+        old_piece, shard.BROADCAST_PIECE = shard.BROADCAST_PIECE, 1 << 20
+        try:
+            same = shard.broadcast_arena(view, dev, src=0, force=True)
+        finally:
+            shard.BROADCAST_PIECE = old_piece
+        assert same.data_ptr() == view.data_ptr() and torch.equal(same, arena)
         idx2 = engine.Index.attach(got)
         q = np.frombuffer(text[1000:1150], dtype=np.uint8)
         off = np.array([0, 150], dtype=np.uint64)

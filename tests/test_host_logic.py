@@ -167,3 +167,45 @@ def test_hidden_sort_and_clean_utilities_match_the_reference(case, tmp_path):
     r = subprocess.run([exe, "-c", "r.fa"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.stdout + b"status %d\n" % r.returncode == open(os.path.join(d, "clean-stdout.txt"), "rb").read()
     assert open(tmp_path / "r-clean.fasta", "rb").read() == open(os.path.join(d, "clean.fasta"), "rb").read()
+
+
+def test_pieces_loader_equals_whole_file_loader(tmp_path):
+    """slh_pieces_*: a query file handed out in pieces (what lets the front end search while it parses) holds exactly the
+    records of slh_load_file, in order: names, lengths, normalised characters -- with short records that -m drops, CRLF
+    lines, lower case / IUPAC letters and a last record without a final newline."""
+    import ctypes as C
+    import numpy as np
+    L = hostlib.lib()
+    L.slh_pieces_open.restype = C.c_void_p
+    L.slh_pieces_open.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_int, C.c_long, C.c_long, C.c_void_p]
+    L.slh_pieces_next.argtypes = [C.c_void_p, C.POINTER(hostlib.SeqSet)]
+    L.slh_pieces_close.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(3)
+    parts = []
+    for k in range(30000):
+        n = int(rng.integers(1, 400))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTacgtNRYn", dtype=np.uint8), size=n))
+        nl = b"\r\n" if k % 7 == 0 else b"\n"
+        parts.append(b">r%d some description" % k + nl + seq[: n // 2] + nl + seq[n // 2:] + (b"" if k == 29999 else nl))
+    path = str(tmp_path / "q.fa")
+    open(path, "wb").write(b"".join(parts))
+    for acgt_only, min_len in ((0, 0), (1, 50)):
+        whole = hostlib.Loaded(path, 0, acgt_only, min_len)
+        h = L.slh_pieces_open(path.encode(), acgt_only, min_len, 1, 100, 1 << 20, None)
+        assert h
+        names, sizes, chars, npieces = [], [], [], 0
+        while True:
+            s = hostlib.SeqSet()
+            n = L.slh_pieces_next(h, C.byref(s))
+            if n == 0:
+                break
+            npieces += 1
+            assert n == s.num
+            names += [s.recs[i].name for i in range(s.num)]
+            sizes += [s.recs[i].size for i in range(s.num)]
+            assert [s.offsets[i + 1] - s.offsets[i] for i in range(s.num)] == sizes[-s.num:]
+            chars.append(C.string_at(s.chars, s.total))
+            L.slh_free_seqset(C.byref(s))
+        L.slh_pieces_close(h)
+        assert npieces >= 4
+        assert names == whole.names and sizes == whole.sizes and b"".join(chars) == whole.chars

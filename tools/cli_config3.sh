@@ -11,6 +11,14 @@ for i in 1 2 3; do
   python3 -c "print('process wall %.3f s' % ($T1 - $T0))"
   grep -h "timing" $D/stderr.txt
 done
+for i in 1 2; do
+  T0=$(date +%s.%N)
+  SLAMEM_OVERLAP_MB=-1 SLAMEM_TIMING=1 slamem_amd/host/slaMEM-hip -b -l 20 -o $D/out-seq.txt $D/ref.fa $D/qry.fa > $D/stdout_seq.txt 2> $D/stderr_seq.txt
+  T1=$(date +%s.%N)
+  python3 -c "print('sequential loading: process wall %.3f s' % ($T1 - $T0))"
+  grep -h "timing" $D/stderr_seq.txt
+done
+cmp $D/out-mems.txt $D/out-seq.txt && echo "overlapped == sequential output"
 tail -3 $D/stdout.txt
 ls -l $D/out-mems.txt | awk '{print $5, "bytes"}'
 sha256sum $D/out-mems.txt
