@@ -439,6 +439,7 @@ struct slh_pieces {
     uint32_t min_len;
     long log_limit;
     FILE *log;
+    int release_parsed; /* drop the file pages of a piece once it is parsed (slh_pieces_release_parsed) */
 };
 
 slh_pieces *slh_pieces_open(const char *path, int acgt_only, uint32_t min_len, int first_number, long log_limit,
@@ -507,10 +508,18 @@ int slh_pieces_next(slh_pieces *p, slh_seqset *out) {
             n = load_mem(p->data + start, end - start, 0, p->acgt_only, p->min_len, NULL, p->first_number, p->log_limit, out,
                          p->first ? p->log : NULL);
         p->first = 0;
+        if (p->release_parsed && p->mapped && end - start > (1L << 20)) { /* the parsed part of the file is not read again */
+            long a = (start + 4095) & ~4095L, b = end & ~4095L;
+            if (b > a) (void)madvise(p->data + a, (size_t)(b - a), MADV_DONTNEED);
+        }
         if (n > 0) { p->first_number += n; return n; }
         /* a piece without an accepted record (all too short / empty): go on */
     }
     return 0;
+}
+
+void slh_pieces_release_parsed(slh_pieces *p, int on) {
+    if (p) p->release_parsed = on;
 }
 
 void slh_pieces_close(slh_pieces *p) {

@@ -47,6 +47,9 @@ slh_pieces *slh_pieces_open(const char *path, int acgt_only, uint32_t min_len, i
                             long piece_bytes, FILE *log);
 int slh_pieces_next(slh_pieces *p, slh_seqset *out); /* records in the piece; 0 at the end */
 void slh_pieces_close(slh_pieces *p);
+/* on: the page-cache mapping of every parsed piece is dropped at once (for inputs whose footprint matters more than the
+ * address-space work this causes beside the other threads; off by default) */
+void slh_pieces_release_parsed(slh_pieces *p, int on);
 /* malloc for buffers of tens of MB and more: 2 MB aligned, marked for transparent huge pages; release with free() */
 void *slh_big_malloc(size_t bytes);
 /* host threads used for loading / formatting: SLAMEM_THREADS or the online CPUs, at most 32 */

@@ -45,7 +45,8 @@ def test_cli_overlapped_loading_changes_nothing(case, tmp_path):
     ref_fa, q_fa, exp_mems, _ = case_paths(case)
     out = str(tmp_path / "out-mems.txt")
     cmd = [exe] + MANIFEST[case]["opts"] + ["-o", out, ref_fa, q_fa] + MANIFEST[case].get("tail", [])
-    plain = subprocess.run(cmd, stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB="-1"))
+    # the plain run: everything loaded first, one process (no forked worker)
+    plain = subprocess.run(cmd, stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB="-1", SLAMEM_FOREGROUND="1"))
     assert plain.returncode == 0
     r = subprocess.run(cmd, stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB="0"))
     assert r.returncode == 0, r.stdout.decode(errors="replace")
@@ -117,9 +118,10 @@ def test_cli_config2_full_size_output_hash(tmp_path):
             h.update(chunk)
     assert os.path.getsize(os.path.join(d, "out.txt")) == 44_723_866
     assert h.hexdigest().startswith("8f711ed6cd088ee1")
-    # the same with the query file parsed in 16 MB pieces by the loader thread while the search runs
+    # the same with the query file parsed in 16 MB pieces by the loader thread while the search runs, every piece released
+    # as soon as its batches are formatted
     r2 = subprocess.run([exe, "-l", "20", "-o", os.path.join(d, "out2.txt"), os.path.join(d, "ref.fa"), os.path.join(d, "qry.fa")],
-                        stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB="0", SLAMEM_PIECE_MB="16"))
+                        stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB="0", SLAMEM_PIECE_MB="16", SLAMEM_RELEASE_EARLY_GB="0"))
     assert r2.returncode == 0
     h2 = hashlib.sha256()
     with open(os.path.join(d, "out2.txt"), "rb") as f:
