@@ -335,9 +335,9 @@ struct QueryStream {
 __device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t tag, uint32_t row,
                                          uint32_t pos, uint32_t len);
 __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t row, uint32_t j,
-                                     uint32_t len) {
+                                     uint32_t len, uint32_t tag = 0u) {
     if (A.rows_out) {  // v3 output path: the BWT row is stored, K9 resolves SA[row]; no returned atomic for the first MEMs
-        emit3_at(A, blockid, k, 0u, row, j, len);
+        emit3_at(A, blockid, k, tag, row, j, len);
         k++;
         return;
     }
@@ -359,15 +359,15 @@ __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint
 //               While pub < min_len no ancestor can qualify and GetEnclosingLCPInterval (slamem.c:192) is skipped.
 __device__ __forceinline__ void emit_levels(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t top,
                                             uint32_t bot, int depth, uint32_t pos, uint32_t left, uint32_t same_left,
-                                            int& pub) {
+                                            int& pub, uint32_t tag = 0u) {
     const IndexView& ix = A.ix;
     const int L = (int)A.min_len;
     uint32_t size = bot - top + 1u;
     if (same_left < size) {
-        if (size == 1u) emit(A, blockid, k, top, pos, (uint32_t)depth);
+        if (size == 1u) emit(A, blockid, k, top, pos, (uint32_t)depth, tag);
         else
             for (uint32_t row = top; row <= bot; row++)  // slamem.c:140
-                if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)depth);
+                if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)depth, tag);
     }
     if (pub < L) return;
     uint32_t t = top, b = bot, pt = top, pb = bot;
@@ -375,9 +375,9 @@ __device__ __forceinline__ void emit_levels(const SearchArgs& A, uint32_t blocki
     pub = msz;
     while (msz >= L) {
         for (uint32_t row = t; row != pt; row++)  // new rows above (slamem.c:140)
-            if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)msz);
+            if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)msz, tag);
         for (uint32_t row = b; row != pb; row--)  // new rows below, bottom-up (slamem.c:165)
-            if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)msz);
+            if (bwt_code(ix, row) != left) emit(A, blockid, k, row, pos, (uint32_t)msz, tag);
         pt = t;
         pb = b;
         msz = parent(ix, t, b);  // slamem.c:192
@@ -476,6 +476,126 @@ __global__ void __launch_bounds__(256) k_find_mams(SearchArgs A) {
         prev_bot = bot;
     }
     A.block_counts[g] = k;
+}
+
+// -mam over SLICES of long strands (genome against genome: one lane per whole strand took 9.8 s for a 4.6 Mbp pair).
+// The scan's state between two positions is (top, bot, prev_top, prev_bot, depth) -- with the reference's stale fall-back
+// interval there is no property that tells when a scan started further right has the same state as the full scan, so the
+// slices are SPECULATED and VERIFIED:
+//   pass 0   every slice [a,b) of a strand starts at e = b + warm-up from the root state without emitting, notes the state
+//            it has when it reaches b (in_used), emits [a,b) from there and notes the state it ends with (out).  A warm-up
+//            in which no extension failed (depth = e - b) cannot have met the true state: it is repeated four times as long.
+//   check    the boundary between slice i (right) and i+1 (left) is consistent if in_used == out: the left slice did exactly
+//            what the full scan does, PROVIDED the right slice did.  The rightmost slice starts at the strand's end: by
+//            induction every slice to the right of the first inconsistent boundary is final.
+//   rerun    the slice left of the first inconsistent boundary of each strand is scanned again from `out` (now final),
+//            with attempt tag 1 (each slice is rerun at most once: its start state is final then); check again.
+// The scan is a deterministic function of the state, so the result is the full scan's, whatever the warm-up guessed.
+struct __attribute__((aligned(16))) MamState {
+    uint32_t top, bot, prev_top, prev_bot;
+    int32_t depth;
+    uint32_t pad0, pad1, pad2;
+};
+struct MamPass {
+    const uint32_t* run_list;   // nullptr: pass 0, every item
+    const uint32_t* run_count;
+    MamState* in_used;          // per boundary: boundary x = (item index of its right slice) - (strand block number)
+    MamState* out;
+    const uint32_t* item_block; // strand block number of every item
+    uint32_t slice_len, warm_up;
+};
+
+__device__ __forceinline__ bool same_state(const MamState& a, const MamState& b) {
+    return a.top == b.top && a.bot == b.bot && a.prev_top == b.prev_top && a.prev_bot == b.prev_bot && a.depth == b.depth;
+}
+
+// one position of the reference's loop without the emission (slamem.c:121-129); returns the size of the new interval
+__device__ __forceinline__ uint32_t mam_step(const IndexView& ix, uint32_t c, MamState& s) {
+    uint32_t size = 0;
+    for (;;) {
+        uint32_t t = s.top, b = s.bot;
+        if (follow(ix, c, t, b)) { s.top = t; s.bot = b; size = b - t + 1u; break; }
+        s.top = s.prev_top;
+        s.bot = s.prev_bot;
+        s.depth = parent(ix, s.top, s.bot);
+        if (s.depth < 0) break;
+        s.prev_top = s.top;
+        s.prev_bot = s.bot;
+    }
+    s.depth++;
+    return size;
+}
+
+__global__ void __launch_bounds__(256) k_find_mams_sliced(SearchArgs A, MamPass P) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool rerun = P.run_list != nullptr;
+    uint64_t it;
+    if (rerun) { if (g >= *P.run_count) return; it = P.run_list[g]; }
+    else { if (g >= A.num_items) return; it = g; }
+    const ItemDesc d = A.items[it];
+    const uint32_t len = d.len, rev = d.slice_rev >> 31, c_idx = d.slice_rev & 0x7FFFFFFFu;
+    const uint32_t cnt = len ? (len + P.slice_len - 1u) / P.slice_len : 1u;
+    const uint32_t i = cnt - 1u - c_idx;  // 0 = the strand's rightmost slice
+    const uint32_t a = c_idx * P.slice_len, b = (len - a <= P.slice_len) ? len : a + P.slice_len;
+    const uint64_t xr = it - 1u - P.item_block[it];  // boundary to the right (i > 0), to the left: xr + 1 (i < cnt - 1)
+    const IndexView& ix = A.ix;
+    const int L = (int)A.min_len;
+    QueryCursor qc;
+    qc.init(A.qwords, d.base, len, rev);
+    MamState s;
+    s.top = 0; s.bot = ix.n; s.prev_top = 0; s.prev_bot = ix.n; s.depth = 0;  // slamem.c:110-113
+    s.pad0 = s.pad1 = s.pad2 = 0;
+    uint32_t attempt = 0;
+    if (i > 0u) {
+        if (rerun) {
+            s = P.out[xr];
+            attempt = (uint32_t)A.item_attempt[it] + 1u;
+        } else {
+            uint32_t w = P.warm_up;
+            for (;;) {
+                const uint32_t e = (len - b <= w) ? len : b + w;
+                s.top = 0; s.bot = ix.n; s.prev_top = 0; s.prev_bot = ix.n; s.depth = 0;
+                for (uint32_t j = e; j-- > b;) {
+                    uint32_t size = mam_step(ix, qc.at(j), s);
+                    if (!(s.depth >= L && size != 1u)) { s.prev_top = s.top; s.prev_bot = s.bot; }  // slamem.c:131 / :197-198
+                }
+                if (e == len || s.depth < (int)(e - b)) break;
+                w = w < 0x20000000u ? w * 4u : 0xFFFFFFFFu;
+            }
+        }
+        P.in_used[xr] = s;
+    }
+    uint32_t k = 0;
+    for (uint32_t j = b; j-- > a;) {
+        uint32_t size = mam_step(ix, qc.at(j), s);
+        if (s.depth >= L) {
+            if (size != 1u) continue;  // slamem.c:131 (prev_top / prev_bot keep their old values)
+            uint32_t left = j ? qc.at(j - 1u) : 0xFFu;  // slamem.c:137-138
+            int pub = 0x3FFFFFFF;
+            emit_levels(A, (uint32_t)it, k, s.top, s.bot, s.depth, j, left, bwt_code(ix, s.top) == left ? 1u : 0u, pub, attempt << 28);
+        }
+        s.prev_top = s.top;  // slamem.c:197-198
+        s.prev_bot = s.bot;
+    }
+    if (i + 1u < cnt) P.out[xr + 1u] = s;
+    A.block_counts[it] = k;
+    A.item_attempt[it] = (uint8_t)attempt;
+}
+
+// the slices to scan again: left of the FIRST inconsistent boundary of their strand (see above)
+__global__ void __launch_bounds__(256) k_mam_check(SearchArgs A, MamPass P, uint32_t* __restrict__ list, unsigned int* __restrict__ count) {
+    const uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= A.num_items) return;
+    const ItemDesc d = A.items[it];
+    const uint32_t len = d.len, c_idx = d.slice_rev & 0x7FFFFFFFu;
+    const uint32_t cnt = len ? (len + P.slice_len - 1u) / P.slice_len : 1u;
+    const uint32_t i = cnt - 1u - c_idx;
+    if (i == 0u) return;
+    const uint64_t xr = it - 1u - P.item_block[it];
+    if (same_state(P.in_used[xr], P.out[xr])) return;
+    for (uint32_t r = 1; r < i; r++)
+        if (!same_state(P.in_used[xr - r], P.out[xr - r])) return;  // not the first one
+    list[atomicAdd(count, 1u)] = (uint32_t)it;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1509,7 +1629,8 @@ __global__ void __launch_bounds__(256) k_item_counts(const uint64_t* __restrict_
 // strand carries the block's offset, positions stay relative to the strand
 __global__ void __launch_bounds__(256) k_item_fill(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ first,
                                                    const uint64_t* __restrict__ wscan, uint32_t nq, uint32_t strands,
-                                                   ItemDesc* __restrict__ items, uint64_t* __restrict__ item_pk) {
+                                                   ItemDesc* __restrict__ items, uint64_t* __restrict__ item_pk,
+                                                   uint32_t* __restrict__ item_block) {
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     uint64_t o0 = offsets[q];
@@ -1521,6 +1642,7 @@ __global__ void __launch_bounds__(256) k_item_fill(const uint64_t* __restrict__ 
             uint64_t it = (uint64_t)strands * f + (uint64_t)s * cnt + (cnt - 1u - c);
             items[it] = ItemDesc{o0, len, c | (s << 31)};
             if (item_pk) item_pk[it] = 2ull + (uint64_t)strands * w0 + (uint64_t)s * wps;
+            if (item_block) item_block[it] = (uint32_t)(q * strands + s);
         }
 }
 
@@ -1598,7 +1720,7 @@ inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_alive, off_workids, off_select, select_bytes, off_itemoff, off_rawkey,
-        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, max_items, bytes;
+        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, off_mamstate, off_mamrun, off_itemblock, max_bounds, max_items, bytes;
 };
 
 // max_items bounds the work items of ANY batch with this many records and characters
@@ -1638,6 +1760,11 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     w.off_pq = off;       off = align_up(off + w.pq_bytes, 256);
     w.off_pq2 = off;      off = align_up(off + w.pq_bytes / 2 + 64, 256);
     w.off_itemflags = off; off = align_up(off + w.max_items, 256);
+    // -mam over slices: two states per slice boundary, the list of slices to scan again, the strand block of every item
+    w.max_bounds = strands * (query_bytes / kSliceLen + 1);
+    w.off_mamstate = off; off = align_up(off + 2 * w.max_bounds * sizeof(MamState), 256);
+    w.off_mamrun = off;   off = align_up(off + w.max_bounds * 4, 256);
+    w.off_itemblock = off; off = align_up(off + w.max_items * 4, 256);
     w.bytes = off;
     return w;
 }
@@ -1645,6 +1772,12 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
 
 uint64_t find_mems_workspace_bytes(uint64_t num_queries, int both_strands, uint64_t query_bytes, uint64_t mems_capacity) {
     return layout_workspace(num_queries, both_strands ? 2 : 1, query_bytes, mems_capacity).bytes;
+}
+
+// SLAMEM_MAM_WHOLE=1: -mam with one lane per whole strand (k_find_mams), no slices
+static bool mam_whole_strands() {
+    static const bool on = [] { const char* v = getenv("SLAMEM_MAM_WHOLE"); return v && atoi(v) != 0; }();
+    return on;
 }
 
 struct SearchJob {
@@ -1709,7 +1842,7 @@ int SearchJob::init(const slamem_index* idx_, const void* queries_dev_, const ui
         return SLAMEM_ERR_ARG;
     }
     static const int env_kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
-    // MAM mode scans whole strands with k_find_mams (one lane per strand); its MAMs leave through the v3 output path
+    // MAM mode scans with k_find_mams_sliced (one lane per slice of a strand); its MAMs leave through the v3 output path
     kernel_version = match_type == 1 ? 1 : env_kernel_version;
     want_stats = search_stats_wanted();
     for (int i = 0; i < 5; i++)
@@ -1737,7 +1870,7 @@ int SearchJob::tables(hipStream_t stream) {
     uint32_t* d_wps = reinterpret_cast<uint32_t*>(ws + w.off_wps);
     uint64_t* d_wscan = reinterpret_cast<uint64_t*>(ws + w.off_wscan);
     hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
-                       num_queries, kernel_version == 3 ? kSliceLen : 0u, d_cnt, d_wps);
+                       num_queries, (kernel_version == 3 || (match_type == 1 && !mam_whole_strands())) ? kSliceLen : 0u, d_cnt, d_wps);
     STEP(hipGetLastError(), "k_item_counts");
     STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
     uint32_t slices = 0;
@@ -1774,7 +1907,7 @@ int SearchJob::tables(hipStream_t stream) {
         uint64_t* d_itempk = reinterpret_cast<uint64_t*>(ws + w.off_itempk);
         uint64_t* d_pq = reinterpret_cast<uint64_t*>(ws + w.off_pq);
         hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
-                           num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk);
+                           num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk, (uint32_t*)nullptr);
         STEP(hipGetLastError(), "k_item_fill");
         STEP(hipMemsetAsync(d_pq, 0, 16, stream), "memset");  // the two leading zero words
         A.pq = d_pq;
@@ -1872,8 +2005,48 @@ int SearchJob::launch(hipStream_t stream) {
     } else if (nitems && match_type == 1) {
         A.rows_out = 1;  // K9 of the v3 path places the MAMs and resolves their rows
         STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
-        hipLaunchKernelGGL(k_find_mams, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
-        STEP(hipGetLastError(), "k_find_mams");
+        static const uint32_t env_warm = [] { const char* v = getenv("SLAMEM_MAM_WARMUP"); return v && atoi(v) > 0 ? (uint32_t)atoi(v) : kWarmUp; }();
+        static const bool env_trace = getenv("SLAMEM_MAM_TRACE") != nullptr;
+        if (mam_whole_strands()) {  // the whole-strand scan (what the slices are checked against in the tests)
+            hipLaunchKernelGGL(k_find_mams, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
+            STEP(hipGetLastError(), "k_find_mams");
+        } else {
+            MamPass P;
+            uint32_t* d_block = reinterpret_cast<uint32_t*>(ws + w.off_itemblock);
+            uint32_t* d_run = reinterpret_cast<uint32_t*>(ws + w.off_mamrun);
+            unsigned int* d_nrun = reinterpret_cast<unsigned int*>(d_total + 6);  // a word of the zeroed scalar block
+            hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev,
+                               reinterpret_cast<const uint32_t*>(ws + w.off_first), (const uint64_t*)nullptr, num_queries, strands,
+                               reinterpret_cast<ItemDesc*>(ws + w.off_items), (uint64_t*)nullptr, d_block);
+            STEP(hipGetLastError(), "k_item_fill");
+            P.run_list = nullptr; P.run_count = nullptr;
+            P.in_used = reinterpret_cast<MamState*>(ws + w.off_mamstate);
+            P.out = P.in_used + w.max_bounds;
+            P.item_block = d_block;
+            P.slice_len = kSliceLen;
+            P.warm_up = env_warm;
+            hipLaunchKernelGGL(k_find_mams_sliced, dim3(grid_for(nitems)), dim3(256), 0, stream, A, P);
+            STEP(hipGetLastError(), "k_find_mams_sliced");
+            uint64_t reruns = 0, passes = 0;
+            while (nitems != num_blocks) {  // some strand has more than one slice: verify, scan again what was guessed wrong
+                unsigned int nrun = 0;
+                STEP(hipMemsetAsync(d_nrun, 0, 4, stream), "memset");
+                hipLaunchKernelGGL(k_mam_check, dim3(grid_for(nitems)), dim3(256), 0, stream, A, P, d_run, d_nrun);
+                STEP(hipGetLastError(), "k_mam_check");
+                STEP(hipMemcpyAsync(&nrun, d_nrun, 4, hipMemcpyDeviceToHost, stream), "memcpy");
+                STEP(hipStreamSynchronize(stream), "k_mam_check (sync)");
+                if (nrun == 0) break;
+                reruns += nrun; passes++;
+                MamPass R = P;
+                R.run_list = d_run;
+                R.run_count = d_nrun;
+                hipLaunchKernelGGL(k_find_mams_sliced, dim3(grid_for(nrun)), dim3(256), 0, stream, A, R);
+                STEP(hipGetLastError(), "k_find_mams_sliced (rerun)");
+            }
+            if (env_trace)
+                fprintf(stderr, "[mam] %llu slices of %llu strands, warm-up %u: %llu scanned again in %llu passes\n", (unsigned long long)nitems,
+                        (unsigned long long)num_blocks, env_warm, (unsigned long long)reruns, (unsigned long long)passes);
+        }
     } else if (nitems) {
         hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
         STEP(hipGetLastError(), "k_find_mems");

@@ -314,10 +314,10 @@ def test_stream_host_to_host_matches_device_path(eng):
 
 
 def test_mam_long_record_matches_oracle_and_overflows_inline_slots(eng):
-    """-mam on a long record (160 kbp against a 250 kbp text with repeat families): one lane scans the whole strand
-    (the mode's stale fall-back interval, slamem.c:122-123,131,197-198, makes a slice depend on its past), its MAMs
-    leave through the v3 output path (4 inline slots, then the overflow list; rows resolved by K9).  In order against
-    the oracle, both strands."""
+    """-mam on a long record (160 kbp against a 250 kbp text with repeat families): 40 verified slices per strand (the
+    mode's stale fall-back interval, slamem.c:122-123,131,197-198, makes a slice depend on its past: k_find_mams_sliced),
+    its MAMs leave through the v3 output path (4 inline slots, then the overflow list; rows resolved by K9).  In order
+    against the oracle, both strands."""
     import time
     from oracle import pyoracle as po
     rng = np.random.default_rng(77)
@@ -340,6 +340,31 @@ def test_mam_long_record_matches_oracle_and_overflows_inline_slots(eng):
         assert np.array_equal(gm[f], om[f]), f
     assert dt < 20.0
     g.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"SLAMEM_MAM_WARMUP": "8"}, {"SLAMEM_MAM_WARMUP": "100000000"}, {"SLAMEM_MAM_WHOLE": "1"}],
+                         ids=["default", "warmup8", "warmup_whole_strand", "whole_strands_kernel"])
+def test_mam_slices_equal_the_whole_strand_scan(eng, env):
+    """-mam over 4096-position slices of long strands (tests/mam_slices_check.py in a child process): the start state of a
+    slice is guessed from a warm-up and verified against the state its right neighbour ends with; wrong guesses are
+    scanned again.  Whatever the warm-up (8 positions: nearly every guess wrong; unbounded: every guess right; the
+    default), and with the one-lane-per-strand kernel, the MAMs are the oracle's whole-strand scan's, in order."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "mam_slices_check.py")], env=dict(os.environ, SLAMEM_MAM_TRACE="1", **env),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-3000:]
+    out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert out["all_equal"], out
+    assert all(c["mams"] > 100 for c in out["cases"].values())
+    trace = r.stderr.decode()
+    if env.get("SLAMEM_MAM_WARMUP") == "8":
+        assert "scanned again" in trace and " 0 scanned again" not in trace  # the verification did its work
+    if env.get("SLAMEM_MAM_WARMUP") == "100000000":
+        assert " 0 scanned again in 0 passes" in trace  # a warm-up from the strand's end is the whole scan
 
 
 def test_skip_variant_is_exact(eng):

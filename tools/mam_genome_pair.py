@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Cost of -mam on long records (one lane per strand, no slicing): the 4.6 Mbp genome pair of configs[0] through the
-API, wall time of the search, checked against the oracle."""
+"""Cost of -mam on long records: the 4.6 Mbp genome pair of configs[0] through the API, wall time of the search, checked
+against the oracle.  (SLAMEM_MAM_WHOLE=1: one lane per whole strand, the round-1 form; default: verified slices.)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
