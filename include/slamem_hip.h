@@ -276,7 +276,8 @@ void slamem_host_free(void *p);
  *   slamem_stream_submit   record i of the batch is queries[offsets[i] .. offsets[i+1]) -- offsets[0] need not be 0, so
  *                          a front end passes its whole character buffer and a window of its offsets array.  Returns at
  *                          once; the characters and offsets must stay unchanged until the batch has been collected.
- *                          Uploads run at full PCIe rate when `queries` is pinned memory (slamem_pinned_alloc).
+ *                          Uploads run at full PCIe rate when `queries` AND `offsets` are pinned memory
+ *                          (slamem_pinned_alloc): 8 bytes of offsets per record go up with every batch.
  *                          Never blocks: SLAMEM_ERR_ARG when every slot is in use.
  *   slamem_stream_next     waits for the OLDEST submitted batch (results come back in submission order) and lends its
  *                          result: mems grouped by strand block in the reference's emission order and block offsets,

@@ -71,6 +71,8 @@ struct slamem_stream {
     // thread 0 uploads, threads 1..nsearch search (batch b on thread 1 + b mod nsearch), the last one downloads
     std::thread th[kMaxThreads];
     hipStream_t st[kMaxThreads] = {};
+    hipStream_t st_up2 = nullptr;  // second copy stream of the upload stage (SLAMEM_STREAM_UPLOAD_SPLIT)
+    int upload_split = 1;
     int nsearch = 2, nthreads = 4;
     std::mutex mu;
     std::condition_variable cv;
@@ -124,10 +126,18 @@ int stage_upload(slamem_stream* s, Slot& sl) {
         sl.cap_chars = nchars;
         sl.cap_q = nrec;
     }
-    if (qbytes)
-        SLAMEM_HIP(hipMemcpyAsync(static_cast<char*>(sl.d_q) + kFront + (base & 15u), sl.chars + base, qbytes, hipMemcpyHostToDevice, s->st[0]));
+    char* dst = static_cast<char*>(sl.d_q) + kFront + (base & 15u);
+    const char* src = sl.chars + base;
+    uint64_t first = qbytes;
+    const bool split = s->upload_split > 1 && s->st_up2 && qbytes >= (8u << 20);
+    if (split) {  // two copy engines: the second half of the characters goes up beside the first
+        first = (qbytes / 2) & ~(uint64_t)4095;
+        SLAMEM_HIP(hipMemcpyAsync(dst + first, src + first, qbytes - first, hipMemcpyHostToDevice, s->st_up2));
+    }
+    if (first) SLAMEM_HIP(hipMemcpyAsync(dst, src, first, hipMemcpyHostToDevice, s->st[0]));
     SLAMEM_HIP(hipMemcpyAsync(sl.d_off, sl.offs, ((uint64_t)sl.nq + 1) * 8, hipMemcpyHostToDevice, s->st[0]));
     SLAMEM_HIP(hipStreamSynchronize(s->st[0]));
+    if (split) SLAMEM_HIP(hipStreamSynchronize(s->st_up2));
     return SLAMEM_OK;
 }
 
@@ -260,6 +270,7 @@ int slamem_stream_destroy(slamem_stream* s) {
     for (int k = 0; k < s->nslots; k++) free_slot(s->slot[k]);
     for (int k = 0; k < kMaxThreads; k++)
         if (s->st[k]) (void)hipStreamDestroy(s->st[k]);
+    if (s->st_up2) (void)hipStreamDestroy(s->st_up2);
     delete s;
     return SLAMEM_OK;
 }
@@ -292,7 +303,16 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
         hipError_t e = hipStreamCreateWithFlags(&s->st[k], hipStreamNonBlocking);
         if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
     }
+    {
+        const char* v = getenv("SLAMEM_STREAM_UPLOAD_SPLIT");
+        if (v && atoi(v) >= 1) s->upload_split = atoi(v);
+        if (rc == SLAMEM_OK && s->upload_split > 1) {
+            hipError_t e = hipStreamCreateWithFlags(&s->st_up2, hipStreamNonBlocking);
+            if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+        }
+    }
     if (rc != SLAMEM_OK) {
+        if (s->st_up2) (void)hipStreamDestroy(s->st_up2);
         for (int k = 0; k < slots; k++) free_slot(s->slot[k]);
         for (int k = 0; k < kMaxThreads; k++)
             if (s->st[k]) (void)hipStreamDestroy(s->st[k]);

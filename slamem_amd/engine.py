@@ -325,7 +325,7 @@ class Stream:
 
 
 def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len: int, min_len: int, both: bool,
-                     steps: int = 2, batch_reads: int = 1_000_000, slots: int = 6) -> dict:
+                     steps: int = 2, batch_reads: int = 1_000_000, slots: int = 6, schedule=None) -> dict:
     """SURVEY.md 8(d)'s metric as defined -- reads resident in host memory -> MEM triples in host memory -- through
     slamem_stream_*: the reads sit in pinned host memory, batches of `batch_reads` are pipelined over `slots` lanes, and
     the clock runs from the first submit to the last result.  Returns fields for the bench line."""
@@ -333,18 +333,26 @@ def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len
     L = read_len
     buf = PinnedBuffer(count * L + 64)
     buf.array[: count * L] = reads_dev[: count * L].cpu().numpy()
-    offsets = (np.arange(count + 1, dtype=np.uint64) * np.uint64(L))
-    # batch boundaries: two short batches first (the pipeline starts searching after a quarter of a batch is up)
+    # the record offsets live in pinned memory like the reads: 8 bytes per read go up with every batch, and from pageable
+    # memory that copy runs at a fifth of the link's rate (measured: 0.8 ms of a 3.6 ms upload per million reads)
+    obuf = PinnedBuffer((count + 1) * 8)
+    offsets = obuf.array.view(np.uint64)
+    offsets[:] = np.arange(count + 1, dtype=np.uint64) * np.uint64(L)
+    # batch boundaries: short batches first (the pipeline starts searching after a quarter of a batch is up), or the sizes
+    # the caller asks for (`schedule`, in reads; the last size repeats)
     cuts, pos = [0], 0
-    for size in (batch_reads // 4, batch_reads // 2):
+    sizes = list(schedule) if schedule else [batch_reads // 4, batch_reads // 2]
+    for size in sizes:
         if 0 < size and pos + size < count:
             pos += size
             cuts.append(pos)
+    tail = (sizes[-1] if schedule else batch_reads) or batch_reads
     while pos < count:
-        pos = min(count, pos + batch_reads)
+        pos = min(count, pos + tail)
         cuts.append(pos)
     nb = len(cuts) - 1
-    st = Stream(index, slots, batch_reads * L, batch_reads, both)
+    biggest = int(np.diff(np.array(cuts)).max())
+    st = Stream(index, slots, biggest * L, biggest, both)
     best, total_mems, kernel_ms = None, 0, 0.0
     try:
         for rep in range(steps + 1):  # first pass warms the stream's buffers up
@@ -365,12 +373,14 @@ def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len
             total_mems, kernel_ms = got, kms
     finally:
         st.close()
+        offsets = None
+        obuf.close()
         buf.close()
     return {"value_host_to_host": total_mems / best, "host_to_host_ms": best * 1e3, "host_to_host_mems": int(total_mems),
             "host_to_host": {"batches": nb, "batch_reads": batch_reads, "slots": slots, "h2d_bytes": count * L,
                              "d2h_bytes": 12 * int(total_mems) + 8 * (count * (2 if both else 1) + nb),
                              "kernel_ms_sum": kernel_ms,
-                             "note": "reads in pinned host memory -> MEMs in pinned host memory through slamem_stream_* "
+                             "note": "reads and record offsets in pinned host memory -> MEMs in pinned host memory through slamem_stream_* "
                                      "(uploads, kernels and downloads of neighbouring batches overlap); best of "
                                      f"{steps} passes over the same {count} reads"}}
 

@@ -25,7 +25,13 @@ m.run(reads, offsets, 20); engine.reset_timings()
 t0 = time.perf_counter(); tot = m.run(reads, offsets, 20); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({"device_resident_ms": dt * 1e3, "mems": tot, "kernel_ms": engine.timings()["search_kernel_ms"]}), flush=True)
 del m
-for batch, slots in ((500_000, 6), (1_000_000, 6), (1_000_000, 8), (1_500_000, 6), (2_000_000, 6)):
-    r = engine.host_to_host_leg(idx, reads, M, L, 20, True, steps=2, batch_reads=batch, slots=slots)
-    print(json.dumps({"batch_reads": batch, "slots": slots, "ms": r["host_to_host_ms"], "MEMs_per_s": r["value_host_to_host"],
+K = 1000
+for name, sched in (("current", None),
+                    ("B", [250 * K, 500 * K, 1000 * K, 2000 * K, 3000 * K, 3250 * K]),
+                    ("C", [250 * K, 500 * K, 1000 * K, 2000 * K, 2500 * K, 2500 * K, 1250 * K]),
+                    ("D", [250 * K, 500 * K, 1000 * K, 1500 * K, 2000 * K, 2000 * K, 1750 * K, 1000 * K]),
+                    ("E", [125 * K, 250 * K, 500 * K, 1000 * K, 2000 * K, 2500 * K, 2000 * K, 1000 * K, 625 * K]),
+                    ("F", [250 * K, 750 * K, 1500 * K, 1500 * K])):
+    r = engine.host_to_host_leg(idx, reads, M, L, 20, True, steps=2, batch_reads=1_000_000, slots=6, schedule=sched)
+    print(json.dumps({"schedule": name, "ms": r["host_to_host_ms"], "MEMs_per_s": r["value_host_to_host"], "batches": r["host_to_host"]["batches"],
                       "kernel_ms_sum": r["host_to_host"]["kernel_ms_sum"]}), flush=True)
