@@ -177,15 +177,4 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                      slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
                      uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out);
 uint64_t find_mems_workspace_bytes(uint64_t num_queries, int both_strands, uint64_t query_bytes, uint64_t mems_capacity);
-// find_mems_device in three steps (mem_search.hip): tables (small sync), launch (asynchronous), finish (synchronous)
-struct SearchJob;
-SearchJob* search_job_new();
-void search_job_delete(SearchJob* j);
-int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev, uint32_t num_queries,
-                    uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type, slamem_mem* mems_dev,
-                    uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev, uint64_t workspace_bytes);
-int search_job_tables(SearchJob* j, hipStream_t stream);
-int search_job_launch(SearchJob* j, hipStream_t stream);
-int search_job_finish(SearchJob* j, hipStream_t stream);
-uint64_t search_job_total(const SearchJob* j);
 }  // namespace slamem

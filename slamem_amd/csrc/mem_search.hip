@@ -2150,19 +2150,6 @@ int SearchJob::finish(hipStream_t stream) {
 }
 #undef STEP
 
-// the same steps behind an opaque pointer, for stream.hip
-SearchJob* search_job_new() { return new (std::nothrow) SearchJob(); }
-void search_job_delete(SearchJob* j) { delete j; }
-int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev, uint32_t num_queries,
-                    uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type, slamem_mem* mems_dev,
-                    uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev, uint64_t workspace_bytes) {
-    return j->init(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev, mems_capacity,
-                   block_offsets_dev, workspace_dev, workspace_bytes);
-}
-int search_job_tables(SearchJob* j, hipStream_t stream) { return j->tables(stream); }
-int search_job_launch(SearchJob* j, hipStream_t stream) { return j->launch(stream); }
-int search_job_finish(SearchJob* j, hipStream_t stream) { return j->finish(stream); }
-uint64_t search_job_total(const SearchJob* j) { return j->total; }
 int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
                      uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
                      slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
