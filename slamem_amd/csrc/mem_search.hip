@@ -167,8 +167,8 @@ struct SearchArgs {
     uint32_t num_queries;
     uint32_t strands;          // 1 or 2
     uint32_t min_len;
-    int32_t spec_depth;        // (unused)
-    uint32_t chunk;            // v3: work items owned by one wave
+    int32_t pad0;
+    uint32_t pad1;
     uint32_t pad;
     uint64_t capacity;         // raw records that fit
     unsigned long long* total; // running number of MEMs
@@ -190,7 +190,7 @@ struct SearchArgs {
     unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
     int32_t direct_min_depth;   // v3: a single-row match at least this deep is extended by comparing with the text (<0: off)
     uint32_t use_jump;          // v3: take the first K letters of a scan through the K-mer jump table
-    uint32_t rows_out;          // v1 / MAM kernels: store rows through the v3 output path (inline slots + overflow list)
+    uint32_t pad2;
     uint32_t skip_w;            // v3: letters verified on the diagonal behind a disagreeing letter (min_len - 1); 0 = no skipping
     const uint64_t* pq2;        // v3: the strands at 2 bits per letter (32 letters per word), at half the offsets of pq
     uint64_t* pq2_out;
@@ -202,7 +202,6 @@ struct SearchArgs {
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
 struct RawRow { uint32_t row, pos, len; };
 constexpr uint32_t kInlineMems = 4;     // MEMs per work item stored in place; more go to the overflow list
-constexpr uint32_t kChunkMax = 128;     // (v1 kernels) work items per wave
 constexpr uint32_t kFetch = 64;         // v3: work items a wave takes from the global cursor at a time
 
 // Work item of K8 v3 = one strand of one query record, or -- for long records (genome against genome) -- one
@@ -334,19 +333,11 @@ struct QueryStream {
 
 __device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t tag, uint32_t row,
                                          uint32_t pos, uint32_t len);
+// the lane-level emission of the -mam kernels: through the v3 output path (the BWT row is stored, K9 resolves SA[row];
+// no returned atomic for the first MEMs of an item)
 __device__ __forceinline__ void emit(const SearchArgs& A, uint32_t blockid, uint32_t& k, uint32_t row, uint32_t j,
                                      uint32_t len, uint32_t tag = 0u) {
-    if (A.rows_out) {  // v3 output path: the BWT row is stored, K9 resolves SA[row]; no returned atomic for the first MEMs
-        emit3_at(A, blockid, k, tag, row, j, len);
-        k++;
-        return;
-    }
-    uint32_t r = A.ix.sa[row];  // FMI_PositionInText
-    unsigned long long slot = atomicAdd(A.total, 1ull);  // the compiler aggregates this per wave
-    if (slot < A.capacity) {
-        A.raw_key[slot] = RawKey{blockid, k};
-        A.raw_mem[slot] = slamem_mem{r, j, len};
-    }
+    emit3_at(A, blockid, k, tag, row, j, len);
     k++;
 }
 
@@ -382,54 +373,6 @@ __device__ __forceinline__ void emit_levels(const SearchArgs& A, uint32_t blocki
         pb = b;
         msz = parent(ix, t, b);  // slamem.c:192
     }
-}
-
-__global__ void __launch_bounds__(256) k_find_mems(SearchArgs A) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t nblocks = (uint64_t)A.num_queries * A.strands;
-    if (g >= nblocks) return;
-    uint32_t qi = (uint32_t)(A.strands == 2 ? g >> 1 : g);
-    uint32_t rev = A.strands == 2 ? (uint32_t)(g & 1u) : 0u;
-    uint64_t o0 = A.offsets[qi], o1 = A.offsets[qi + 1];
-    uint32_t len = (uint32_t)(o1 - o0);
-    const IndexView& ix = A.ix;
-    const int L = (int)A.min_len;
-
-    QueryCursor qc;
-    qc.init(A.qwords, o0, len, rev);
-
-    BlkCache bc;
-    bc.it = bc.ib = 0xFFFFFFFFu;
-    uint32_t top = 0, bot = ix.n;  // root: all rows  (slamem.c:110-111)
-    int depth = 0;
-    int pub = -1;       // bound on the parent depth of [top,bot]: the root has no parent
-    bool pend = false;  // position j+1 matched >= min_len characters: its rows wait for the left letter
-    uint32_t k = 0;
-    for (uint32_t j = len; j-- > 0u;) {  // slamem.c:114
-        cache_blocks(ix, bc, top, bot);  // issue the block loads first: they do not depend on the query letter
-        uint32_t c = qc.at(j);
-        uint32_t nt, nb1;
-        occ_pair(ix, bc, c, top, bot, nt, nb1);
-        if (pend) emit_levels(A, (uint32_t)g, k, top, bot, depth, j + 1u, c, nb1 - nt, pub);
-        // extend to the left, widening to parent intervals while the extension fails (slamem.c:121-128)
-        while (nt >= nb1) {
-            int d = parent(ix, top, bot);
-            depth = d;
-            if (d < 0) break;  // root and the letter does not occur at all
-            pub = d - 1;       // the parent of an interval of depth d is shallower than d
-            cache_blocks(ix, bc, top, bot);
-            occ_pair(ix, bc, c, top, bot, nt, nb1);
-        }
-        if (nt < nb1) {
-            top = nt;
-            bot = nb1 - 1u;
-            pub++;  // parent depth of cW <= parent depth of W + 1
-        }
-        depth++;  // slamem.c:129
-        pend = depth >= L && depth > 0;  // slamem.c:130
-    }
-    if (pend) emit_levels(A, (uint32_t)g, k, top, bot, depth, 0u, 0xFFu, 0u, pub);  // j == 0: nothing to the left (slamem.c:138)
-    A.block_counts[g] = k;
 }
 
 // -mam (slamem.c:131,657): the reference's scan with its MAM test -- a position whose interval is not a single row is
@@ -601,10 +544,11 @@ __global__ void __launch_bounds__(256) k_mam_check(SearchArgs A, MamPass P, uint
 // ------------------------------------------------------------------------------------------
 // K8 v3: the same scan as a persistent, desynchronised state machine with ONE memory phase per trip.
 //
-// k_find_mems (v1) walks all 64 strands of a wave through position j in lockstep.  Per-lane rare events (a
-// failed extension, an emitted MEM, a record that starts) are per-wave COMMON events, and each one is a
-// dependent round trip that stalls the whole wave with a handful of loads in flight: measured 66 requests in
-// flight per CU, TA 75 % busy, 1100-cycle request latency -- latency-bound far below the random-line ceiling.
+// Round 1's first kernel (one lane per strand, all 64 strands of a wave walked through position j in lockstep; removed
+// in round 2) showed why: per-lane rare events (a failed extension, an emitted MEM, a record that starts) are per-wave
+// COMMON events, and each one is a dependent round trip that stalls the whole wave with a handful of loads in flight:
+// measured 66 requests in flight per CU, TA 75 % busy, 1100-cycle request latency -- latency-bound far below the
+// random-line ceiling.
 //
 // Here every loop trip issues all of its loads up front from addresses known since the previous trip -- FM block
 // of `top`, FM block of `bot+1`, the two row records, the next query word -- waits once, and then every lane
@@ -616,7 +560,7 @@ __global__ void __launch_bounds__(256) k_mam_check(SearchArgs A, MamPass P, uint
 //     an LDS copy made once per wave;
 //   * only genuinely rare work (intervals of several rows, ancestors that are still >= min_len deep, the letter N,
 //     more than kInlineMems MEMs in one strand) takes divergent dependent loads.
-// Results are identical to v1: same MEMs, same per-strand emission order.
+// Results: the reference's MEMs in the reference's per-strand emission order.
 // ------------------------------------------------------------------------------------------
 // store MEM number kk of strand block g (kk is assigned by the caller)
 __device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t tag, uint32_t row,
@@ -1659,16 +1603,6 @@ __global__ void __launch_bounds__(256) k_block_offsets(const uint32_t* __restric
     block_offsets[b] = item_off[(uint64_t)strands * f + (uint64_t)sidx * cnt];
 }
 
-// K9: raw list -> grouped output
-__global__ void __launch_bounds__(256) k_scatter_mems(const RawKey* __restrict__ key, const slamem_mem* __restrict__ raw,
-                                                      uint64_t count, const uint64_t* __restrict__ block_offsets,
-                                                      slamem_mem* __restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    RawKey kk = key[i];
-    out[block_offsets[kk.block] + kk.k] = raw[i];
-}
-
 // ------------------------------------------------------------------------------------------
 // fine-grained batch kernels (one lane per element) -- same device functions as K8
 // ------------------------------------------------------------------------------------------
@@ -1786,7 +1720,7 @@ struct SearchJob {
     const uint64_t* offsets_dev = nullptr;
     uint32_t num_queries = 0, min_len = 0, strands = 1;
     uint64_t query_bytes = 0, mems_capacity = 0, workspace_bytes = 0, num_blocks = 0, nitems = 0, total = 0;
-    int both_strands = 0, match_type = 0, kernel_version = 3;
+    int both_strands = 0, match_type = 0;
     slamem_mem* mems_dev = nullptr;
     uint64_t* block_offsets_dev = nullptr;
     void* workspace_dev = nullptr;
@@ -1841,9 +1775,6 @@ int SearchJob::init(const slamem_index* idx_, const void* queries_dev_, const ui
                   (unsigned long long)workspace_bytes, (unsigned long long)w.bytes);
         return SLAMEM_ERR_ARG;
     }
-    static const int env_kernel_version = [] { const char* v = getenv("SLAMEM_SEARCH_KERNEL"); return v ? atoi(v) : 3; }();
-    // MAM mode scans with k_find_mams_sliced (one lane per slice of a strand); its MAMs leave through the v3 output path
-    kernel_version = match_type == 1 ? 1 : env_kernel_version;
     want_stats = search_stats_wanted();
     for (int i = 0; i < 5; i++)
         if (!ev[i]) SLAMEM_HIP(hipEventCreate(&ev[i]));
@@ -1866,16 +1797,16 @@ int SearchJob::tables(hipStream_t stream) {
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
     STEP(hipMemsetAsync(d_total, 0, 64 + SC_COUNT * 8, stream), "memset");
     if (want_stats) STEP(hipMemsetAsync(d_total + 8 + SC_T_FIRST, 0xFF, 16, stream), "memset");  // the two minima
-    // ---- work items: one per strand, long records cut into slices (v1 scans whole strands) ----------------
+    // ---- work items: one per strand, long records cut into slices ----------------------------------------------
     uint32_t* d_wps = reinterpret_cast<uint32_t*>(ws + w.off_wps);
     uint64_t* d_wscan = reinterpret_cast<uint64_t*>(ws + w.off_wscan);
     hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
-                       num_queries, (kernel_version == 3 || (match_type == 1 && !mam_whole_strands())) ? kSliceLen : 0u, d_cnt, d_wps);
+                       num_queries, (match_type == 1 && mam_whole_strands()) ? 0u : kSliceLen, d_cnt, d_wps);
     STEP(hipGetLastError(), "k_item_counts");
     STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
     uint32_t slices = 0;
     STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
-    if (kernel_version == 3) {  // packed strands: offsets of the strand blocks
+    if (match_type != 1) {  // packed strands: offsets of the strand blocks
         size_t need3 = w.scan_bytes;
         STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need3, d_wps, d_wscan, (uint64_t)num_queries, stream), "scan");
     }
@@ -1901,9 +1832,7 @@ int SearchJob::tables(hipStream_t stream) {
     A.item_attempt = reinterpret_cast<uint8_t*>(ws + w.off_attempt);
     A.query_words = (query_bytes + 7) / 8;
     A.stats = d_total + 8;  // behind the 64 bytes of scalars
-    A.spec_depth = -1;
-    A.chunk = kChunkMax;
-    if (nitems && kernel_version == 3) {
+    if (nitems && match_type != 1) {
         uint64_t* d_itempk = reinterpret_cast<uint64_t*>(ws + w.off_itempk);
         uint64_t* d_pq = reinterpret_cast<uint64_t*>(ws + w.off_pq);
         hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
@@ -1951,7 +1880,7 @@ int SearchJob::launch(hipStream_t stream) {
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
     prefiltered = false; timed_k8 = false; launched = true;
     (void)hipEventRecord(ev[0], stream);
-    if (nitems && kernel_version == 3) {
+    if (nitems && match_type != 1) {
         static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
         if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
             uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
@@ -2002,8 +1931,7 @@ int SearchJob::launch(hipStream_t stream) {
             else hipLaunchKernelGGL((k_find_mems_v3<false, false, false>), grid8, dim3(256), 0, stream, A);
         }
         STEP(hipGetLastError(), "k_find_mems_v3");
-    } else if (nitems && match_type == 1) {
-        A.rows_out = 1;  // K9 of the v3 path places the MAMs and resolves their rows
+    } else if (nitems) {  // -mam: K9 of the v3 path places the MAMs and resolves their rows
         STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
         static const uint32_t env_warm = [] { const char* v = getenv("SLAMEM_MAM_WARMUP"); return v && atoi(v) > 0 ? (uint32_t)atoi(v) : kWarmUp; }();
         static const bool env_trace = getenv("SLAMEM_MAM_TRACE") != nullptr;
@@ -2047,9 +1975,6 @@ int SearchJob::launch(hipStream_t stream) {
                 fprintf(stderr, "[mam] %llu slices of %llu strands, warm-up %u: %llu scanned again in %llu passes\n", (unsigned long long)nitems,
                         (unsigned long long)num_blocks, env_warm, (unsigned long long)reruns, (unsigned long long)passes);
         }
-    } else if (nitems) {
-        hipLaunchKernelGGL(k_find_mems, dim3(grid_for(num_blocks)), dim3(256), 0, stream, A);
-        STEP(hipGetLastError(), "k_find_mems");
     }
     (void)hipEventRecord(ev[1], stream);
     return SLAMEM_OK;
@@ -2104,7 +2029,7 @@ int SearchJob::finish(hipStream_t stream) {
         o.survivors = prefiltered ? nwork : nitems;
         o.mems = total;
         o.overflow_records = listed;
-        o.valid = kernel_version == 3 ? 1 : 0;
+        o.valid = match_type != 1 ? 1 : 0;
     }
     if (total > mems_capacity || listed > mems_capacity) {
         // the atomic list also holds the records of abandoned slice attempts: ask for room for those too
@@ -2113,21 +2038,15 @@ int SearchJob::finish(hipStream_t stream) {
                   (unsigned long long)mems_capacity);
         return SLAMEM_ERR_CAPACITY;
     }
-    if (kernel_version == 3 || match_type == 1) {
-        if (total) {
-            hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
-                               d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);
-            STEP(hipGetLastError(), "k_place_inline");
-        }
-        if (listed) {
-            hipLaunchKernelGGL(k_place_overflow, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                               (uint64_t)listed, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev);
-            STEP(hipGetLastError(), "k_place_overflow");
-        }
-    } else if (listed) {
-        hipLaunchKernelGGL(k_scatter_mems, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                           (uint64_t)listed, d_itemoff, mems_dev);
-        STEP(hipGetLastError(), "k_scatter_mems");
+    if (total) {
+        hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
+                           d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);
+        STEP(hipGetLastError(), "k_place_inline");
+    }
+    if (listed) {
+        hipLaunchKernelGGL(k_place_overflow, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
+                           (uint64_t)listed, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev);
+        STEP(hipGetLastError(), "k_place_overflow");
     }
     (void)hipEventRecord(ev[2], stream);
     STEP(hipStreamSynchronize(stream), "K9 (sync)");
