@@ -117,9 +117,6 @@ typedef struct {
     uint64_t skip_probe_lines;      /* K8 skipping: words of the k-mer occurrence bitmap read                          */
     uint64_t skip_attempts;         /* K8 skipping: diagonals verified (probes follow)                                 */
     uint64_t skips;                 /* K8 skipping: stretches skipped (min_len positions each)                         */
-    uint64_t mig_moved;             /* K8 migration: lanes handed to the wave of their state family                     */
-    uint64_t mig_blocked;           /* K8 migration: attempts that found the mailbox full (the lane went on in place)   */
-    uint64_t mig_foreign_trips;     /* K8 migration: lane trips executed in a wave of the other family                  */
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

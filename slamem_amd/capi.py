@@ -76,8 +76,7 @@ class SearchStats(C.Structure):
         "fm_lines_top", "fm_lines_bottom", "rec_lines_fail", "rec_lines_pend", "rec_lines_flush", "query_loads",
         "lane_trips", "wave_trips", "positions", "enum_jobs", "prefilter_probes", "prefilter_query_loads",
         "prefilter_items", "items", "survivors", "mems", "overflow_records", "valid", "dir_sa_lines", "dir_group_loads",
-        "dir_rec_lines", "dir_letters", "jump_lines", "skip_group_loads", "skip_probe_lines", "skip_attempts", "skips", "mig_moved",
-        "mig_blocked", "mig_foreign_trips")]
+        "dir_rec_lines", "dir_letters", "jump_lines", "skip_group_loads", "skip_probe_lines", "skip_attempts", "skips")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -771,13 +771,16 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         }
     }
     {   // k-mer occurrence bitmap: k = ceil(log4 n) + 2 (at most 16: the value fits 32 bits, the bitmap 512 MB), only while
-        // fewer than a tenth of all k-mers occur -- a denser bitmap proves nothing absent; SLAMEM_KBITS=0 builds without
+        // fewer than a tenth of all k-mers occur -- a denser bitmap proves nothing absent.  Only the skipping states of K8
+        // read it, and they are not the default: built when SLAMEM_SKIP=1 (or SLAMEM_KBITS=1) is set
         const char* kb = getenv("SLAMEM_KBITS");
+        const char* sk = getenv("SLAMEM_SKIP");
+        const bool want_kbits = (kb && atoi(kb) != 0) || (!kb && sk && atoi(sk) != 0);
         uint32_t k = 2;
         for (uint64_t v = 1; v < (uint64_t)n; v <<= 2) k++;
         if (k < 8) k = 8;
         if (k > 16) k = 16;
-        if (!(kb && atoi(kb) == 0) && n >= k && (uint64_t)n * 10ull <= (1ull << (2u * k))) {
+        if (want_kbits && n >= k && (uint64_t)n * 10ull <= (1ull << (2u * k))) {
             hdr.kbits_k = k;
             hdr.off_kbits = off; off = align_up(off + ((1ull << (2u * k)) >> 3), 256);
         }

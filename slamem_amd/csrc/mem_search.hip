@@ -624,7 +624,7 @@ enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
     SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
-    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_MIG_MOVED, SC_MIG_BLOCKED, SC_MIG_FOREIGN, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_COUNT
+    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -777,20 +777,8 @@ enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, 
 // exact, 27 % fewer lines and 32 % fewer lane trips, but the same time -- the kernel is bound by instruction issue and
 // every trip pays for the union of the states its lanes are in -- so the default kernel is the one without them
 // (SLAMEM_SKIP=1 selects this one).
-// kMig: lanes MIGRATE between the waves of a block so that a wave mostly holds lanes of one state family -- waves 0-2 the
-// index walk (EXT / REC / FLUSH / JQ / JT), wave 3 the text-side states (DSA / DIR / DEND / SKV / SKQ / SKP).  Every wave can
-// still execute every state (a lane whose mailbox is full simply goes on where it is: migration is a hint, never a
-// condition), but a state block whose lanes are all elsewhere is skipped by the hardware (s_cbranch_execz), so a trip
-// executes about half the instructions.  Mailboxes: six rings of 32 records (64 B) in LDS, each written by one wave and read
-// by one wave (index wave w -> wave 3: box w; wave 3 -> index wave w: box 3+w), counters with release / acquire at workgroup
-// scope.  Waves of a block leave together: when the three index waves have seen the end of the work list and the block holds
-// no unfinished strand.
-constexpr uint32_t kBoxCap = 32;
-struct __attribute__((aligned(16))) MigRec { uint4 q[4]; };
-template <bool kStats, bool kSkip, bool kMig>
+template <bool kStats, bool kSkip>
 __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
-    __shared__ MigRec mig_rec[kMig ? 6 : 1][kMig ? kBoxCap : 1];
-    __shared__ uint32_t mig_wr[6], mig_rd[6], blk_live, blk_drained;
     __shared__ ItemDesc lds_item[4][kFetch];
     __shared__ uint64_t lds_pk[4][kFetch];
     __shared__ uint32_t lds_id[4][kFetch];
@@ -806,14 +794,8 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t next = 0, chunk_first = 0, chunk_end = 0;  // wave-uniform: the piece being handed out
     uint32_t seen = 0;                                  // wave-uniform: how far this wave has seen the cursor get
-    const uint32_t nwaves = kMig ? gridDim.x * 3u : gridDim.x * (blockDim.x >> 6);  // waves that take work from the list
-    const bool text_wave = kMig && wv == 3u;            // this wave's family: the text-side states
-    bool drained = text_wave;                           // wave-uniform: the cursor is past the end of the list (or never read)
-    if (kMig) {
-        if (threadIdx.x < 6u) { mig_wr[threadIdx.x] = 0; mig_rd[threadIdx.x] = 0; }
-        if (threadIdx.x == 6u) { blk_live = 0; blk_drained = 0; }
-        __syncthreads();
-    }
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);  // waves that take work from the list
+    bool drained = false;                               // wave-uniform: the cursor is past the end of the list
     // direct extension: the class threshold of this launch (flag <=> class >= cL; a parent depth >= L implies it)
     const int dmin = A.direct_min_depth;  // < 0: off
     const uint32_t cL = depth_class(L);
@@ -833,15 +815,13 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
     if (kStats && (threadIdx.x & 63u) == 0u) atomicMin(A.stats + SC_T_FIRST, t_wave0);
     uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_wtrips = 0, n_pos = 0,
              n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0, n_jump = 0, n_skv = 0, n_skq = 0,
-             n_skp = 0, n_skok = 0, n_mig = 0, n_migblk = 0, n_foreign = 0;
+             n_skp = 0, n_skok = 0;
 
     bool active = false, pend = false, dmis = false, dcool = false;
     uint32_t st = ST_EXT;
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
     uint32_t a_pos = 0, b_pos = 0, attempt = 0, qlen = 0;  // emitted slice [a_pos, b_pos) of the strand, warm-up attempt
     uint32_t dir_r = 0;  // direct extension: text position where the current match starts
-    uint32_t mig_wait = 0;  // migration: trips this lane has waited for room in its mailbox
-    constexpr uint32_t kPatience = 0;  // (waiting was measured: 16 trips of patience doubled the kernel time -- the text wave is the bottleneck)
     int depth = 0, pub = -1;
     PackedCursor qc;
     qc.init(A.pq);
@@ -854,32 +834,6 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
     for (;;) {
         // ---- hand the next items to idle lanes ----------------------------------------------------------------
         unsigned long long idle = __ballot(!active);
-        if (kMig && idle != 0ull) {  // lanes that other waves sent here come first
-            for (uint32_t bi = 0; bi < (text_wave ? 3u : 1u); bi++) {
-                const uint32_t b = text_wave ? bi : 3u + wv;
-                const uint32_t rd = mig_rd[b];  // (only this wave writes it)
-                const uint32_t avail = __hip_atomic_load(&mig_wr[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - rd;
-                if (avail == 0u || idle == 0ull) continue;
-                const uint32_t nidle = (uint32_t)__popcll(idle);
-                const uint32_t n = avail < nidle ? avail : nidle;
-                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (!active && rank < n) {
-                    const MigRec& r = mig_rec[b][(rd + rank) & (kBoxCap - 1u)];
-                    const uint4 q0 = r.q[0], q1 = r.q[1], q2 = r.q[2], q3 = r.q[3];
-                    g = q0.x; j = q0.y; top = q0.z; bot = q0.w;
-                    k = q1.x; a_pos = q1.y; b_pos = q1.z; qlen = q1.w;
-                    dir_r = q2.x; depth = (int)q2.y; pub = (int)q2.z;
-                    st = q2.w & 0xFFu; attempt = (q2.w >> 8) & 0xFFu;
-                    pend = (q2.w >> 16) & 1u; dmis = (q2.w >> 17) & 1u; dcool = (q2.w >> 18) & 1u;
-                    qc.init(A.pq + q3.x);
-                    tag_t = 0xFFFFFFFFu;
-                    active = true;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the records are read before the slots are given back
-                if (lane == 0u) __hip_atomic_store(&mig_rd[b], rd + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                idle = __ballot(!active);
-            }
-        }
         if (idle != 0ull && next >= chunk_end && !drained) {  // fetch the next piece of the work list
             // guided self-scheduling: pieces of kFetch items while the list is long, smaller ones (down to 8) towards its
             // end -- the items a wave has fetched but not yet started are captive to it, and at the end of the list they
@@ -892,12 +846,10 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
             if (base >= nitems) {
                 drained = true;
                 if (kStats && lane == 0u) atomicMin(A.stats + SC_T_DRAIN, (unsigned long long)wall_clock64());
-                if (kMig && lane == 0u) atomicAdd(&blk_drained, 1u);
             } else {
                 chunk_first = next = base;
                 chunk_end = nitems - base < want ? nitems : base + want;
                 seen = chunk_end;
-                if (kMig && lane == 0u) atomicAdd(&blk_live, chunk_end - chunk_first);  // strands this block now owes
                 const uint32_t i = chunk_first + lane;
                 if (i < chunk_end) {  // descriptors -> LDS: one coalesced read per wave instead of a round trip per item
                     uint32_t id = A.work_ids ? A.work_ids[i] : (uint32_t)i;
@@ -931,40 +883,22 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
                 if (d.len == 0) {  // empty record: nothing to scan
                     A.block_counts[g] = 0;
                     A.item_attempt[g] = 0;
-                    if (kMig) atomicSub(&blk_live, 1u);
                 } else active = true;
             }
             next += (uint32_t)__popcll(idle);
             // the LDS slots are reused by the next fetch: every lane has copied its descriptor by then (same wave, in order)
         }
         if (__ballot(active) == 0ull) {
-            if (kMig) {  // the block leaves together: nothing more can arrive once every strand it took is finished
-                if (drained && next >= chunk_end &&
-                    __hip_atomic_load(&blk_drained, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u &&
-                    __hip_atomic_load(&blk_live, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
-                __builtin_amdgcn_s_sleep(4);
-                continue;
-            }
             if (drained && next >= chunk_end) break;
             continue;
         }
         if (kStats) n_wtrips += lane == 0u;
-        // a lane of the other family waits for room in its mailbox (it does nothing this trip) -- up to kPatience trips, then
-        // it goes on where it is: no wave ever depends on another one making progress
-        bool hold = false;
-        if (kMig) {
-            const bool foreign = active && (((st >= ST_DSA && st <= ST_DEND) || st >= ST_SKV) != text_wave) && st != ST_SKP;
-            hold = foreign && mig_wait < kPatience;
-            if (!foreign || mig_wait >= kPatience) mig_wait = 0;
-            if (kStats && active && foreign && !hold) n_foreign++;
-        }
-
         // enumeration job of this trip (rare): rows that the lane does not emit itself
         bool e_on = false, e_level0 = false, e_up = false;
         uint32_t e_pos = 0, e_left = 0;
         bool consumed = false, finished = false;
 
-        if (active && !hold) {
+        if (active) {
             // ---- memory phase: every load of this trip, no use in between -------------------------------------
             // two generic 16-byte slots, addressed by state: the row records of `top` and `bot`; or the suffix-array
             // quad of `top`; or a text group and the query words that face it; or the text-ordered record
@@ -1334,37 +1268,6 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
             A.item_attempt[g] = (uint8_t)attempt;
             active = false;
         }
-        if (kMig) {
-            const unsigned long long fin = __ballot(finished);
-            if (fin != 0ull && lane == 0u) atomicSub(&blk_live, (uint32_t)__popcll(fin));
-            // lanes whose next state belongs to the other family move there, if their mailbox has room
-            const bool text_state = (st >= ST_DSA && st <= ST_DEND) || st >= ST_SKV;
-            // (not between SKQ and SKP: the lane's 2-bit words wait in this thread's LDS slot)
-            const bool want = active && text_state != text_wave && st != ST_SKP;
-            for (uint32_t bi = 0; bi < (text_wave ? 3u : 1u); bi++) {
-                const uint32_t b = text_wave ? 3u + bi : wv;
-                const bool mine = want && (!text_wave || g % 3u == bi);
-                const unsigned long long m = __ballot(mine);
-                if (m == 0ull) continue;
-                const uint32_t wr = mig_wr[b];  // (only this wave writes it)
-                const uint32_t room = kBoxCap - (wr - __hip_atomic_load(&mig_rd[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (kStats && mine) { if (rank < room) n_mig++; else n_migblk++; }
-                if (mine && rank >= room) mig_wait++;
-                if (mine && rank < room) {
-                    MigRec& r = mig_rec[b][(wr + rank) & (kBoxCap - 1u)];
-                    r.q[0] = make_uint4(g, j, top, bot);
-                    r.q[1] = make_uint4(k, a_pos, b_pos, qlen);
-                    r.q[2] = make_uint4(dir_r, (uint32_t)depth, (uint32_t)pub,
-                                        st | (attempt << 8) | ((uint32_t)pend << 16) | ((uint32_t)dmis << 17) | ((uint32_t)dcool << 18));
-                    r.q[3] = make_uint4((uint32_t)(reinterpret_cast<const uint64_t*>(qc.p) - A.pq), 0u, 0u, 0u);
-                    active = false;
-                }
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0u) __hip_atomic_store(&mig_wr[b], wr + (cnt < room ? cnt : room), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
         if (kStats) n_enum += e_on;
     }
     if (kStats) {
@@ -1378,8 +1281,6 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
         stat_flush<kStats>(A.stats + SC_JUMP_LINES, n_jump);
         stat_flush<kStats>(A.stats + SC_SKIP_GROUPS, n_skv); stat_flush<kStats>(A.stats + SC_SKIP_QLOADS, n_skq);
         stat_flush<kStats>(A.stats + SC_SKIP_PROBES, n_skp); stat_flush<kStats>(A.stats + SC_SKIP_OK, n_skok);
-        stat_flush<kStats>(A.stats + SC_MIG_MOVED, n_mig); stat_flush<kStats>(A.stats + SC_MIG_BLOCKED, n_migblk);
-        stat_flush<kStats>(A.stats + SC_MIG_FOREIGN, n_foreign);
         if ((threadIdx.x & 63u) == 0u) {
             const unsigned long long t1 = wall_clock64();
             atomicMax(A.stats + SC_T_LAST, t1);
@@ -1919,16 +1820,12 @@ int SearchJob::launch(hipStream_t stream) {
         (void)hipEventRecord(ev[4], stream);
         timed_k8 = true;
         const dim3 grid8(grid_for(waves * 64));
-        static const bool env_mig = [] { const char* v = getenv("SLAMEM_MIGRATE"); return v && atoi(v) != 0; }();
-        if (A.skip_w && env_mig) {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, true>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, true, true>), grid8, dim3(256), 0, stream, A);
-        } else if (A.skip_w) {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, false>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, true, false>), grid8, dim3(256), 0, stream, A);
+        if (A.skip_w) {
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, true>), grid8, dim3(256), 0, stream, A);
         } else {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false>), grid8, dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false>), grid8, dim3(256), 0, stream, A);
         }
         STEP(hipGetLastError(), "k_find_mems_v3");
     } else if (nitems) {  // -mam: K9 of the v3 path places the MAMs and resolves their rows
@@ -2019,7 +1916,6 @@ int SearchJob::finish(hipStream_t stream) {
         o.dir_letters = c[SC_DIR_LETTERS]; o.jump_lines = c[SC_JUMP_LINES];
         o.skip_group_loads = c[SC_SKIP_GROUPS]; o.skip_probe_lines = c[SC_SKIP_PROBES]; o.skips = c[SC_SKIP_OK];
         o.skip_attempts = c[SC_SKIP_QLOADS];
-        o.mig_moved = c[SC_MIG_MOVED]; o.mig_blocked = c[SC_MIG_BLOCKED]; o.mig_foreign_trips = c[SC_MIG_FOREIGN];
         // 100 MHz clock -> microseconds
         last_search_clock()[0] = (c[SC_T_DRAIN] - c[SC_T_FIRST]) / 100.0;
         last_search_clock()[1] = (c[SC_T_LAST] - c[SC_T_DRAIN]) / 100.0;
