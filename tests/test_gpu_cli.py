@@ -54,6 +54,24 @@ def test_cli_overlapped_loading_changes_nothing(case, tmp_path):
     assert _stable_stdout(r.stdout) == _stable_stdout(plain.stdout)
 
 
+@pytest.mark.parametrize("overlap", ["-1", "0"])
+def test_cli_without_a_valid_query_record(overlap, tmp_path):
+    """slamem.c:648: "No query files provided" when no query record could be loaded -- also when the run only finds out
+    after it has started (queries parsed beside the search): status 255, no output file left behind."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    ref_fa, _, _, _ = case_paths("acgt_l20_both")
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b"this is not FASTA\nACGT\n")
+    out = tmp_path / "o.txt"
+    r = subprocess.run([exe, "-o", str(out), ref_fa, str(bad)], stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_OVERLAP_MB=overlap))
+    assert r.returncode == 255
+    assert b"> ERROR: No query files provided" in r.stdout and b"successfully loaded" not in r.stdout
+    assert not out.exists()
+
+
 def test_cli_default_output_name_and_batches(tmp_path):
     import shutil
     import torch

@@ -113,6 +113,29 @@ def test_cli_fails_loudly_without_gpu(tmp_path):
     ref_fa, q_fa, _, _ = case_paths("acgt_l20_fwd")
     r = subprocess.run([exe, "-o", str(tmp_path / "o.txt"), ref_fa, q_fa], stdout=subprocess.PIPE)
     assert r.returncode == 255 and b"no CPU" in r.stdout
+    # the same through one process (the default runs the work in a forked worker and passes its status on)
+    r1 = subprocess.run([exe, "-o", str(tmp_path / "o.txt"), ref_fa, q_fa], stdout=subprocess.PIPE,
+                        env=dict(os.environ, SLAMEM_FOREGROUND="1"))
+    assert r1.returncode == 255 and r1.stdout == r.stdout
+
+
+@pytest.mark.parametrize("env", [{}, {"SLAMEM_FOREGROUND": "1"}, {"SLAMEM_OVERLAP_MB": "0"}], ids=["worker", "one_process", "overlapped"])
+def test_cli_error_exits_keep_the_reference_messages_and_status(env, tmp_path):
+    """Error paths that end before any GPU work (tools.c:21-25 exit(-1) -> status 255), through the forked worker, in one
+    process, and with the loader thread: same text on stdout, same status, nothing left hanging."""
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", hostlib.HOST_DIR], stdout=subprocess.DEVNULL)
+    ref_fa, q_fa, _, _ = case_paths("acgt_l20_fwd")
+    e = dict(os.environ, **env)
+    r = subprocess.run([exe, str(tmp_path / "missing.fa"), q_fa], stdout=subprocess.PIPE, env=e, timeout=60)
+    assert r.returncode == 255 and b"> ERROR: No valid sequences found in reference file" in r.stdout
+    r = subprocess.run([exe, ref_fa], stdout=subprocess.PIPE, env=e, timeout=60)
+    assert r.returncode == 255 and b"Usage:" in r.stdout                      # argc < 3
+    r = subprocess.run([exe, "-l", "20", ref_fa], stdout=subprocess.PIPE, env=e, timeout=60)
+    assert r.returncode == 255 and b"> ERROR: Not enough input sequence files provided" in r.stdout
+    r = subprocess.run([exe, "-r", ref_fa, q_fa], stdout=subprocess.PIPE, env=e, timeout=60)
+    assert r.returncode == 255
 
 
 def test_parallel_loader_equals_sequential(tmp_path):
