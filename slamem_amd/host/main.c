@@ -61,6 +61,7 @@ typedef struct {
     pthread_cond_t cv;
     int ready, done, total_queries;
     int release_early; /* footprint before speed: see main */
+    int failed;        /* more pieces than main made room for */
     double seconds;
 } loader_t;
 
@@ -82,6 +83,9 @@ static void *loader_run(void *arg) {
                 ld->sets[ld->ready++] = s;
                 ld->total_queries += n;
                 ld->numbering += n;
+            } else { /* cannot happen (a piece is at least piece_bytes of its file): never drop reads silently */
+                ld->failed = 1;
+                slh_free_seqset(&s);
             }
             pthread_cond_broadcast(&ld->cv);
             pthread_mutex_unlock(&ld->mu);
@@ -782,6 +786,7 @@ int main(int argc, char **argv) {
         free(ranges);
         release_stdout(); /* the loader is done: the "successfully loaded" line, then what was held back */
         total_queries = ld->total_queries;
+        if (ld->failed) pipeline_fail("Internal error: the query files came in more pieces than planned");
         if (ld->ready == 0) { /* slamem.c:648 (an overlapped run only knows it now) */
             shutdown_pipeline();
             fclose(out);
