@@ -168,11 +168,12 @@ typedef struct {
 /* Text buffers go round: formatter -> writer -> pool -> formatter.  A fresh 20 MB buffer costs its page faults every
  * time (the output of the reference-sized run is 638 MB); a recycled one is already mapped. */
 static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
-static slh_buffer g_pool[64];
+static slh_buffer g_pool[256];
 static int g_pool_n = 0;
+static long g_pool_hits = 0, g_pool_misses = 0; /* (SLAMEM_TIMING) */
 static void pool_put(slh_buffer *b) {
     pthread_mutex_lock(&g_pool_mu);
-    if (b->data && g_pool_n < 64) { b->len = 0; g_pool[g_pool_n++] = *b; b->data = NULL; }
+    if (b->data && g_pool_n < 256) { b->len = 0; g_pool[g_pool_n++] = *b; b->data = NULL; }
     pthread_mutex_unlock(&g_pool_mu);
     if (b->data) slh_buffer_free(b);
     b->data = NULL; b->len = b->cap = 0;
@@ -182,7 +183,8 @@ static void pool_get(slh_buffer *b, size_t need) {
     pthread_mutex_lock(&g_pool_mu);
     for (i = 0; i < g_pool_n; i++)
         if (g_pool[i].cap >= need && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
-    if (best >= 0) { *b = g_pool[best]; g_pool[best] = g_pool[--g_pool_n]; }
+    if (best >= 0) { *b = g_pool[best]; g_pool[best] = g_pool[--g_pool_n]; g_pool_hits++; }
+    else g_pool_misses++;
     pthread_mutex_unlock(&g_pool_mu);
 }
 
@@ -818,8 +820,9 @@ int main(int argc, char **argv) {
     if (timing)
         fprintf(stderr, "[timing] load %.3f s%s (index build of %.3f s overlapped; %.3f s more waiting for it), pipeline set-up %.3f s, "
                         "waiting for the GPU (upload + search + download, overlapped with formatting) %.3f s, format %.3f s "
-                        "(writer thread busy %.3f s, overlapped), close %.3f s, total %.3f s\n",
-                t_load, overlap_note, t_build, t_join, t_streams, t_gpu, t_format, t_write, t_end1 - t_end0, now_s() - t_start);
+                        "(writer thread busy %.3f s, overlapped; text buffers: %ld recycled, %ld fresh), close %.3f s, total %.3f s\n",
+                t_load, overlap_note, t_build, t_join, t_streams, t_gpu, t_format, t_write, g_pool_hits, g_pool_misses, t_end1 - t_end0,
+                now_s() - t_start);
     fflush(stdout);
     fflush(stderr);
     if (getenv("SLAMEM_FULL_TEARDOWN") == NULL) {

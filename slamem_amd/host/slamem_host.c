@@ -693,12 +693,24 @@ static int buf_reserve(slh_buffer *b, size_t extra) {
 
 int slh_buffer_reserve(slh_buffer *b, size_t bytes) { return buf_reserve(b, bytes); }
 
+/* decimal digits, two at a time (24 M lines of three numbers each per 10 M reads: the formatter is the front end's
+ * longest stage once the search is on the GPU) */
+static const char DIGIT_PAIRS[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+
 static inline char *put_u32(char *p, uint32_t v) {
     char tmp[10];
-    int n = 0;
-    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) *p++ = tmp[--n];
-    return p;
+    int n = 10;
+    while (v >= 100) {
+        uint32_t q = v / 100, r = v - q * 100;
+        n -= 2;
+        memcpy(tmp + n, DIGIT_PAIRS + 2 * r, 2);
+        v = q;
+    }
+    if (v >= 10) { n -= 2; memcpy(tmp + n, DIGIT_PAIRS + 2 * v, 2); }
+    else tmp[--n] = (char)('0' + v);
+    memcpy(p, tmp + n, (size_t)(10 - n));
+    return p + (10 - n);
 }
 
 int slh_format_block(slh_buffer *buf, const char *query_name, int reverse, const uint32_t *mems, uint64_t count,
@@ -706,32 +718,43 @@ int slh_format_block(slh_buffer *buf, const char *query_name, int reverse, const
     size_t nl = strlen(query_name);
     uint64_t i, sum = 0;
     char *p;
-    if (buf_reserve(buf, nl + 16)) return -1;
+    /* room for the whole block at once when its lines have a known bound (one reference record: three numbers of at
+       most ten digits, two tabs, a newline) */
+    if (buf_reserve(buf, nl + 16 + (num_refs == 1 ? (size_t)count * 33 : 0))) return -1;
     p = buf->data + buf->len;
     *p++ = '>';
     memcpy(p, query_name, nl);
     p += nl;
     if (reverse) { memcpy(p, " Reverse", 8); p += 8; } /* slamem.c:102 */
     *p++ = '\n';
-    buf->len = (size_t)(p - buf->data);
-    for (i = 0; i < count; i++) {
-        uint32_t rp = mems[3 * i], qp = mems[3 * i + 1], ln = mems[3 * i + 2];
-        size_t namelen = 0;
-        const char *rname = NULL;
-        if (num_refs != 1) { /* slamem.c:144-147 */
-            int id = slh_seq_id_from_merged_pos(merged_start, num_refs, &rp);
-            rname = refs[id].name;
-            namelen = strlen(rname);
+    if (num_refs == 1) { /* slamem.c:148 */
+        for (i = 0; i < count; i++) {
+            const uint32_t ln = mems[3 * i + 2];
+            p = put_u32(p, mems[3 * i] + 1);
+            *p++ = '\t';
+            p = put_u32(p, mems[3 * i + 1] + 1);
+            *p++ = '\t';
+            p = put_u32(p, ln);
+            *p++ = '\n';
+            sum += ln;
         }
+        buf->len = (size_t)(p - buf->data);
+        if (sum_len_out) *sum_len_out = sum;
+        return 0;
+    }
+    buf->len = (size_t)(p - buf->data);
+    for (i = 0; i < count; i++) { /* slamem.c:144-148: several reference records, every line names its record */
+        uint32_t rp = mems[3 * i], qp = mems[3 * i + 1], ln = mems[3 * i + 2];
+        int id = slh_seq_id_from_merged_pos(merged_start, num_refs, &rp);
+        const char *rname = refs[id].name;
+        size_t namelen = strlen(rname);
         if (buf_reserve(buf, namelen + 48)) return -1;
         p = buf->data + buf->len;
-        if (rname) {
-            *p++ = ' ';
-            memcpy(p, rname, namelen);
-            p += namelen;
-            *p++ = '\t';
-        }
-        p = put_u32(p, rp + 1); /* slamem.c:148 */
+        *p++ = ' ';
+        memcpy(p, rname, namelen);
+        p += namelen;
+        *p++ = '\t';
+        p = put_u32(p, rp + 1);
         *p++ = '\t';
         p = put_u32(p, qp + 1);
         *p++ = '\t';

@@ -232,3 +232,16 @@ def test_pieces_loader_equals_whole_file_loader(tmp_path):
         L.slh_pieces_close(h)
         assert npieces >= 4
         assert names == whole.names and sizes == whole.sizes and b"".join(chars) == whole.chars
+
+
+def test_formatter_numbers_of_every_width(tmp_path):
+    """slamem.c:148 prints "%d\\t%d\\t%d\\n" of 1-based positions: every digit count from 1 to 10, the pair-table edges."""
+    ref_fa = tmp_path / "r.fa"
+    ref_fa.write_bytes(b">r\nACGT\n")
+    ref = hostlib.Loaded(str(ref_fa), 1)
+    vals = [0, 8, 9, 10, 98, 99, 100, 101, 999, 1000, 9999, 10000, 99999, 100000, 999999, 1000000, 9999999, 10000000,
+            99999999, 100000000, 999999999, 1000000000, 2147483647, 4294967294]
+    mems = np.array([(v, vals[-1 - i], (v % 1000003) + 1) for i, v in enumerate(vals)], dtype=np.uint32)
+    got = hostlib.format_block(b"q name", 1, mems, ref)
+    want = b">q name Reverse\n" + b"".join(b"%d\t%d\t%d\n" % (int(a) + 1, int(b) + 1, int(c)) for a, b, c in mems)
+    assert got == want
