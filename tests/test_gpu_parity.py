@@ -313,6 +313,37 @@ def test_stream_host_to_host_matches_device_path(eng):
     idx.close()
 
 
+def test_stream_slots_grow_with_the_batches(eng):
+    """slamem_stream_create's sizes are a reservation, not a limit: a stream set up for 4 records of 1 kB takes batches that
+    grow from 3 to 600 records (and a 30 kB record among 100-letter reads), from pageable memory, with empty records and an
+    empty batch in between; every batch equals the oracle in order."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(808)
+    text = rand_text(rng, 80000, "ACGT", 30, max_rep=400)
+    t = np.frombuffer(text, dtype=np.uint8)
+    qs = make_queries(rng, text, 1200, "ACGT")
+    qs[700] = t[20000:50000].tobytes()  # a record that is cut into slices
+    qs[5] = b""
+    qs[650] = b""
+    q, off = pack(qs)
+    idx = eng.Index.build(text)
+    o = po.OracleIndex(bytes(text))
+    st = eng.Stream(idx, 3, 1024, 4, True)
+    bounds = [0, 3, 3, 10, 60, 300, 900, 1200]  # (an empty batch: 3..3)
+    qa = np.array(q)  # pageable
+    for b in range(len(bounds) - 1):
+        w = off[bounds[b]: bounds[b + 1] + 1]
+        st.submit(qa, w, 12)
+        m, boff, _ = st.next()
+        sub = q[int(w[0]): int(w[-1])]
+        om, obc = o.match_batch(sub, w - w[0], 12, True)
+        assert np.array_equal(np.diff(boff.astype(np.int64)), obc.astype(np.int64)), b
+        for f in ("ref_pos", "query_pos", "length"):
+            assert np.array_equal(m[f], om[f]), (b, f)
+    st.close()
+    idx.close()
+
+
 def test_mam_long_record_matches_oracle_and_overflows_inline_slots(eng):
     """-mam on a long record (160 kbp against a 250 kbp text with repeat families): 40 verified slices per strand (the
     mode's stale fall-back interval, slamem.c:122-123,131,197-198, makes a slice depend on its past: k_find_mams_sliced),
