@@ -231,6 +231,8 @@ int slamem_char_at_bwt_pos_batch(const slamem_index *idx, const uint32_t *rows_d
  *   block_offsets_dev out: uint64[num_blocks+1]; block b owns [off[b], off[b+1])
  *   workspace_dev     scratch of slamem_find_mems_workspace_bytes() bytes
  *   total_out         number of MEMs found (also when SLAMEM_ERR_CAPACITY is returned)
+ *   limit             a strand (or a 4096-position slice of a long one) may emit fewer than 2^28 MEMs: beyond that the call
+ *                     fails with SLAMEM_ERR_ARG and says so (never wrong output)
  *
  * Synchronous with respect to the stream on return (it has to read the total). */
 int slamem_find_mems_workspace_bytes(uint32_t num_queries, int both_strands, uint64_t query_bytes,

@@ -14,7 +14,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libslamem_hip.so")
 SYNTH_PATH = os.path.join(_HERE, "csrc", "libslamem_synth.so")
 
 SLAMEM_OK = 0
+SLAMEM_ERR_ARG = 1
+SLAMEM_ERR_HIP = 2
+SLAMEM_ERR_NOMEM = 3
 SLAMEM_ERR_CAPACITY = 4
+SLAMEM_ERR_FORMAT = 5
+SLAMEM_ERR_IO = 6
 SLAMEM_ERR_NO_DEVICE = 7
 
 ARRAY_SA, ARRAY_BWT, ARRAY_LCP, ARRAY_PSV, ARRAY_NSV = range(5)

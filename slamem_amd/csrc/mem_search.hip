@@ -1898,9 +1898,10 @@ int SearchJob::finish(hipStream_t stream) {
     listed = scal[0];
     total = tot;
     if ((uint32_t)(scal[4] >> 32) != 0u) {
+        // (not SLAMEM_ERR_CAPACITY: callers answer that one by asking again with more room)
         set_error("slamem_find_mems_device: one work item emits 2^28 or more MEMs (a 4096-position slice against a highly "
                   "repetitive text with a small minimum length); raise min_len");
-        return SLAMEM_ERR_CAPACITY;
+        return SLAMEM_ERR_ARG;
     }
     if (want_stats) {
         unsigned long long c[SC_COUNT];

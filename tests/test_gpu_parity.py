@@ -313,6 +313,31 @@ def test_stream_host_to_host_matches_device_path(eng):
     idx.close()
 
 
+def test_a_slice_with_2_to_the_28_mems_is_an_error_not_wrong_output(eng):
+    """The overflow records carry the MEM's ordinal within its work item in 28 bits.  A text of 1.4 M copies of one 20-mer,
+    each behind a different letter than the query's, and a 4095-letter query of 195 copies: 273 M MEMs from ONE slice.
+    The call must fail with SLAMEM_ERR_ARG and a message that names the limit (not SLAMEM_ERR_CAPACITY, which callers
+    answer by asking again)."""
+    from slamem_amd import capi
+    rng = np.random.default_rng(28)
+    motif = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=20)
+    copies = 1_400_000
+    text = np.empty((copies, 21), dtype=np.uint8)
+    text[:, 0] = rng.choice(np.frombuffer(b"ACT", dtype=np.uint8), size=copies)
+    text[:, 1:] = motif
+    query = np.tile(np.concatenate([np.frombuffer(b"G", dtype=np.uint8), motif]), 195)
+    assert query.shape[0] == 4095
+    idx = eng.Index.build(text.reshape(-1))
+    off = np.array([0, query.shape[0]], dtype=np.uint64)
+    with pytest.raises(capi.SlamemError) as e:
+        idx.find_mems(query, off, 20, False)
+    assert e.value.code == capi.SLAMEM_ERR_ARG and "2^28" in str(e.value)
+    # one letter fewer per copy of the query's motif: nothing reaches min_len, and the same index answers normally
+    m, boff = idx.find_mems(np.tile(np.concatenate([np.frombuffer(b"G", dtype=np.uint8), motif[:19]]), 100), np.array([0, 2000], dtype=np.uint64), 20, False)
+    assert len(m) == 0 and list(boff) == [0, 0]
+    idx.close()
+
+
 def test_stream_slots_grow_with_the_batches(eng):
     """slamem_stream_create's sizes are a reservation, not a limit: a stream set up for 4 records of 1 kB takes batches that
     grow from 3 to 600 records (and a 30 kB record among 100-letter reads), from pageable memory, with empty records and an
