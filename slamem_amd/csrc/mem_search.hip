@@ -197,6 +197,8 @@ struct SearchArgs {
     uint8_t* item_flags;        // v3: 1 = the strand holds a letter that is not A,C,G,T (or is a slice): no skipping
     uint32_t skip_s1;           // v3: stride of the probed k-mers, min_len - k + 1
     uint32_t pad4;
+    const struct SliceState* slice_state;  // v3: start states of the slices of long records (k_slice_states), or nullptr
+    const uint32_t* item_block;            //     strand block number of every item (with slice_state)
 };
 
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
@@ -205,10 +207,11 @@ constexpr uint32_t kInlineMems = 4;     // MEMs per work item stored in place; m
 constexpr uint32_t kFetch = 64;         // v3: work items a wave takes from the global cursor at a time
 
 // Work item of K8 v3 = one strand of one query record, or -- for long records (genome against genome) -- one
-// slice of kSliceLen positions of it.  A slice [a,b) is scanned from e = b + warm-up: a scan that starts at e
-// finds min(true match length, e - j) at position j (the truncation property), so position j is exact
-// whenever its match does not reach e.  If a position of the slice does reach e, the lane restarts the item with a
-// four times longer warm-up (attempt tag in the records; at attempt 7 the scan starts at the record's end).
+// slice of kSliceLen positions of it.  The strand's rightmost slice is scanned from the record's end; every other slice
+// [a,b) starts at b from the state the full scan has there, which k_slice_states works out beforehand from a warm-up of
+// kWarmUp positions (see there; -mam: k_find_mams_sliced guesses and verifies instead).  (K8 still carries the older
+// scheme -- scan from b + warm-up, restart with four times the warm-up when a match of the slice reaches the scan's
+// start, attempt tag in the records -- for a slice that comes without a state.)
 constexpr uint32_t kSliceLen = 4096;
 constexpr uint32_t kWarmUp = 1024;
 constexpr uint32_t kMaxAttempt = 7;
@@ -421,6 +424,123 @@ __global__ void __launch_bounds__(256) k_find_mams(SearchArgs A) {
     A.block_counts[g] = k;
 }
 
+// Start states of the slices of long records.  The scan of slice [a,b) needs the state the full scan has after
+// position b: the interval and length of the longest match that starts at b.  A scan started at e = b + warm-up from the
+// root finds min(true length, e - b) there (the truncation property), so (k_slice_states, a lane per slice):
+//   * an extension failed on the way (depth < e - b): the state is the full scan's;
+//   * none failed and the interval has several rows (a repeat longer than the warm-up): four times the warm-up;
+//   * none failed and the interval is ONE row: q[b..e) occurs once in the text, at r = SA[row] -- the full scan is on that
+//     row too, and its length is e - b plus the letters that agree further right, found by comparing the strand with the
+//     text itself, at most kSliceLen letters of it: by then the comparison is past the next slice's start b' = b + kSliceLen.
+// If the letters still agree there (the state is left OPEN), k_slice_chain (a lane per strand, right to left) finishes
+// it from the right neighbour's state: when that is one row on the SAME diagonal (text position - strand position), the
+// match from b is the neighbour's match from b' plus the kSliceLen letters in between.  Every slice of a genome compared
+// with itself is such a case: the chain costs one step per slice where independent comparisons would cost len^2 / 8192
+// letters (measured: 1.48 s for 4.6 Mbp).  Only when the neighbour is on another diagonal does the lane compare on.
+// K8 starts a slice at b from the stored state (no warm-up in the search kernel); -mam takes it as its guess when no
+// extension failed (k_find_mams_sliced).
+struct __attribute__((aligned(16))) SliceState {
+    uint32_t top, bot;
+    int32_t depth;
+    uint32_t flags;   // kSsValid | kSsOneRow (diag is set) | kSsNoFail (no extension failed in the warm-up) | kSsOpen
+    int64_t diag;     // one row: text position of the match - strand position (the diagonal)
+    uint32_t seen;    // open: letters of the strand from b on that are known to agree (the comparison stopped there)
+    uint32_t pad;
+};
+enum : uint32_t { kSsValid = 1u, kSsOneRow = 2u, kSsNoFail = 4u, kSsOpen = 8u };
+
+// letters that agree between the strand from position qp on and the text from position tp on, at most `limit` (letter codes
+// of K1's packed words in the text groups; past the text the code is 0, which no strand letter has)
+__device__ __forceinline__ uint32_t agree_forward(const IndexView& ix, QueryCursor& qc, uint32_t qp, uint32_t len, uint64_t tp,
+                                                  uint32_t limit) {
+    const uint32_t q0 = qp;
+    uint64_t gi = ~0ull, letters = 0;
+    while (qp < len && tp < (uint64_t)ix.n && qp - q0 < limit) {
+        if ((tp >> 4) != gi) { gi = tp >> 4; letters = ix.tgrp[gi].letters; }
+        const uint32_t tc = (uint32_t)(letters >> (60u - 4u * (uint32_t)(tp & 15u))) & 15u;
+        if (tc != qc.at(qp)) break;
+        qp++; tp++;
+    }
+    return qp - q0;
+}
+
+__global__ void __launch_bounds__(256) k_slice_states(SearchArgs A, SliceState* __restrict__ out, uint32_t warm_up) {
+    const uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= A.num_items) return;
+    const ItemDesc d = A.items[it];
+    const uint32_t len = d.len, rev = d.slice_rev >> 31, sl = d.slice_rev & 0x7FFFFFFFu;
+    const uint32_t a = sl * kSliceLen;
+    if (len - a <= kSliceLen) return;  // the strand's rightmost slice (or an unsliced strand): K8 starts at the record's end
+    const uint32_t b = a + kSliceLen;
+    const IndexView& ix = A.ix;
+    SliceState s;
+    s.top = 0; s.bot = ix.n; s.depth = 0; s.flags = 0; s.diag = 0; s.seen = 0; s.pad = 0;
+    const uint64_t x = it - 1u - A.item_block[it];  // boundary to the right of this slice (see MamPass)
+    if (A.item_alive && !A.item_alive[it]) { out[x] = s; return; }  // proven empty by the prefilter: never scanned
+    QueryCursor qc;
+    qc.init(A.qwords, d.base, len, rev);
+    uint32_t w = warm_up;
+    for (;;) {
+        const uint32_t e = (len - b <= w) ? len : b + w;
+        uint32_t top = 0, bot = ix.n;
+        int depth = 0;
+        for (uint32_t j = e; j-- > b;) {  // slamem.c:121-129
+            const uint32_t c = qc.at(j);
+            for (;;) {
+                uint32_t t = top, bb = bot;
+                if (follow(ix, c, t, bb)) { top = t; bot = bb; break; }
+                depth = parent(ix, top, bot);
+                if (depth < 0) break;
+            }
+            depth++;
+        }
+        const bool nofail = depth >= (int)(e - b);
+        if (e != len && nofail && (top != bot || !ix.tgrp)) { w = w < 0x20000000u ? w * 4u : 0xFFFFFFFFu; continue; }
+        s.flags = kSsValid | (nofail ? kSsNoFail : 0u);
+        if (top == bot && depth > 0) {
+            const uint64_t r = ix.sa[top];  // the text position that faces strand position b
+            s.flags |= kSsOneRow;
+            s.diag = (int64_t)r - (int64_t)b;
+            if (e != len && nofail) {  // the match may go on to the right of e
+                const uint32_t n = agree_forward(ix, qc, e, len, r + (e - b), kSliceLen);
+                depth += (int)n;
+                if (n == kSliceLen) { s.flags |= kSsOpen; s.seen = (uint32_t)depth; }
+            }
+        }
+        s.top = top; s.bot = bot; s.depth = depth;
+        break;
+    }
+    out[x] = s;
+}
+
+// the open states of a strand, right to left (one lane per strand: the item of its rightmost slice)
+__global__ void __launch_bounds__(256) k_slice_chain(SearchArgs A, SliceState* __restrict__ st) {
+    const uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= A.num_items) return;
+    const ItemDesc d = A.items[it];
+    const uint32_t len = d.len, rev = d.slice_rev >> 31, sl = d.slice_rev & 0x7FFFFFFFu;
+    const uint32_t cnt = len ? (len + kSliceLen - 1u) / kSliceLen : 1u;
+    if (cnt < 3u || sl != cnt - 1u) return;  // (the slice next to the rightmost one is never open: its comparison reaches the end)
+    const IndexView& ix = A.ix;
+    const uint64_t x0 = it - A.item_block[it];  // boundary between the rightmost slice and its left neighbour
+    QueryCursor qc;
+    qc.init(A.qwords, d.base, len, rev);
+    for (uint32_t k = 1; k + 1u < cnt; k++) {  // state k belongs to the slice k+1 from the right; its right neighbour's is k-1
+        SliceState s = st[x0 + k];
+        if (!(s.flags & kSsOpen)) continue;
+        const SliceState r = st[x0 + k - 1u];
+        if ((r.flags & kSsValid) && (r.flags & kSsOneRow) && !(r.flags & kSsOpen) && r.diag == s.diag) {
+            s.depth = (int)kSliceLen + r.depth;  // the neighbour's match from its b, and the letters in between
+        } else {  // (a dead or multi-row neighbour, or one whose longest match lies on another diagonal): compare on
+            const uint32_t b = (cnt - 1u - k) * kSliceLen;
+            const uint32_t qp = b + s.seen;
+            s.depth = (int)s.seen + (int)agree_forward(ix, qc, qp, len, (uint64_t)((int64_t)qp + s.diag), 0xFFFFFFFFu);
+        }
+        s.flags &= ~kSsOpen;
+        st[x0 + k] = s;
+    }
+}
+
 // -mam over SLICES of long strands (genome against genome: one lane per whole strand took 9.8 s for a 4.6 Mbp pair).
 // The scan's state between two positions is (top, bot, prev_top, prev_bot, depth) -- with the reference's stale fall-back
 // interval there is no property that tells when a scan started further right has the same state as the full scan, so the
@@ -445,6 +565,7 @@ struct MamPass {
     MamState* in_used;          // per boundary: boundary x = (item index of its right slice) - (strand block number)
     MamState* out;
     const uint32_t* item_block; // strand block number of every item
+    const SliceState* guess;    // k_slice_states + k_slice_chain: taken where no extension failed and the match is one row
     uint32_t slice_len, warm_up;
 };
 
@@ -494,8 +615,21 @@ __global__ void __launch_bounds__(256) k_find_mams_sliced(SearchArgs A, MamPass 
             s = P.out[xr];
             attempt = (uint32_t)A.item_attempt[it] + 1u;
         } else {
+            bool guessed = false;
+            if (P.guess) {
+                // a warm-up in which no extension failed and whose match is one row: the full scan is on that row too (it
+                // emitted it at b, so its fall-back interval is the row), with the length that the comparison with the text
+                // gave (k_slice_states / k_slice_chain) -- a guess like any other, verified by k_mam_check
+                const SliceState gs = P.guess[xr];
+                const uint32_t need = kSsValid | kSsOneRow | kSsNoFail;
+                if ((gs.flags & (need | kSsOpen)) == need && gs.depth >= L) {
+                    s.top = s.bot = s.prev_top = s.prev_bot = gs.top;
+                    s.depth = gs.depth;
+                    guessed = true;
+                }
+            }
             uint32_t w = P.warm_up;
-            for (;;) {
+            while (!guessed) {
                 const uint32_t e = (len - b <= w) ? len : b + w;
                 s.top = 0; s.bot = ix.n; s.prev_top = 0; s.prev_bot = ix.n; s.depth = 0;
                 for (uint32_t j = e; j-- > b;) {
@@ -777,7 +911,7 @@ enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, 
 // exact, 27 % fewer lines and 32 % fewer lane trips, but the same time -- the kernel is bound by instruction issue and
 // every trip pays for the union of the states its lanes are in -- so the default kernel is the one without them
 // (SLAMEM_SKIP=1 selects this one).
-template <bool kStats, bool kSkip>
+template <bool kStats, bool kSkip, bool kSliced>
 __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
     __shared__ ItemDesc lds_item[4][kFetch];
     __shared__ uint64_t lds_pk[4][kFetch];
@@ -880,6 +1014,14 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
                 // the first K letters through the jump table: no position that shallow can emit (K < L), and the scan
                 // must have more than K letters before the slice ends
                 if (jK != 0u && j - a_pos > jK) st = ST_JQ;
+                // kSliced: the instantiation for batches with a record longer than a slice.  Every slice but the strand's
+                // rightmost starts at b_pos from the state the full scan has there (k_slice_states): exact from the first
+                // position, so "attempt" is set to the one that never restarts.  (The instantiation without it is the
+                // headline workload's kernel: its code is not touched by the slice logic.)
+                if (kSliced && A.slice_state && d.len - a_pos > kSliceLen) {
+                    const uint4 ss = *reinterpret_cast<const uint4*>(A.slice_state + ((uint64_t)g - 1u - A.item_block[g]));
+                    if (ss.w) { j = b_pos; top = ss.x; bot = ss.y; depth = (int)ss.z; pub = depth - 1; attempt = kMaxAttempt; st = ST_EXT; }
+                }
                 if (d.len == 0) {  // empty record: nothing to scan
                     A.block_counts[g] = 0;
                     A.item_attempt[g] = 0;
@@ -1555,7 +1697,7 @@ inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_alive, off_workids, off_select, select_bytes, off_itemoff, off_rawkey,
-        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, off_mamstate, off_mamrun, off_itemblock, max_bounds, max_items, bytes;
+        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, off_mamstate, off_mamrun, off_itemblock, off_slicestate, max_bounds, max_items, bytes;
 };
 
 // max_items bounds the work items of ANY batch with this many records and characters
@@ -1600,6 +1742,7 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     w.off_mamstate = off; off = align_up(off + 2 * w.max_bounds * sizeof(MamState), 256);
     w.off_mamrun = off;   off = align_up(off + w.max_bounds * 4, 256);
     w.off_itemblock = off; off = align_up(off + w.max_items * 4, 256);
+    w.off_slicestate = off; off = align_up(off + w.max_bounds * sizeof(SliceState), 256);  // start states of slices (k_slice_states)
     w.bytes = off;
     return w;
 }
@@ -1737,7 +1880,8 @@ int SearchJob::tables(hipStream_t stream) {
         uint64_t* d_itempk = reinterpret_cast<uint64_t*>(ws + w.off_itempk);
         uint64_t* d_pq = reinterpret_cast<uint64_t*>(ws + w.off_pq);
         hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
-                           num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk, (uint32_t*)nullptr);
+                           num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk,
+                           nitems != num_blocks ? reinterpret_cast<uint32_t*>(ws + w.off_itemblock) : (uint32_t*)nullptr);
         STEP(hipGetLastError(), "k_item_fill");
         STEP(hipMemsetAsync(d_pq, 0, 16, stream), "memset");  // the two leading zero words
         A.pq = d_pq;
@@ -1802,6 +1946,16 @@ int SearchJob::launch(hipStream_t stream) {
             A.work_count = d_nwork;
         }
         if (A.item_flags) STEP(hipMemsetAsync(A.item_flags, 0, nitems, stream), "memset");
+        if (nitems != num_blocks) {  // some record is longer than a slice: the slices' start states (k_slice_states)
+            static const uint32_t env_warm = [] { const char* v = getenv("SLAMEM_SLICE_WARMUP"); return v && atoi(v) > 0 ? (uint32_t)atoi(v) : kWarmUp; }();
+            SliceState* d_states = reinterpret_cast<SliceState*>(ws + w.off_slicestate);
+            A.item_block = reinterpret_cast<const uint32_t*>(ws + w.off_itemblock);
+            hipLaunchKernelGGL(k_slice_states, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_states, env_warm);
+            STEP(hipGetLastError(), "k_slice_states");
+            hipLaunchKernelGGL(k_slice_chain, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_states);
+            STEP(hipGetLastError(), "k_slice_chain");
+            A.slice_state = d_states;
+        }
         {   // K7q: the strands K8 will scan, packed; then (only if some record was cut into slices) all of those slices
             uint64_t pb = (nitems * 8 + 255) / 256;
             hipLaunchKernelGGL(k_pack_queries<8>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, false);
@@ -1820,12 +1974,16 @@ int SearchJob::launch(hipStream_t stream) {
         (void)hipEventRecord(ev[4], stream);
         timed_k8 = true;
         const dim3 grid8(grid_for(waves * 64));
-        if (A.skip_w) {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, true>), grid8, dim3(256), 0, stream, A);
+        const bool sliced = nitems != num_blocks;  // some record is longer than a slice
+        if (A.skip_w) {  // (the skipping variant: one instantiation, with the slice logic)
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, true>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, true, true>), grid8, dim3(256), 0, stream, A);
+        } else if (sliced) {
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, true>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, true>), grid8, dim3(256), 0, stream, A);
         } else {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, false>), grid8, dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false>), grid8, dim3(256), 0, stream, A);
         }
         STEP(hipGetLastError(), "k_find_mems_v3");
     } else if (nitems) {  // -mam: K9 of the v3 path places the MAMs and resolves their rows
@@ -1844,6 +2002,16 @@ int SearchJob::launch(hipStream_t stream) {
                                reinterpret_cast<const uint32_t*>(ws + w.off_first), (const uint64_t*)nullptr, num_queries, strands,
                                reinterpret_cast<ItemDesc*>(ws + w.off_items), (uint64_t*)nullptr, d_block);
             STEP(hipGetLastError(), "k_item_fill");
+            P.guess = nullptr;
+            if (nitems != num_blocks && idx->view.tgrp) {  // long records: the states where a warm-up meets no failed extension
+                SliceState* d_states = reinterpret_cast<SliceState*>(ws + w.off_slicestate);
+                A.item_block = d_block;
+                hipLaunchKernelGGL(k_slice_states, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_states, env_warm);
+                STEP(hipGetLastError(), "k_slice_states");
+                hipLaunchKernelGGL(k_slice_chain, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_states);
+                STEP(hipGetLastError(), "k_slice_chain");
+                P.guess = d_states;
+            }
             P.run_list = nullptr; P.run_count = nullptr;
             P.in_used = reinterpret_cast<MamState*>(ws + w.off_mamstate);
             P.out = P.in_used + w.max_bounds;

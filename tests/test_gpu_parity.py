@@ -410,7 +410,7 @@ def test_mam_slices_equal_the_whole_strand_scan(eng, env):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "mam_slices_check.py")], env=dict(os.environ, SLAMEM_MAM_TRACE="1", **env),
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "mam_slices_check.py"), "mam"], env=dict(os.environ, SLAMEM_MAM_TRACE="1", **env),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-3000:]
     out = json.loads(r.stdout.decode().strip().splitlines()[-1])
@@ -421,6 +421,27 @@ def test_mam_slices_equal_the_whole_strand_scan(eng, env):
         assert "scanned again" in trace and " 0 scanned again" not in trace  # the verification did its work
     if env.get("SLAMEM_MAM_WARMUP") == "100000000":
         assert " 0 scanned again in 0 passes" in trace  # a warm-up from the strand's end is the whole scan
+
+
+@pytest.mark.parametrize("env", [{}, {"SLAMEM_SLICE_WARMUP": "8"}, {"SLAMEM_SLICE_WARMUP": "100000000"}, {"SLAMEM_TEXT_SECTIONS": "0"}],
+                         ids=["default", "warmup8", "warmup_whole_strand", "index_without_text_sections"])
+def test_mem_slices_equal_the_whole_strand_scan(eng, env):
+    """-mem over 4096-position slices of long strands (tests/mam_slices_check.py mem, in a child process): k_slice_states
+    gives every slice the state the full scan has at its right end -- from a warm-up when an extension failed in it, by
+    comparing the query with the text when the warm-up's match is one row (an exact 120 kbp copy among the queries), by a
+    longer warm-up otherwise (and always, on an index built without the text sections).  Whatever the warm-up, the MEMs
+    are the oracle's whole-strand scan's, in order."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "mam_slices_check.py"), "mem"], env=dict(os.environ, **env),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-3000:]
+    out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert out["all_equal"], out
+    assert all(c["mams"] > 100 for c in out["cases"].values())
 
 
 def test_skip_variant_is_exact(eng):
