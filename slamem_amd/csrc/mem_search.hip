@@ -566,6 +566,7 @@ struct MamPass {
     MamState* out;
     const uint32_t* item_block; // strand block number of every item
     const SliceState* guess;    // k_slice_states + k_slice_chain: taken where no extension failed and the match is one row
+    const uint8_t* alive;       // nullptr, or 0 for strands that the presence filter proved to hold no match >= min_len
     uint32_t slice_len, warm_up;
 };
 
@@ -602,6 +603,10 @@ __global__ void __launch_bounds__(256) k_find_mams_sliced(SearchArgs A, MamPass 
     const uint32_t i = cnt - 1u - c_idx;  // 0 = the strand's rightmost slice
     const uint32_t a = c_idx * P.slice_len, b = (len - a <= P.slice_len) ? len : a + P.slice_len;
     const uint64_t xr = it - 1u - P.item_block[it];  // boundary to the right (i > 0), to the left: xr + 1 (i < cnt - 1)
+    if (P.alive && cnt == 1u && !P.alive[it]) {  // no match of min_len letters anywhere in the strand: no MAM either
+        A.block_counts[it] = 0;                  // (slices of long strands are scanned regardless: their neighbours need their states)
+        return;
+    }
     const IndexView& ix = A.ix;
     const int L = (int)A.min_len;
     QueryCursor qc;
@@ -2003,6 +2008,18 @@ int SearchJob::launch(hipStream_t stream) {
                                reinterpret_cast<ItemDesc*>(ws + w.off_items), (uint64_t*)nullptr, d_block);
             STEP(hipGetLastError(), "k_item_fill");
             P.guess = nullptr;
+            P.alive = nullptr;
+            {   // the presence filter of -mem serves -mam as well: a strand without any match of min_len letters has no MAM
+                static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
+                if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
+                    uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
+                    hipLaunchKernelGGL(k_prefilter<false>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
+                    STEP(hipGetLastError(), "k_prefilter");
+                    (void)hipEventRecord(ev[3], stream);
+                    prefiltered = true;
+                    P.alive = d_alive;
+                }
+            }
             if (nitems != num_blocks && idx->view.tgrp) {  // long records: the states where a warm-up meets no failed extension
                 SliceState* d_states = reinterpret_cast<SliceState*>(ws + w.off_slicestate);
                 A.item_block = d_block;
