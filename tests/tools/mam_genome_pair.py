@@ -2,8 +2,8 @@
 """Cost of -mam on long records: the 4.6 Mbp genome pair of configs[0] through the API, wall time of the search, checked
 against the oracle.  (SLAMEM_MAM_WHOLE=1: one lane per whole strand, the round-1 form; default: verified slices.)"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from golden_cases import ecoli_like_pair
 from slamem_amd import engine

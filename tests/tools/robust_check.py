@@ -4,14 +4,14 @@ run of N (centromere gap), a tandem repeat, a homopolymer run, a long exact dupl
 oracle (sizes are too large): SA is a permutation, sampled neighbours in the suffix order are in order and their LCP
 is exact (compared in the text), sampled MEMs of reads are real and maximal.
 
-    tools/robust_check.py [scale]      scale 1.0 = 40 Mbp text, 8 Mbp N run, 2 Mbp tandem, 1 Mbp poly-A, 3 Mbp copy
+    tests/tools/robust_check.py [scale]      scale 1.0 = 40 Mbp text, 8 Mbp N run, 2 Mbp tandem, 1 Mbp poly-A, 3 Mbp copy
 """
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from slamem_amd import capi, engine  # noqa: E402

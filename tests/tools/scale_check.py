@@ -3,7 +3,7 @@
 size-independent properties only -- every sampled MEM is a real match and maximal on both sides (checked
 against the text itself), MEMs per read and structure statistics stay where theory puts them.
 
-    tools/scale_check.py <n> [reads] [min_len] [repeats]
+    tests/tools/scale_check.py <n> [reads] [min_len] [repeats]
         e.g. 1000000000, 2200000000 (> 2^31: 32-bit row arithmetic)
         repeats=1 plants the repeat model of SURVEY.md 8(d): 0.5 % of the text copied as 1-10 kbp segments with 1 %
         divergence (BASELINE.json configs[3] = 248000000 6250000 50 1 per GPU, configs[4] = 3100000000 12500000 20 1)
@@ -13,7 +13,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from slamem_amd import engine  # noqa: E402

@@ -2,8 +2,8 @@
 """Worst case of the sliced scans: a genome against ITSELF (one exact match as long as the record, so every slice's
 warm-up grows to the record's end).  Wall time of -mem and -mam, checked against the oracle."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from golden_cases import ecoli_like_pair
 from slamem_amd import engine

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """400 more random cases of tests/test_gpu_stress.py (other seeds) against the oracle, in emission order: a longer soak
-of the search path than the test suite affords.  Run on the GPU box:  python tools/stress_more.py  -> "cases 400 bad 0"."""
+of the search path than the test suite affords.  Run on the GPU box:  python tests/tools/stress_more.py  -> "cases 400 bad 0"."""
 import os
 import sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_stress as T
 from oracle import pyoracle as po

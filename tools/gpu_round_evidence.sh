@@ -17,4 +17,4 @@ cp gpurun_out/prof/$TAG/summary.json gpurun_out/${TAG}_pmc_summary.json
 bash tools/k8_size_sweep.sh > gpurun_out/${TAG}_k8_size_sweep.txt 2>&1
 python tools/host_leg_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_host_leg_sweep.jsonl
 bash tools/cli_config3.sh > gpurun_out/${TAG}_cli_config3.txt 2>&1; tail -4 gpurun_out/${TAG}_cli_config3.txt
-python tools/mam_genome_pair.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_mam_genome_pair.json; cat gpurun_out/${TAG}_mam_genome_pair.json
+python tests/tools/mam_genome_pair.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_mam_genome_pair.json; cat gpurun_out/${TAG}_mam_genome_pair.json

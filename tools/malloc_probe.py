@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How long does hipMalloc / hipFree take for tens of GB on this box?  (The 3.1 Gbp index build spends most of its wall
-time there: tools/scale_check.py with SLAMEM_BUILD_TRACE=1.)"""
+time there: tests/tools/scale_check.py with SLAMEM_BUILD_TRACE=1.)"""
 import ctypes as C
 import time
 
