@@ -353,23 +353,28 @@ def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len
     nb = len(cuts) - 1
     biggest = int(np.diff(np.array(cuts)).max())
     st = Stream(index, slots, biggest * L, biggest, both)
-    best, total_mems, kernel_ms = None, 0, 0.0
+    best, total_mems, kernel_ms, steady = None, 0, 0.0, None
     try:
         for rep in range(steps + 1):  # first pass warms the stream's buffers up
             t0 = time.perf_counter()
             got, kms = 0, 0.0
             for b in range(min(slots - 1, nb)):
                 st.submit(buf.array, offsets[cuts[b]: cuts[b + 1] + 1], min_len)
+            marks = []
             for b in range(nb):
                 m, _, tm = st.next(copy=False)
                 got += len(m)
                 kms += tm["search_kernel_ms"]
+                marks.append((time.perf_counter(), len(m)))
                 nxt = b + slots - 1
                 if nxt < nb:
                     st.submit(buf.array, offsets[cuts[nxt]: cuts[nxt + 1] + 1], min_len)
             dt = time.perf_counter() - t0
             if rep and (best is None or dt < best):
                 best = dt
+                # the pipeline's rate once it is full: results of the full-size batches in the middle of the run
+                lo, hi = min(3, nb - 1), max(nb - 2, 0)
+                steady = (sum(c for _, c in marks[lo + 1: hi + 1]) / (marks[hi][0] - marks[lo][0])) if hi > lo + 1 else None
             total_mems, kernel_ms = got, kms
     finally:
         st.close()
@@ -380,6 +385,9 @@ def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len
             "host_to_host": {"batches": nb, "batch_reads": batch_reads, "slots": slots, "h2d_bytes": count * L,
                              "d2h_bytes": 12 * int(total_mems) + 8 * (count * (2 if both else 1) + nb),
                              "kernel_ms_sum": kernel_ms,
+                             "steady_state_MEMs_per_s": steady,
+                             "steady_state_note": "results of the full-size batches in the middle of the run / the time between "
+                                                  "them: the pipeline without its ramp and drain (a longer job tends to this)",
                              "note": "reads and record offsets in pinned host memory -> MEMs in pinned host memory through slamem_stream_* "
                                      "(uploads, kernels and downloads of neighbouring batches overlap); best of "
                                      f"{steps} passes over the same {count} reads"}}
