@@ -27,11 +27,11 @@ print(json.dumps({"device_resident_ms": dt * 1e3, "mems": tot, "kernel_ms": engi
 del m
 K = 1000
 for name, sched in (("current", None),
-                    ("B", [250 * K, 500 * K, 1000 * K, 2000 * K, 3000 * K, 3250 * K]),
-                    ("C", [250 * K, 500 * K, 1000 * K, 2000 * K, 2500 * K, 2500 * K, 1250 * K]),
                     ("D", [250 * K, 500 * K, 1000 * K, 1500 * K, 2000 * K, 2000 * K, 1750 * K, 1000 * K]),
-                    ("E", [125 * K, 250 * K, 500 * K, 1000 * K, 2000 * K, 2500 * K, 2000 * K, 1000 * K, 625 * K]),
-                    ("F", [250 * K, 750 * K, 1500 * K, 1500 * K])):
+                    ("S1", [100 * K, 200 * K, 400 * K, 800 * K, 1500 * K, 2000 * K, 2000 * K, 1500 * K, 1000 * K, 500 * K]),
+                    ("S2", [125 * K, 250 * K, 500 * K, 1000 * K, 1500 * K, 1500 * K, 1500 * K, 1500 * K, 1000 * K, 750 * K, 375 * K]),
+                    ("S3", [250 * K, 500 * K, 1000 * K, 1500 * K, 1500 * K, 1500 * K, 1500 * K, 1250 * K, 750 * K, 250 * K]),
+                    ("S4", [100 * K, 300 * K, 700 * K, 1400 * K, 2000 * K, 2000 * K, 2000 * K, 1000 * K, 500 * K])):
     r = engine.host_to_host_leg(idx, reads, M, L, 20, True, steps=2, batch_reads=1_000_000, slots=6, schedule=sched)
     print(json.dumps({"schedule": name, "ms": r["host_to_host_ms"], "MEMs_per_s": r["value_host_to_host"], "batches": r["host_to_host"]["batches"],
                       "kernel_ms_sum": r["host_to_host"]["kernel_ms_sum"]}), flush=True)
