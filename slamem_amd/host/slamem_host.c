@@ -5,6 +5,9 @@
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <sys/mman.h>
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -100,6 +103,24 @@ void slh_free_seqset(slh_seqset *s) {
     memset(s, 0, sizeof(*s));
 }
 
+/* 1 if the `len` bytes at p are all upper-case A, C, G or T (a line of a read file almost always is: it is then copied
+ * as it stands instead of going through the table byte by byte) */
+static int line_is_acgt(const unsigned char *p, size_t len) {
+    size_t i = 0;
+#if defined(__SSE2__)
+    const __m128i a = _mm_set1_epi8('A'), c = _mm_set1_epi8('C'), g = _mm_set1_epi8('G'), t = _mm_set1_epi8('T');
+    for (; i + 16 <= len; i += 16) {
+        const __m128i x = _mm_loadu_si128((const __m128i *)(p + i));
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(x, a), _mm_cmpeq_epi8(x, c)),
+                                        _mm_or_si128(_mm_cmpeq_epi8(x, g), _mm_cmpeq_epi8(x, t)));
+        if (_mm_movemask_epi8(ok) != 0xFFFF) return 0;
+    }
+#endif
+    for (; i < len; i++)
+        if (p[i] != 'A' && p[i] != 'C' && p[i] != 'G' && p[i] != 'T') return 0;
+    return 1;
+}
+
 /* the records of one memory range that starts with '>' */
 static int load_mem(const unsigned char *data, long fsize, int merge, int acgt_only, uint32_t min_len,
                     const char *name_filter, int first_number, long log_limit, slh_seqset *out, FILE *log) {
@@ -133,6 +154,15 @@ static int load_mem(const unsigned char *data, long fsize, int merge, int acgt_o
         name_start = r.p;
         matchpos = 0;
         desclen = 0;
+        if (quiet && !name_filter) { /* nothing to print or to match: find the end of the line in one step */
+            const unsigned char *nl = (const unsigned char *)memchr(r.p, '\n', (size_t)(r.end - r.p));
+            const unsigned char *stop = nl ? nl : r.end;
+            const unsigned char *cr = (const unsigned char *)memchr(r.p, '\r', (size_t)(stop - r.p));
+            if (cr) stop = cr;
+            desclen = (int)(stop - r.p);
+            c = stop < r.end ? (int)*stop : EOF;
+            r.p = stop < r.end ? stop + 1 : stop;
+        } else
         while ((c = rd(&r)) != EOF && c != '\n' && c != '\r') {
             if (!quiet && desclen < 50) fputc(c, log);
             if (name_filter && name_filter[matchpos] != '\0') { /* sequence.c:137-140 */
@@ -161,12 +191,24 @@ static int load_mem(const unsigned char *data, long fsize, int merge, int acgt_o
             if (!merge) { /* query records: tight, branch-light copy loop (the 'N' separator logic is reference-only) */
                 const unsigned char *p = r.p, *pe = r.end;
                 unsigned char *dst = (unsigned char *)chars + seqlen;
-                while (p < pe) {
-                    unsigned char t = (unsigned char)table[*p];
-                    if (t == 0xFF) break;
-                    p++;
-                    *dst = t;
-                    dst += (t != 0);
+                while (p < pe && *p != '>') { /* line by line; a '>' anywhere ends the record (sequence.c:157) */
+                    const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(pe - p));
+                    const unsigned char *end = nl ? nl : pe;
+                    if (line_is_acgt(p, (size_t)(end - p))) {
+                        memcpy(dst, p, (size_t)(end - p));
+                        dst += end - p;
+                        p = end;
+                    } else {
+                        while (p < end) {
+                            unsigned char t = (unsigned char)table[*p];
+                            if (t == 0xFF) break;
+                            p++;
+                            *dst = t;
+                            dst += (t != 0);
+                        }
+                        if (p < end) break; /* stopped at a '>' inside the line */
+                    }
+                    if (nl) p = nl + 1; /* (the table maps the newline to "skip") */
                 }
                 seqsize = (uint32_t)(dst - ((unsigned char *)chars + seqlen));
                 seqlen += seqsize;

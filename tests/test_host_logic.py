@@ -245,3 +245,73 @@ def test_formatter_numbers_of_every_width(tmp_path):
     got = hostlib.format_block(b"q name", 1, mems, ref)
     want = b">q name Reverse\n" + b"".join(b"%d\t%d\t%d\n" % (int(a) + 1, int(b) + 1, int(c)) for a, b, c in mems)
     assert got == want
+
+
+def _reference_query_loader(data: bytes, acgt_only: bool):
+    """The query loader's rules, byte by byte (sequence.c:128-215 for one file, no filter, no minimum length)."""
+    keep = {}
+    for ch in range(ord("A"), ord("Z") + 1):
+        if not acgt_only:
+            keep[ch] = keep[ch + 32] = ord("N")
+    for ch in b"ACGT":
+        keep[ch] = keep[ch + 32] = ch
+    names, seqs, i, n = [], [], 0, len(data)
+    if not data or data[0] != ord(">"):
+        return names, seqs
+    while i < n:
+        while i < n and data[i] != ord(">"):
+            i += 1
+        if i >= n:
+            break
+        i += 1
+        j = i
+        while j < n and data[j] not in (10, 13):
+            j += 1
+        name = data[i:j]
+        i = j + 1 if j < n else j
+        out = bytearray()
+        while i < n and data[i] != ord(">"):
+            if data[i] in keep:
+                out.append(keep[data[i]])
+            i += 1
+        if out:
+            names.append(name)
+            seqs.append(bytes(out))
+    return names, seqs
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_loader_fast_paths_follow_the_byte_by_byte_rules(seed, tmp_path):
+    """Whole-line copies (lines of upper-case A,C,G,T) and the one-step header scan must give what the byte-by-byte rules
+    give: random files mixing clean lines, lower case, CR LF, other letters, digits, blanks, '>' inside a line, empty
+    lines and records, a header ended by CR, no newline at the end."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for r in range(int(rng.integers(5, 60))):
+        parts.append(b">rec%d %s" % (r, bytes(rng.choice(np.frombuffer(b"abc xyz_|", dtype=np.uint8), size=int(rng.integers(0, 12))))))
+        parts.append([b"\n", b"\r\n", b"\r"][int(rng.integers(0, 3))])
+        for _ in range(int(rng.integers(0, 6))):
+            kind = int(rng.integers(0, 7))
+            L = int(rng.integers(0, 90))
+            if kind <= 2:
+                line = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L))
+            elif kind == 3:
+                line = bytes(rng.choice(np.frombuffer(b"acgtnACGTN", dtype=np.uint8), size=L))
+            elif kind == 4:
+                line = bytes(rng.choice(np.frombuffer(b"ACGTRYKM*-1 \t", dtype=np.uint8), size=L))
+            elif kind == 5:
+                line = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)) + b">mid%d\nAC" % r  # '>' inside a line
+            else:
+                line = b""
+            parts.append(line)
+            parts.append([b"\n", b"\n", b"\r\n"][int(rng.integers(0, 3))])
+    data = b"".join(parts)
+    if seed % 2:
+        data = data.rstrip(b"\r\n")
+    p = tmp_path / "x.fa"
+    p.write_bytes(data)
+    for acgt_only in (0, 1):
+        names, seqs = _reference_query_loader(data, bool(acgt_only))
+        a = hostlib.Loaded(str(p), 0, acgt_only)
+        assert a.names == names
+        assert a.chars == b"".join(seqs) and a.sizes == [len(x) for x in seqs]
