@@ -163,17 +163,19 @@ typedef struct {
     slh_buffer buf;
     long long matches, sum;
     int failed;
+    double t_start, t_end; /* (SLAMEM_TIMING) when the thread worked */
 } fmt_job;
 
 /* Text buffers go round: formatter -> writer -> pool -> formatter.  A fresh 20 MB buffer costs its page faults every
  * time (the output of the reference-sized run is 638 MB); a recycled one is already mapped. */
 static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
-static slh_buffer g_pool[256];
+static slh_buffer g_pool[512];
 static int g_pool_n = 0;
 static long g_pool_hits = 0, g_pool_misses = 0; /* (SLAMEM_TIMING) */
+static double g_fmt_busy = 0, g_fmt_longest = 0, g_fmt_latest_start = 0; /* (SLAMEM_TIMING) formatter threads: CPU time, per-batch maxima */
 static void pool_put(slh_buffer *b) {
     pthread_mutex_lock(&g_pool_mu);
-    if (b->data && g_pool_n < 256) { b->len = 0; g_pool[g_pool_n++] = *b; b->data = NULL; }
+    if (b->data && g_pool_n < 512) { b->len = 0; g_pool[g_pool_n++] = *b; b->data = NULL; }
     pthread_mutex_unlock(&g_pool_mu);
     if (b->data) slh_buffer_free(b);
     b->data = NULL; b->len = b->cap = 0;
@@ -191,6 +193,7 @@ static void pool_get(slh_buffer *b, size_t need) {
 static void *fmt_run(void *arg) {
     fmt_job *j = (fmt_job *)arg;
     uint64_t b;
+    j->t_start = now_s();
     /* about 36 characters per MEM line and a header per block: reserve once instead of doubling on the way */
     const size_t need = (size_t)(j->boff[j->b1] - j->boff[j->b0]) * 36 + (size_t)(j->b1 - j->b0) * 48 + 4096;
     pool_get(&j->buf, need);
@@ -203,7 +206,26 @@ static void *fmt_run(void *arg) {
         j->matches += (long long)cnt;
         j->sum += (long long)sum;
     }
+    j->t_end = now_s();
     return NULL;
+}
+
+/* the formatter threads of a batch take its chunks (ranges of strand blocks) from a shared counter: equal shares per
+ * thread left the batch waiting for its slowest thread (measured: twice the mean, on a box whose CPU share is smaller
+ * than the number of threads) */
+typedef struct {
+    fmt_job *jobs;
+    int njobs;
+    int next; /* atomic */
+} fmt_queue;
+
+static void *fmt_worker(void *arg) {
+    fmt_queue *q = (fmt_queue *)arg;
+    for (;;) {
+        int c = __atomic_fetch_add(&q->next, 1, __ATOMIC_RELAXED);
+        if (c >= q->njobs) return NULL;
+        fmt_run(&q->jobs[c]);
+    }
 }
 
 /* The index is built on the GPU by its own host thread while the main thread parses the query files: the two do not
@@ -757,28 +779,43 @@ int main(int argc, char **argv) {
                 if (bseq < nblk) {
                     fmt_job *jobs;
                     pthread_t *tid;
+                    fmt_queue fq;
                     uint64_t per;
+                    int njobs;
+                    double fmt_t0 = now_s(), fmt_longest = 0, fmt_latest_start = 0;
                     if ((nblk - bseq) < 4096 || nthr < 1) nthr = 1;
-                    jobs = (fmt_job *)calloc((size_t)nthr, sizeof(fmt_job));
+                    /* chunks of 32 k strand blocks, at least one per thread */
+                    njobs = (int)((nblk - bseq + 32767) / 32768);
+                    if (njobs < nthr) njobs = nthr;
+                    jobs = (fmt_job *)calloc((size_t)njobs, sizeof(fmt_job));
                     tid = (pthread_t *)calloc((size_t)nthr, sizeof(pthread_t));
                     if (!jobs || !tid) pipeline_fail("Out of memory");
-                    per = (nblk - bseq + (uint64_t)nthr - 1) / (uint64_t)nthr;
-                    for (t = 0; t < nthr; t++) {
+                    per = (nblk - bseq + (uint64_t)njobs - 1) / (uint64_t)njobs;
+                    for (t = 0; t < njobs; t++) {
                         jobs[t].q = q; jobs[t].ref = &ref; jobs[t].mems = mems; jobs[t].boff = boff;
                         jobs[t].first_rec = first; jobs[t].strands = strands;
                         jobs[t].b0 = bseq + per * (uint64_t)t < nblk ? bseq + per * (uint64_t)t : nblk;
                         jobs[t].b1 = jobs[t].b0 + per < nblk ? jobs[t].b0 + per : nblk;
-                        if (t == nthr - 1 || pthread_create(&tid[t], NULL, fmt_run, &jobs[t]) != 0) { fmt_run(&jobs[t]); tid[t] = 0; }
                     }
-                    for (t = 0; t < nthr; t++) {
+                    fq.jobs = jobs; fq.njobs = njobs; fq.next = 0;
+                    for (t = 0; t + 1 < nthr; t++)
+                        if (pthread_create(&tid[t], NULL, fmt_worker, &fq) != 0) tid[t] = 0;
+                    fmt_worker(&fq); /* the main thread takes chunks too */
+                    for (t = 0; t + 1 < nthr; t++)
                         if (tid[t]) pthread_join(tid[t], NULL);
+                    for (t = 0; t < njobs; t++) {
                         if (jobs[t].failed) pipeline_fail("Out of memory");
+                        g_fmt_busy += jobs[t].t_end - jobs[t].t_start;
+                        if (jobs[t].t_end - jobs[t].t_start > fmt_longest) fmt_longest = jobs[t].t_end - jobs[t].t_start;
+                        if (jobs[t].t_start - fmt_t0 > fmt_latest_start) fmt_latest_start = jobs[t].t_start - fmt_t0;
                         total_matches += jobs[t].matches;
                         total_sum += jobs[t].sum;
                         if (writer_push(&g_writer, &jobs[t].buf)) pipeline_fail("Out of memory");
                     }
                     free(jobs);
                     free(tid);
+                    g_fmt_longest += fmt_longest;
+                    g_fmt_latest_start += fmt_latest_start;
                 }
                 if (g_writer.failed) pipeline_fail("Cannot write output file");
             }
@@ -817,6 +854,9 @@ int main(int argc, char **argv) {
     char overlap_note[96] = "";
     if (g_ld.seconds > 0)
         snprintf(overlap_note, sizeof(overlap_note), " + queries parsed in pieces beside the search in %.3f s (%.3f s waited for)", g_ld.seconds, t_wait_load);
+    if (timing)
+        fprintf(stderr, "[timing] formatter threads: busy %.3f s in all; per batch the longest chunk %.3f s, the last chunk started %.3f s after the batch began (sums over the batches)\n",
+                g_fmt_busy, g_fmt_longest, g_fmt_latest_start);
     if (timing)
         fprintf(stderr, "[timing] load %.3f s%s (index build of %.3f s overlapped; %.3f s more waiting for it), pipeline set-up %.3f s, "
                         "waiting for the GPU (upload + search + download, overlapped with formatting) %.3f s, format %.3f s "
