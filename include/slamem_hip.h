@@ -127,6 +127,9 @@ int slamem_device_count(int *count_out);
 /* Creates the HIP context of `device` (runtime start-up takes ~0.2 s): a front end calls this from a helper thread
  * while it parses its input, so that the index build does not pay for it.  No reference counterpart. */
 int slamem_device_warmup(int device);
+/* PCI address of `device` ("0000:c1:00.0"): a front end reads /sys/bus/pci/devices/<address>/local_cpulist to keep its host
+ * threads on the GPU's NUMA node.  No reference counterpart. */
+int slamem_device_pci_bus_id(int device, char *out, int out_bytes);
 int slamem_get_timings(slamem_timings *out);
 int slamem_reset_timings(void);
 /* on != 0: the NEXT slamem_find_mems_device calls of this thread run the diagnostic kernel instantiations (same results,

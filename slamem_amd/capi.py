@@ -27,7 +27,7 @@ ARRAY_SA, ARRAY_BWT, ARRAY_LCP, ARRAY_PSV, ARRAY_NSV = range(5)
 # every symbol include/slamem_hip.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = (
     "slamem_abi_version", "slamem_strerror", "slamem_last_error_message", "slamem_device_count",
-    "slamem_get_timings", "slamem_reset_timings", "slamem_device_warmup",
+    "slamem_get_timings", "slamem_reset_timings", "slamem_device_warmup", "slamem_device_pci_bus_id",
     "slamem_index_build", "slamem_index_build_device", "slamem_index_free", "slamem_index_get_info",
     "slamem_index_arena", "slamem_index_export", "slamem_index_attach", "slamem_index_adopt_arena", "slamem_index_save", "slamem_index_load",
     "slamem_index_validate_header", "slamem_search_stats_enable", "slamem_get_search_stats", "slamem_get_search_clock",
@@ -98,6 +98,7 @@ def _declare(L):
     L.slamem_strerror.argtypes = [i32]
     L.slamem_last_error_message.restype = C.c_char_p
     L.slamem_device_count.argtypes = [C.POINTER(i32)]
+    L.slamem_device_pci_bus_id.argtypes = [i32, C.c_char_p, i32]
     L.slamem_get_timings.argtypes = [C.POINTER(Timings)]
     L.slamem_index_build.argtypes = [C.c_char_p, u32, i32, C.POINTER(vp)]
     L.slamem_index_build_device.argtypes = [vp, u32, i32, vp, C.POINTER(vp)]

@@ -147,6 +147,14 @@ int slamem_device_warmup(int device) {
     return SLAMEM_OK;
 }
 
+int slamem_device_pci_bus_id(int device, char* out, int out_bytes) {
+    if (!out || out_bytes < 16) return SLAMEM_ERR_ARG;
+    int rc = check_device(device);
+    if (rc) return rc;
+    SLAMEM_HIP(hipDeviceGetPCIBusId(out, out_bytes, device));
+    return SLAMEM_OK;
+}
+
 int slamem_get_timings(slamem_timings* out) {
     if (!out) return SLAMEM_ERR_ARG;
     *out = g_tm.t;
