@@ -338,6 +338,38 @@ def test_a_slice_with_2_to_the_28_mems_is_an_error_not_wrong_output(eng):
     idx.close()
 
 
+def test_stream_large_batches_from_ordinary_and_page_locked_memory(eng):
+    """Batches of 40 MB and 72 MB whose characters live in ordinary (pageable) memory, the same batches from page-locked
+    memory, and slamem_find_mems_device on the same reads must agree MEM for MEM.  (Staging pageable batches through
+    page-locked buffers inside the stream was measured against the runtime's own path: slower, not adopted.)"""
+    from slamem_amd import synth
+    n, nreads, L = 2_000_000, 750_000, 150
+    ref = synth.make_reference(n, seed=9)
+    reads = synth.make_reads(ref, 0, nreads, L, 0.02, seed=9, rc_percent=50).reshape(-1)
+    off = np.arange(nreads + 1, dtype=np.uint64) * np.uint64(L)
+    idx = eng.Index.build(ref)
+    want, want_off = idx.find_mems(reads, off, 20, True)
+    cuts = [0, 270_000, 750_000]  # 40.5 MB and 72 MB
+    pinned = eng.PinnedBuffer(len(reads) + 64)
+    pinned.array[: len(reads)] = reads
+    for src in (np.array(reads), pinned.array):
+        st = eng.Stream(idx, 3, 1 << 20, 1024, True)
+        got, got_counts = [], []
+        for b in range(len(cuts) - 1):
+            st.submit(src, off[cuts[b]: cuts[b + 1] + 1], 20)
+        for b in range(len(cuts) - 1):
+            m, boff, _ = st.next()
+            got.append(m.copy())
+            got_counts.append(np.diff(boff.astype(np.int64)))
+        st.close()
+        gm = np.concatenate(got)
+        assert np.array_equal(np.concatenate(got_counts), np.diff(want_off.astype(np.int64)))
+        for f in ("ref_pos", "query_pos", "length"):
+            assert np.array_equal(gm[f], want[f]), f
+    pinned.close()
+    idx.close()
+
+
 def test_stream_slots_grow_with_the_batches(eng):
     """slamem_stream_create's sizes are a reservation, not a limit: a stream set up for 4 records of 1 kB takes batches that
     grow from 3 to 600 records (and a 30 kB record among 100-letter reads), from pageable memory, with empty records and an
