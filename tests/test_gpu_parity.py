@@ -338,6 +338,31 @@ def test_a_slice_with_2_to_the_28_mems_is_an_error_not_wrong_output(eng):
     idx.close()
 
 
+@pytest.mark.parametrize("min_len", [8, 9, 13, 15, 16, 17, 21, 40, 151])
+def test_minimum_length_thresholds_of_the_search_path(eng, min_len):
+    """One 3 Mbp text (presence filter k = 15, jump table K = 9) and 20,000 (1,000) reads of 150 letters, both strands, for the
+    minimum lengths at which the path changes shape: below / at K (no jump), below / at the filter's k (no prefilter,
+    one level, two, three levels), a common value, a large one, and one above the read length (nothing can match).
+    Equal to the oracle in order every time."""
+    from oracle import pyoracle as po
+    from slamem_amd import synth
+    n, nreads, L = 3_000_000, (20_000 if min_len >= 13 else 1_000), 150  # (short matches are many: fewer reads for them)
+    ref = synth.make_reference(n, seed=31)
+    synth.plant_repeats(ref, 31)
+    reads = synth.make_reads(ref, 0, nreads, L, 0.03, seed=31, rc_percent=50).reshape(-1)
+    off = np.arange(nreads + 1, dtype=np.uint64) * np.uint64(L)
+    idx = eng.Index.build(ref)
+    o = po.OracleIndex(ref.tobytes())
+    om, obc = o.match_batch(reads, off, min_len, True)
+    gm, goff = idx.find_mems(reads, off, min_len, True)
+    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+    for f in ("ref_pos", "query_pos", "length"):
+        assert np.array_equal(gm[f], om[f]), f
+    if min_len > L:
+        assert len(gm) == 0
+    idx.close()
+
+
 def test_stream_large_batches_from_ordinary_and_page_locked_memory(eng):
     """Batches of 40 MB and 72 MB whose characters live in ordinary (pageable) memory, the same batches from page-locked
     memory, and slamem_find_mems_device on the same reads must agree MEM for MEM.  (Staging pageable batches through
