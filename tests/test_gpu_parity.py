@@ -338,12 +338,13 @@ def test_a_slice_with_2_to_the_28_mems_is_an_error_not_wrong_output(eng):
     idx.close()
 
 
-@pytest.mark.parametrize("min_len", [8, 9, 13, 15, 16, 17, 21, 40, 151])
-def test_minimum_length_thresholds_of_the_search_path(eng, min_len):
+@pytest.mark.parametrize("min_len,mam", [(8, False), (9, False), (13, False), (15, False), (16, False), (17, False), (21, False),
+                                         (40, False), (151, False), (9, True), (13, True), (15, True), (21, True), (151, True)])
+def test_minimum_length_thresholds_of_the_search_path(eng, min_len, mam):
     """One 3 Mbp text (presence filter k = 15, jump table K = 9) and 20,000 (1,000) reads of 150 letters, both strands, for the
     minimum lengths at which the path changes shape: below / at K (no jump), below / at the filter's k (no prefilter,
     one level, two, three levels), a common value, a large one, and one above the read length (nothing can match).
-    Equal to the oracle in order every time."""
+    Equal to the oracle in order every time; -mam (its own kernel, behind the same filter) at five of them."""
     from oracle import pyoracle as po
     from slamem_amd import synth
     n, nreads, L = 3_000_000, (20_000 if min_len >= 13 else 1_000), 150  # (short matches are many: fewer reads for them)
@@ -353,8 +354,8 @@ def test_minimum_length_thresholds_of_the_search_path(eng, min_len):
     off = np.arange(nreads + 1, dtype=np.uint64) * np.uint64(L)
     idx = eng.Index.build(ref)
     o = po.OracleIndex(ref.tobytes())
-    om, obc = o.match_batch(reads, off, min_len, True)
-    gm, goff = idx.find_mems(reads, off, min_len, True)
+    om, obc = o.match_batch(reads, off, min_len, True, mam=mam)
+    gm, goff = idx.find_mems(reads, off, min_len, True, mam=mam)
     assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
     for f in ("ref_pos", "query_pos", "length"):
         assert np.array_equal(gm[f], om[f]), f
