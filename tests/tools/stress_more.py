@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """400 more random cases of tests/test_gpu_stress.py (other seeds) against the oracle, in emission order: a longer soak
-of the search path than the test suite affords.  Run on the GPU box:  python tests/tools/stress_more.py  -> "cases 400 bad 0"."""
+of the search path than the test suite affords.  Run on the GPU box:  python tests/tools/stress_more.py [first seed] [cases]  -> "cases 400 bad 0"."""
 import os
 import sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,9 @@ import test_gpu_stress as T
 from oracle import pyoracle as po
 from slamem_amd import engine
 bad = 0
-for seed in range(2000, 2400):
+BASE = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+COUNT = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+for seed in range(BASE, BASE + COUNT):
     rng = np.random.default_rng(seed)
     text, qs, l, both = T.random_case(rng)
     q = np.concatenate(qs) if qs else np.zeros(0, dtype=np.uint8)
@@ -24,4 +26,4 @@ for seed in range(2000, 2400):
         bad += 1
         print("MISMATCH seed", seed, "l", l, "both", both, "n", len(text), len(gm), len(om))
     g.close()
-print("cases 400 bad", bad)
+print("cases", COUNT, "bad", bad)

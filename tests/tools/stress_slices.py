@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the sliced scans (records longer than 4096 letters): random texts with repeats and runs of N, queries pieced
 together from text segments (exact, mutated, reverse-complemented, repeated), -mem and -mam, against the oracle in order.
-    python tests/tools/stress_slices.py [cases]      -> "cases N bad 0"
+    python tests/tools/stress_slices.py [cases] [first seed]      -> "cases N bad 0"
 SLAMEM_SLICE_WARMUP / SLAMEM_MAM_WARMUP vary the warm-up (read once per process)."""
 import os
 import sys
@@ -13,19 +13,20 @@ from oracle import pyoracle as po
 from slamem_amd import engine
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
 LET = np.frombuffer(b"ACGT", dtype=np.uint8)
 COMP = np.zeros(256, dtype=np.uint8)
 for a, b in zip(b"ACGTN", b"TGCAN"):
     COMP[a] = b
 bad = 0
-for seed in range(7000, 7000 + ncases):
+for seed in range(first, first + ncases):
     rng = np.random.default_rng(seed)
     n = int(rng.integers(30_000, 200_000))
     alpha = "ACGT" if seed % 3 else "ACGTN"
     t = np.frombuffer(rand_text(rng, n, alpha, int(rng.integers(0, 60)), max_rep=int(rng.integers(200, 6000)),
                                 nrun=int(rng.integers(0, 3000)) if alpha == "ACGTN" else 0), dtype=np.uint8).copy()
     if seed % 4 == 0:  # a long duplicate
-        L = int(rng.integers(5_000, 20_000)); a = int(rng.integers(0, n - 2 * L)); b = int(rng.integers(a + L, n - L))
+        L = int(rng.integers(5_000, min(20_000, n // 4))); a = int(rng.integers(0, n - 3 * L)); b = int(rng.integers(a + L, n - L))
         t[b:b + L] = t[a:a + L]
     qs = []
     for _ in range(int(rng.integers(1, 5))):
