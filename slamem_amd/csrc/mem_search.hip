@@ -909,6 +909,12 @@ struct PackedCursor {
 enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, ST_DEND = 5, ST_JQ = 6, ST_JT = 7,
                   ST_SKV = 8, ST_SKQ = 9, ST_SKP = 10 };
 
+// kMam: the instantiation for -mam on reads (slamem.c:131): a position is reported only when its interval is ONE row, and a
+// position whose interval is deeper than min_len but NOT one row skips the bookkeeping of slamem.c:197-198 -- so the interval
+// that a later failed extension falls back to (:122-123) is the one noted at an earlier position.  That is two more
+// registers of state (prev_top, prev_bot), another address for the records of a failed extension, and one more condition on
+// `pend`; everything else of the state machine is the -mem one (a direct run is a run of one-row positions: the fall-back
+// interval is the row all along).  Long strands in slices stay with k_find_mams_sliced (their states are verified there).
 #ifndef SLAMEM_V3_WAVES
 #define SLAMEM_V3_WAVES 1
 #endif
@@ -916,8 +922,8 @@ enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, 
 // exact, 27 % fewer lines and 32 % fewer lane trips, but the same time -- the kernel is bound by instruction issue and
 // every trip pays for the union of the states its lanes are in -- so the default kernel is the one without them
 // (SLAMEM_SKIP=1 selects this one).
-template <bool kStats, bool kSkip, bool kSliced>
-__global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
+template <bool kStats, bool kSkip, bool kSliced, bool kMam>
+__global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
     __shared__ ItemDesc lds_item[4][kFetch];
     __shared__ uint64_t lds_pk[4][kFetch];
     __shared__ uint32_t lds_id[4][kFetch];
@@ -960,6 +966,7 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
     uint32_t st = ST_EXT;
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
     uint32_t a_pos = 0, b_pos = 0, attempt = 0, qlen = 0;  // emitted slice [a_pos, b_pos) of the strand, warm-up attempt
+    uint32_t prev_top = 0, prev_bot = 0;  // kMam: the interval a failed extension falls back to (slamem.c:122-123)
     uint32_t dir_r = 0;  // direct extension: text position where the current match starts
     int depth = 0, pub = -1;
     PackedCursor qc;
@@ -1016,6 +1023,7 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
                 attempt = 0;
                 j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
                 top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; k = 0; dcool = false;
+                if (kMam) { prev_top = 0; prev_bot = ix.n; }
                 // the first K letters through the jump table: no position that shallow can emit (K < L), and the scan
                 // must have more than K letters before the slice ends
                 if (jK != 0u && j - a_pos > jK) st = ST_JQ;
@@ -1135,7 +1143,12 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
                 if (st == ST_REC) n_rec_fail += 1u + ((top >> 2) != (bot >> 2));
                 if (st == ST_FLUSH) n_rec_flush += 1u + ((top >> 2) != (bot >> 2));
             }
-            if (want_rec) { a1 = R + top; a2 = reinterpret_cast<const uint2*>(R + bot); }
+            if (want_rec) {
+                // (kMam, state REC: the records of the fall-back interval; with a pending position it IS [top,bot])
+                const bool of_prev = kMam && st == ST_REC;
+                a1 = R + (of_prev ? prev_top : top);
+                a2 = reinterpret_cast<const uint2*>(R + (of_prev ? prev_bot : bot));
+            }
             if (a1) rt = *a1;
             if (a2) { rb0 = a2[0]; if (st != ST_JT) rb1 = a2[1]; }
             if (a3) { const uint2 t3 = a3[0]; rt.x = t3.x; rt.y = t3.y; }
@@ -1160,9 +1173,10 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
             } else if (st == ST_REC) {  // a deep match ended at this letter: widen, retry next trip
                 st = ST_EXT;
                 dcool = false;
+                if (kMam) { top = prev_top; bot = prev_bot; }  // slamem.c:122-123
                 int d = parent_from(rt, rb, top, bot);
                 if (d < 0) { depth = 0; pub = -1; consumed = true; }
-                else { depth = d; pub = d - 1; }
+                else { depth = d; pub = d - 1; if (kMam) { prev_top = top; prev_bot = bot; } }
             } else if (st == ST_JQ) {
                 // K letters, first on top -> 2 bits each (the layout of the table's keys, index_build.hip k_kjump_keys)
                 const uint64_t w0 = u64_of(rb0.x, rb0.y), w1 = u64_of(rb1.x, rb1.y);
@@ -1184,6 +1198,7 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
                 st = ST_EXT;
                 if (rb0.x <= rb0.y) {  // the K-mer occurs: K successful extensions from the root (slamem.c:110-129)
                     top = rb0.x; bot = rb0.y; depth = (int)jK; pub = (int)jK - 1; j -= jK;
+                    if (kMam) { prev_top = top; prev_bot = bot; }  // (K < min_len: every one of those positions noted its interval)
                     if (kStats) n_pos += jK;
                 }
             } else if (kSkip && st == ST_SKQ) {
@@ -1300,6 +1315,7 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
                     dcool = false;
                 }
                 // otherwise the index walk continues from the single row (pending position, exact parent depth)
+                if (kMam) { prev_top = top; prev_bot = bot; }  // the run's positions were one row each: noted; or its parent (:126-127)
             } else {  // ST_EXT
                 uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
                 uint32_t nt, nb1;
@@ -1353,11 +1369,11 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
                         pub++;  // parent depth of cW <= parent depth of W + 1
                         depth++;
                         consumed = true;
-                    } else if (want_rec) {
+                    } else if (want_rec) {  // (kMam: a pending position is one row and was noted: the fall-back interval is [top,bot])
                         int d = parent_from(rt, rb, top, bot);
                         dcool = false;
                         if (d < 0) { depth = 0; pub = -1; consumed = true; }  // root, letter absent (slamem.c:125)
-                        else { depth = d; pub = d - 1; }                      // widened; retry the letter next trip
+                        else { depth = d; pub = d - 1; if (kMam) { prev_top = top; prev_bot = bot; } }  // widened; retry the letter next trip
                     } else {
                         st = ST_REC;  // fetch the records in the next trip
                     }
@@ -1367,7 +1383,8 @@ __global__ void __launch_bounds__(256, kSkip ? 4 : SLAMEM_V3_WAVES) k_find_mems_
                 if (kStats) n_pos++;
                 j--;  // position j is done: it matched `depth` characters
                 bool in_slice = j >= a_pos && j < b_pos;
-                pend = depth >= L && depth > 0 && in_slice;  // slamem.c:130
+                pend = depth >= L && depth > 0 && in_slice && (!kMam || top == bot);  // slamem.c:130 (:131)
+                if (kMam && !(depth >= L && top != bot)) { prev_top = top; prev_bot = bot; }  // slamem.c:197-198, skipped by :131
                 // scan start of this attempt; a match that reaches it may be truncated: redo with a longer warm-up
                 uint32_t e = (attempt >= kMaxAttempt || qlen - b_pos < (kWarmUp << (2u * attempt))) ? qlen
                                                                                                  : b_pos + (kWarmUp << (2u * attempt));
@@ -1777,6 +1794,7 @@ struct SearchJob {
     SearchArgs A;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // before K8a, after K8, after K9, after K8a, before K8
     bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
+    bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
     ~SearchJob();
     int init(const slamem_index* idx_, const void* queries_dev_, const uint64_t* offsets_dev_, uint32_t num_queries_,
              uint64_t query_bytes_, uint32_t min_len_, int both_strands_, int match_type_, slamem_mem* mems_dev_,
@@ -1855,12 +1873,16 @@ int SearchJob::tables(hipStream_t stream) {
     STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
     uint32_t slices = 0;
     STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
-    if (match_type != 1) {  // packed strands: offsets of the strand blocks
+    {   // packed strands: offsets of the strand blocks
         size_t need3 = w.scan_bytes;
         STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need3, d_wps, d_wscan, (uint64_t)num_queries, stream), "scan");
     }
     STEP(hipStreamSynchronize(stream), "item count (sync)");
     nitems = (uint64_t)slices * strands;
+    {   // -mam: reads go through K8 (kMam); batches with a record longer than a slice through k_find_mams_sliced
+        static const bool env_v3 = [] { const char* v = getenv("SLAMEM_MAM_V3"); return !(v && atoi(v) == 0); }();
+        mam_v3 = match_type == 1 && nitems == num_blocks && !mam_whole_strands() && env_v3;
+    }
     if (nitems > w.max_items) { set_error("slamem_find_mems_device: query_bytes is smaller than the offsets say"); return SLAMEM_ERR_ARG; }
     STEP(hipMemsetAsync(d_counts + nitems, 0, 4, stream), "memset");
     memset(&A, 0, sizeof(A));
@@ -1881,7 +1903,7 @@ int SearchJob::tables(hipStream_t stream) {
     A.item_attempt = reinterpret_cast<uint8_t*>(ws + w.off_attempt);
     A.query_words = (query_bytes + 7) / 8;
     A.stats = d_total + 8;  // behind the 64 bytes of scalars
-    if (nitems && match_type != 1) {
+    if (nitems && (match_type != 1 || mam_v3)) {
         uint64_t* d_itempk = reinterpret_cast<uint64_t*>(ws + w.off_itempk);
         uint64_t* d_pq = reinterpret_cast<uint64_t*>(ws + w.off_pq);
         hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
@@ -1930,7 +1952,7 @@ int SearchJob::launch(hipStream_t stream) {
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
     prefiltered = false; timed_k8 = false; launched = true;
     (void)hipEventRecord(ev[0], stream);
-    if (nitems && match_type != 1) {
+    if (nitems && (match_type != 1 || mam_v3)) {
         static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
         if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
             uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
@@ -1981,14 +2003,17 @@ int SearchJob::launch(hipStream_t stream) {
         const dim3 grid8(grid_for(waves * 64));
         const bool sliced = nitems != num_blocks;  // some record is longer than a slice
         if (A.skip_w) {  // (the skipping variant: one instantiation, with the slice logic)
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, true>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, true, true>), grid8, dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, true, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, true, true, false>), grid8, dim3(256), 0, stream, A);
         } else if (sliced) {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, true>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, false, true>), grid8, dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, true, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, true, false>), grid8, dim3(256), 0, stream, A);
+        } else if (mam_v3) {
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false, true>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true>), grid8, dim3(256), 0, stream, A);
         } else {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false>), grid8, dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false>), grid8, dim3(256), 0, stream, A);
         }
         STEP(hipGetLastError(), "k_find_mems_v3");
     } else if (nitems) {  // -mam: K9 of the v3 path places the MAMs and resolves their rows

@@ -47,8 +47,9 @@ def random_case(rng):
     return t.tobytes(), qs, l, bool(rng.random() < 0.5)
 
 
+@pytest.mark.parametrize("mam", [False, True], ids=["mem", "mam"])
 @pytest.mark.parametrize("seed", range(40))
-def test_random_case_matches_oracle_in_order(seed):
+def test_random_case_matches_oracle_in_order(seed, mam):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
@@ -60,11 +61,11 @@ def test_random_case_matches_oracle_in_order(seed):
     off = np.zeros(len(qs) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(x) for x in qs])
     o = po.OracleIndex(text)
-    om, obc = o.match_batch(q, off, l, both)
+    om, obc = o.match_batch(q, off, l, both, mam=mam)
     if len(om) > 3_000_000:
         pytest.skip("degenerate case with millions of MEMs")
     g = engine.Index.build(text)
-    gm, goff = g.find_mems(q, off, l, both)
+    gm, goff = g.find_mems(q, off, l, both, mam=mam)
     assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64)), (len(text), l, both)
     for f in ("ref_pos", "query_pos", "length"):
         assert np.array_equal(gm[f], om[f]), (f, len(text), l, both)
