@@ -11,6 +11,8 @@ Cases (inputs: slamem_amd/synth.py generators, SURVEY.md Appendix C.2 + the repe
                     (2 % substitutions, half reverse-complemented), -b -l 50
   config1_pair      BASELINE.json configs[0]: a 4.64 Mbp genome against a 1.5 %-diverged strain with three
                     inversions and two deletions (tests/golden_cases.py::ecoli_like_pair), -b -l 20
+  config1_pair_mam  the same pair with -mam (sha256 of the reference's output file)
+  config2_mam_first200k   the 100 Mbp reference of configs[1]/[2], its first 200,000 reads, -b -l 20 -mam
 
 Every MEM the reference prints is also checked here against the texts (real match, maximal on both sides) before the
 digest is recorded: the reference is known to print impossible MEMs on some texts with an LCP >= 255 (DESIGN.md 5,
@@ -119,7 +121,40 @@ def case_config1_pair(tmp):
     return d
 
 
-CASES = {"config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair}
+def case_config2_mam_first200k(tmp):
+    """-mam at the headline workload's scale: the 100 Mbp reference of BASELINE.json configs[1]/[2], the first 200,000 of
+    its reads, both strands"""
+    n, nreads, L, min_len = 100_000_000, 200_000, 150, 20
+    ref = synth.make_reference(n, 42)
+    synth.write_fasta_reference(os.path.join(tmp, "ref.fa"), ref)
+    reads = synth.make_reads(ref, 0, nreads, L, 0.02, 42, 50)
+    with open(os.path.join(tmp, "qry.fa"), "wb") as f:
+        f.write(b"".join(b">q%d\n" % i + reads[i].tobytes() + b"\n" for i in range(nreads)))
+    rc, secs = run_reference(["-b", "-l", str(min_len), "-o", "out.txt", "ref.fa", "qry.fa", "-mam"], tmp)
+    rows = parse(os.path.join(tmp, "out.txt"), True)
+    bad = check_rows_against_text(rows, ref, reads, 2)
+    d = digest_rows(rows)
+    d.update({"reference_rc": rc, "reference_seconds": round(secs, 1), "reference_valid": bad == 0, "invalid_rows": bad,
+              "workload": f"n={n} seed 42, reads 0..{nreads - 1} of 150 bp, 2% substitutions, 50% reverse-complemented, "
+                          f"-b -l {min_len} -mam"})
+    return d
+
+
+def case_config1_pair_mam(tmp):
+    from golden_cases import ecoli_like_pair
+    import hashlib
+    ref, qry = ecoli_like_pair()
+    synth.write_fasta_reference(os.path.join(tmp, "ref.fa"), ref, "ecoli_like_ref")
+    synth.write_fasta_reference(os.path.join(tmp, "qry.fa"), qry, "ecoli_like_strain")
+    rc, secs = run_reference(["-b", "-l", "20", "-o", "out.txt", "ref.fa", "qry.fa", "-mam"], tmp)
+    data = open(os.path.join(tmp, "out.txt"), "rb").read()
+    return {"file_bytes": len(data), "file_sha256": hashlib.sha256(data).hexdigest(), "reference_rc": rc,
+            "reference_seconds": round(secs, 1),
+            "workload": f"ecoli_like_pair(): {ref.shape[0]} bp genome vs {qry.shape[0]} bp strain, -b -l 20 -mam"}
+
+
+CASES = {"config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
+         "config2_mam_first200k": case_config2_mam_first200k, "config1_pair_mam": case_config1_pair_mam}
 
 
 def main():

@@ -120,6 +120,52 @@ def test_config1_genome_pair_cli_byte_identical_to_reference(eng, tmp_path):
     assert hashlib.sha256(data).hexdigest() == known["file_sha256"]
 
 
+def test_config1_genome_pair_mam_cli_byte_identical_to_reference(eng, tmp_path):
+    """The same genome pair with -mam: 2226 slices whose start states are guessed and verified (k_find_mams_sliced); the
+    output FILE must have the sha256 of the file the REAL reference wrote (known_answers.json: config1_pair_mam)."""
+    from golden_cases import ecoli_like_pair
+    from slamem_amd import synth
+    known = KNOWN["config1_pair_mam"]
+    ref, qry = ecoli_like_pair()
+    synth.write_fasta_reference(str(tmp_path / "ref.fa"), ref, "ecoli_like_ref")
+    synth.write_fasta_reference(str(tmp_path / "qry.fa"), qry, "ecoli_like_strain")
+    exe = os.path.join(ROOT, "slamem_amd", "host", "slaMEM-hip")
+    r = subprocess.run([exe, "-b", "-l", "20", "-o", "out.txt", "ref.fa", "qry.fa", "-mam"], cwd=str(tmp_path),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-2000:]
+    data = (tmp_path / "out.txt").read_bytes()
+    assert len(data) == known["file_bytes"]
+    assert hashlib.sha256(data).hexdigest() == known["file_sha256"]
+
+
+def test_config2_mam_known_answer(eng):
+    """-mam at the headline workload's scale: the 100 Mbp reference of configs[1]/[2] and the first 200,000 of its reads,
+    -b -l 20 -mam, on K8's kMam instantiation -- against the digest of what the REAL reference printed for the same FASTA
+    files (known_answers.json: config2_mam_first200k; every line of it checked against the texts)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from mems_digest import digest_rows
+    known = KNOWN["config2_mam_first200k"]
+    assert known["reference_valid"]
+    n, nreads, L = 100_000_000, 200_000, 150
+    ref = eng.synth_reference(n, 42, "cuda:0")
+    reads = eng.synth_reads(ref, 0, nreads, L, 0.02, 42, 50)
+    offsets = torch.arange(nreads + 1, dtype=torch.int64, device="cuda:0") * L
+    idx = eng.Index.build(ref, "cuda:0")
+    m = eng.Matcher(idx, nreads, True, 8 * nreads, nreads * L, mam=True)
+    total = m.run(reads, offsets, 20)
+    assert total == known["mems"]
+    mems = m.mems[:total].cpu().numpy().view(np.uint32)
+    boff = m.block_offsets[: 2 * nreads + 1].cpu().numpy()
+    rows = np.empty((total, 4), dtype=np.uint32)
+    rows[:, 0] = np.repeat(np.arange(2 * nreads, dtype=np.uint32), np.diff(boff))
+    rows[:, 1] = mems[:, 0] + 1
+    rows[:, 2] = mems[:, 1] + 1
+    rows[:, 3] = mems[:, 2]
+    assert digest_rows(rows) == {k: known[k] for k in ("mems", "sum_len", "max_len", "sha256")}
+    idx.close()
+
+
 def test_config4_chr1_sized_known_answer(eng):
     """configs[3] (human chr1 stand-in): 248 Mbp text WITH the repeat model, 150 bp reads, -b -l 50.
     (1) the first 1 M reads against the answer of the REAL reference (known_answers.json: config4_first1M);
