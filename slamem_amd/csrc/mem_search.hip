@@ -1070,10 +1070,6 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
             Blk kb;  // block of bot+1 when it differs from top's (wide intervals only: not kept across trips)
             kb.a = kb.b = kb.c = kb.d = make_uint4(0, 0, 0, 0);
             if (st == ST_EXT) {
-                uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
-                if (kStats) { n_kt += bt != tag_t; n_kb += bb != bt; }
-                if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
-                if (bb != bt) kb = load_blk(ix.fm, bb);
                 // records together with the blocks when a pending position's parent may still be >= min_len deep
                 want_rec = pend && pub >= L;
                 if (kStats && want_rec) n_rec_pend += 1u + ((top >> 2) != (bot >> 2));
@@ -1156,6 +1152,20 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
             if (st == ST_EXT) {
                 if (kStats) n_qloads += qc.would_load(j - 1u);
                 c = qc.at(j - 1u);  // issues the query-window load (if any) behind the ones above
+                // The FM blocks LAST.  The compiler rearranges the registers of the second block as soon as they are loaded --
+                // s_waitcnt inside this branch, taken in 94 % of the wave trips (some lane's interval spans two blocks) --
+                // and with the blocks first, the record / text / query loads of the other lanes were issued only after
+                // those waits: two memory phases per trip.  In this order every load of the trip is in flight before the
+                // first wait (checked in the ISA: twelve loads back to back): K8 21.76 -> 20.65 ms.
+                uint32_t bt = top >> kFmRowsLog2, bb = (bot + 1u) >> kFmRowsLog2;
+                if (kStats) { n_kt += bt != tag_t; n_kb += bb != bt; }
+                if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
+                if (bb != bt) kb = load_blk(ix.fm, bb);
+            }
+            if (kMam) {
+                // keeps the compiler from copying parts of the record out of its load's registers right behind the load (an
+                // s_waitcnt between the loads of one trip: seen in this instantiation's ISA): the values "change" here
+                asm volatile("" : "+v"(rt.x), "+v"(rt.y), "+v"(rt.z), "+v"(rt.w));
             }
             const uint4 rb = make_uint4(rb0.x, rb0.y, rb1.x, rb1.y);
 
@@ -1382,10 +1392,12 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
             if (consumed) {
                 if (kStats) n_pos++;
                 j--;  // position j is done: it matched `depth` characters
-                bool in_slice = j >= a_pos && j < b_pos;
+                bool in_slice = !kSliced || (j >= a_pos && j < b_pos);
                 pend = depth >= L && depth > 0 && in_slice && (!kMam || top == bot);  // slamem.c:130 (:131)
                 if (kMam && !(depth >= L && top != bot)) { prev_top = top; prev_bot = bot; }  // slamem.c:197-198, skipped by :131
                 // scan start of this attempt; a match that reaches it may be truncated: redo with a longer warm-up
+                // (without a slice this never fires, but compiling it out moves a register copy next to the record load
+                //  above -- an s_waitcnt between the loads of one trip, +1 ms: the instruction stream is checked, not assumed)
                 uint32_t e = (attempt >= kMaxAttempt || qlen - b_pos < (kWarmUp << (2u * attempt))) ? qlen
                                                                                                  : b_pos + (kWarmUp << (2u * attempt));
                 if (in_slice && e < qlen && (uint32_t)depth == e - j) {
