@@ -1061,7 +1061,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
             const uint2* a2 = nullptr;
             const uint2* a3 = nullptr;    // (SKQ only: a third 8-byte word)
             const uint8_t* a4 = nullptr;  // (SKQ only: the item's flag)
-            uint32_t pk_bits = 0, pk_bit5 = 0, pk_mask = 0, flag8 = 0;  // (SKP only: bit positions of the probes, which exist)
+            uint32_t pk_bits = 0, pk_mask = 0, flag8 = 0;  // (SKP only: bit positions of the probes, which exist)
             uint4 rt = make_uint4(0, 0, 0, 0);
             uint2 rb0 = make_uint2(0, 0), rb1 = rb0;
             bool want_rec = false;
@@ -1106,31 +1106,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                 a4 = A.item_flags + g;
                 if (kStats) n_skq++;
             } else if (kSkip && st == ST_SKP) {
-                // the probed k-mers: starts p-(k-1), p-(k-1)+s1, ... and p itself -- every one contains p, consecutive starts
-                // are at most s1 = min_len-k+1 apart, so every min_len-mer window that covers p contains one of them
-                // (the lane's 2-bit words wait in LDS since the last trip: a k-mer of 16 letters or fewer lies in two
-                //  consecutive 32-bit halves)
-                const uint32_t y0 = j - kd;
-                const uint32_t o0 = y0 & 31u;
-#pragma unroll
-                for (uint32_t i = 0; i < 6u; i++) {
-                    if (i < sknp) {
-                        uint32_t d = i * sks1;
-                        if (d > kd - 1u) d = kd - 1u;
-                        const uint32_t o = o0 + d;  // letter offset from the start of the first word (< 32 + k)
-                        const uint32_t h0 = lds_q2[o >> 4][threadIdx.x], h1 = lds_q2[(o >> 4) + 1u][threadIdx.x];
-                        const uint32_t sh = 2u * (o & 15u);
-                        const uint32_t v32 = sh ? (h0 << sh) | (h1 >> (32u - sh)) : h0;
-                        const uint32_t key = v32 >> (32u - 2u * kd);
-                        if (i < 5u) pk_bits |= (key & 63u) << (6u * i); else pk_bit5 = key & 63u;
-                        pk_mask |= 1u << i;
-                        const uint2 wv = *reinterpret_cast<const uint2*>(ix.kbits + (key >> 6));
-                        if (i == 0) { kb.a.x = wv.x; kb.a.y = wv.y; } else if (i == 1) { kb.a.z = wv.x; kb.a.w = wv.y; }
-                        else if (i == 2) { kb.b.x = wv.x; kb.b.y = wv.y; } else if (i == 3) { kb.b.z = wv.x; kb.b.w = wv.y; }
-                        else if (i == 4) { kb.c.x = wv.x; kb.c.y = wv.y; } else { kb.c.z = wv.x; kb.c.w = wv.y; }
-                        if (kStats) n_skp++;
-                    }
-                }
+                // (the probes are issued further down, beside the FM blocks: they land in the same registers)
             } else {
                 want_rec = true;  // ST_REC, ST_FLUSH
             }
@@ -1161,6 +1137,37 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                 if (kStats) { n_kt += bt != tag_t; n_kb += bb != bt; }
                 if (bt != tag_t) { kt = load_blk(ix.fm, bt); tag_t = bt; }
                 if (bb != bt) kb = load_blk(ix.fm, bb);
+            } else if (kSkip && st == ST_SKP) {
+                // the probed k-mers: starts p-(k-1), p-(k-1)+s1, ... and p itself -- every one contains p, consecutive starts
+                // are at most s1 = min_len-k+1 apart, so every min_len-mer window that covers p contains one of them
+                // (the lane's 2-bit words wait in LDS since the last trip: a k-mer of 16 letters or fewer lies in two
+                //  consecutive 32-bit halves)
+                const uint32_t y0 = j - kd;
+                const uint32_t o0 = y0 & 31u;
+                // (at most four probes -- the host side checks: their words land in the record slots rt / rb0 / rb1, which
+                //  this state does not use otherwise, so they share no register with the FM blocks of the other lanes)
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; i++) {
+                    if (i < sknp) {
+                        uint32_t d = i * sks1;
+                        if (d > kd - 1u) d = kd - 1u;
+                        const uint32_t o = o0 + d;  // letter offset from the start of the first word (< 32 + k)
+                        const uint32_t h0 = lds_q2[o >> 4][threadIdx.x], h1 = lds_q2[(o >> 4) + 1u][threadIdx.x];
+                        const uint32_t sh = 2u * (o & 15u);
+                        const uint32_t v32 = sh ? (h0 << sh) | (h1 >> (32u - sh)) : h0;
+                        const uint32_t key = v32 >> (32u - 2u * kd);
+                        pk_bits |= (key & 63u) << (6u * i);
+                        pk_mask |= 1u << i;
+                        const uint2 wv = *reinterpret_cast<const uint2*>(ix.kbits + (key >> 6));
+                        if (i == 0) { rt.x = wv.x; rt.y = wv.y; } else if (i == 1) { rt.z = wv.x; rt.w = wv.y; }
+                        else if (i == 2) rb0 = wv; else rb1 = wv;
+                        if (kStats) n_skp++;
+                    }
+                }
+            }
+            if (kSkip) {  // (as for kMam below: nothing of these is touched before every load of the trip is out)
+                asm volatile("" : "+v"(rt.x), "+v"(rt.y), "+v"(rt.z), "+v"(rt.w), "+v"(flag8));
+                asm volatile("" : "+v"(rb0.x), "+v"(rb0.y), "+v"(rb1.x), "+v"(rb1.y));
             }
             if (kMam) {
                 // keeps the compiler from copying parts of the record out of its load's registers right behind the load (an
@@ -1221,13 +1228,10 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                 }
             } else if (kSkip && st == ST_SKP) {
                 uint32_t present = 0;
-                present |= (pk_mask >> 0) & (uint32_t)(u64_of(kb.a.x, kb.a.y) >> ((pk_bits >> 0) & 63u));
-                present |= (pk_mask >> 1) & (uint32_t)(u64_of(kb.a.z, kb.a.w) >> ((pk_bits >> 6) & 63u));
-                present |= (pk_mask >> 2) & (uint32_t)(u64_of(kb.b.x, kb.b.y) >> ((pk_bits >> 12) & 63u));
-                present |= (pk_mask >> 3) & (uint32_t)(u64_of(kb.b.z, kb.b.w) >> ((pk_bits >> 18) & 63u));
-                present |= (pk_mask >> 4) & (uint32_t)(u64_of(kb.c.x, kb.c.y) >> ((pk_bits >> 24) & 63u));
-                // (a sixth probe's bit position does not fit pk_bits: kept apart)
-                present |= (pk_mask >> 5) & (uint32_t)(u64_of(kb.c.z, kb.c.w) >> (pk_bit5 & 63u));
+                present |= (pk_mask >> 0) & (uint32_t)(u64_of(rt.x, rt.y) >> ((pk_bits >> 0) & 63u));
+                present |= (pk_mask >> 1) & (uint32_t)(u64_of(rt.z, rt.w) >> ((pk_bits >> 6) & 63u));
+                present |= (pk_mask >> 2) & (uint32_t)(u64_of(rb0.x, rb0.y) >> ((pk_bits >> 12) & 63u));
+                present |= (pk_mask >> 3) & (uint32_t)(u64_of(rb1.x, rb1.y) >> ((pk_bits >> 18) & 63u));
                 if (present & 1u) { dmis = true; st = ST_DEND; }  // one of the k-mers occurs: the normal route
                 else {
                     // certified.  The position in front of the disagreeing letter is left-maximal: its one row (text position
@@ -1937,14 +1941,14 @@ int SearchJob::tables(hipStream_t stream) {
         static const bool env_jump = [] { const char* v = getenv("SLAMEM_KJUMP_USE"); return !(v && atoi(v) == 0); }();
         A.use_jump = env_jump ? 1u : 0u;
         {   // skipping the chance matches behind a disagreeing letter (K8 states SKV / SKQ / SKP): needs the occurrence
-            // bitmap, min_len >= its k, at most 6 probes per letter, and a class that can vouch for a depth of min_len - 1
+            // bitmap, min_len >= its k, at most 4 probes per letter (their words go into the record slots), and a class that can vouch for a depth of min_len - 1
             static const bool env_skip = [] { const char* v = getenv("SLAMEM_SKIP"); return v && atoi(v) != 0; }();  // off unless asked for
             const uint32_t kd = idx->view.kbits ? idx->view.kbits_k : 0u;
             A.skip_w = 0;
             if (env_skip && kd && min_len >= kd && min_len >= 9u && min_len < 0x10000u && A.direct_min_depth >= 0) {
                 const uint32_t s1 = min_len - kd + 1u;
                 const uint32_t nprobes = (kd - 1u + s1 - 1u) / s1 + 1u;  // starts p-(k-1), +s1, ..., p
-                if (nprobes <= 6u && depth_class((int)min_len - 1) >= 1u) {
+                if (nprobes <= 4u && depth_class((int)min_len - 1) >= 1u) {
                     A.skip_w = min_len - 1u;
                     A.skip_s1 = s1;
                     A.pq2 = reinterpret_cast<const uint64_t*>(ws + w.off_pq2);
