@@ -797,13 +797,19 @@ __global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A, bool long_on
     // grid-stride over the list (the table above is set up once per block)
     for (uint64_t e = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kLanes; e < count; e += stride) {
     const uint64_t item = (!long_only && A.work_ids) ? (uint64_t)A.work_ids[e] : e;
-    const ItemDesc d = A.items[item];
+    // the descriptor and the strand's place in the packed copy in ONE round trip (as a struct load the length came first,
+    // for the test below, and the rest a round trip later: five dependent memory phases per item, now three)
+    uint4 dv = *reinterpret_cast<const uint4*>(A.items + item);
+    uint64_t pk_word = A.item_pk[item];
+    asm volatile("" : "+v"(dv.x), "+v"(dv.y), "+v"(dv.z), "+v"(dv.w), "+v"(pk_word));
+    ItemDesc d;
+    d.base = u64_of(dv.x, dv.y); d.len = dv.z; d.slice_rev = dv.w;
     if (long_only != (d.len > kSliceLen)) continue;
     const uint32_t rev = d.slice_rev >> 31, sl = d.slice_rev & 0x7FFFFFFFu;
     const uint32_t a = sl * kSliceLen;
     const uint32_t b = d.len - a < kSliceLen ? d.len : a + kSliceLen;
-    uint64_t* out = A.pq_out + A.item_pk[item];
-    uint32_t* out2 = A.pq2_out ? reinterpret_cast<uint32_t*>(A.pq2_out + (A.item_pk[item] >> 1)) : nullptr;
+    uint64_t* out = A.pq_out + pk_word;
+    uint32_t* out2 = A.pq2_out ? reinterpret_cast<uint32_t*>(A.pq2_out + (pk_word >> 1)) : nullptr;
     const uint32_t w0 = a >> 4;
     // the last slice also writes the zero padding up to the strand's 16-byte-aligned end
     const uint32_t w1 = b == d.len ? 2u * ((d.len + 31u) >> 5) : (b >> 4);
@@ -1603,15 +1609,32 @@ __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__
                                                       slamem_mem* __restrict__ out) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nitems) return;
+    // three memory phases whatever the count (count + offset; the rows; their text positions), not two per MEM
     uint32_t cnt = counts[g];
-    if (cnt > kInlineMems) cnt = kInlineMems;
     uint64_t off = item_off[g];
-    for (uint32_t i = 0; i < cnt; i++) {
-        if (off + i >= capacity) return;
-        RawRow r = inl[g * kInlineMems + i];
-        // bit 31 of the length: `row` already is the text position (a MEM emitted from a direct run)
-        out[off + i] = slamem_mem{(r.len >> 31) ? r.row : sa[r.row], r.pos, r.len & 0x7FFFFFFFu};
-    }
+    asm volatile("" : "+v"(cnt), "+v"(off));
+    if (cnt > kInlineMems) cnt = kInlineMems;
+    if (cnt == 0u) return;
+    static_assert(kInlineMems == 4, "k_place_inline is written for four inline slots");
+    const RawRow* in = inl + g * kInlineMems;
+    const RawRow none = {0u, 0u, 0x80000000u};  // (bit 31: no suffix-array read)
+    RawRow r0 = in[0], r1 = none, r2 = none, r3 = none;
+    if (cnt > 1u) r1 = in[1];
+    if (cnt > 2u) r2 = in[2];
+    if (cnt > 3u) r3 = in[3];
+    asm volatile("" : "+v"(r0.row), "+v"(r0.pos), "+v"(r0.len), "+v"(r1.row), "+v"(r1.pos), "+v"(r1.len));
+    asm volatile("" : "+v"(r2.row), "+v"(r2.pos), "+v"(r2.len), "+v"(r3.row), "+v"(r3.pos), "+v"(r3.len));
+    // bit 31 of the length: `row` already is the text position (a MEM emitted from a direct run)
+    uint32_t p0 = r0.row, p1 = r1.row, p2 = r2.row, p3 = r3.row;
+    if (!(r0.len >> 31)) p0 = sa[r0.row];
+    if (cnt > 1u && !(r1.len >> 31)) p1 = sa[r1.row];
+    if (cnt > 2u && !(r2.len >> 31)) p2 = sa[r2.row];
+    if (cnt > 3u && !(r3.len >> 31)) p3 = sa[r3.row];
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+    if (off < capacity) out[off] = slamem_mem{p0, r0.pos, r0.len & 0x7FFFFFFFu};
+    if (cnt > 1u && off + 1u < capacity) out[off + 1u] = slamem_mem{p1, r1.pos, r1.len & 0x7FFFFFFFu};
+    if (cnt > 2u && off + 2u < capacity) out[off + 2u] = slamem_mem{p2, r2.pos, r2.len & 0x7FFFFFFFu};
+    if (cnt > 3u && off + 3u < capacity) out[off + 3u] = slamem_mem{p3, r3.pos, r3.len & 0x7FFFFFFFu};
 }
 
 __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict__ key, const slamem_mem* __restrict__ raw,
