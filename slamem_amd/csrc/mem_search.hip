@@ -280,6 +280,18 @@ typedef QueryCursorT<32> QueryCursor;  // the search kernels (a 16-byte window s
 // a shift, sixteen more wait in registers, one aligned 16-byte load per 16 letters.  ~15 instructions per letter, where
 // the random-access cursor needs ~45 -- and the prefilter is bound by instruction issue (a wave64 VALU instruction
 // occupies its SIMD for four cycles).
+// 16-byte chunks of the query buffer that one block of K8a stages in LDS when the strands of its 256 items lie in a
+// span this short (128 reads of up to 160 letters): both strands of a read then cost one coalesced pass over its lines
+// instead of two scattered ones that the probes in between evict from L2 (-40 M of 417 M requests on the benchmark
+// batch).  20 KB, not more: K8a needs its 7-8 waves per SIMD to keep the memory system's request queue full (with
+// 40 KB -- four blocks per CU -- it takes 10.9 ms instead of 7.5).  0 = never stage
+#ifndef SLAMEM_PF_STAGE_CHUNKS
+#define SLAMEM_PF_STAGE_CHUNKS 1280
+#endif
+constexpr uint32_t kPfStageChunks = SLAMEM_PF_STAGE_CHUNKS;
+
+// kLds: the chunks come from `stage` (LDS copy of chunks [lo, lo+n) of the buffer) instead of global memory
+template <bool kLds>
 struct QueryStream {
     const uint4* p;          // next 16-byte chunk (forward strand: ascending addresses, reverse strand: descending)
     uint64_t cur, n1, n2, n3;  // bytes being consumed / the 8-byte pieces that follow, in consumption order
@@ -288,22 +300,35 @@ struct QueryStream {
     uint32_t chunks;         // 16-byte chunks not loaded yet that still overlap the record
     uint32_t rev;
     uint32_t loads;          // 16-byte loads issued (read by the diagnostic instantiation only; dead code otherwise)
-    __device__ __forceinline__ void init(const uint64_t* words, uint64_t base, uint32_t len, uint32_t r, uint32_t start) {
+    const uint4* stage;      // kLds only
+    int32_t pi;              // kLds only: index in `stage` of the next chunk
+    __device__ __forceinline__ uint4 chunk(int off) const {
+        if constexpr (kLds) return stage[pi + off];
+        else return p[off];
+    }
+    __device__ __forceinline__ void advance(int by) {
+        if constexpr (kLds) pi += by;
+        else p += by;
+    }
+    __device__ __forceinline__ void init(const uint64_t* words, uint64_t base, uint32_t len, uint32_t r, uint32_t start,
+                                         const uint4* lds = nullptr, uint64_t lds_first_chunk = 0) {
         rev = r;
         loads = 1;
         uint64_t addr = base + (r ? (uint64_t)(len - 1u - start) : (uint64_t)start);  // byte offset of the first letter
         p = reinterpret_cast<const uint4*>(words) + (addr >> 4);
+        stage = lds;
+        pi = (int32_t)((addr >> 4) - lds_first_chunk);
         chunks = r ? (uint32_t)((addr >> 4) - (base >> 4)) : (uint32_t)(((base + len - 1u) >> 4) - (addr >> 4));
-        uint4 a = *p;
+        uint4 a = chunk(0);
         uint64_t lo = u64_of(a.x, a.y), hi = u64_of(a.z, a.w);
         uint32_t o = (uint32_t)(addr & 15ull);
         n1 = n2 = n3 = 0;
         if (!r) {
-            p++;
+            advance(1);
             if (o < 8u) { cur = lo >> (8u * o); left = 8u - o; n1 = hi; nq = 1; }
             else { cur = hi >> (8u * (o - 8u)); left = 16u - o; nq = 0; }
         } else {  // the letters come from descending addresses: take them from the top of the register
-            p--;
+            advance(-1);
             if (o >= 8u) { cur = hi << (8u * (15u - o)); left = o - 7u; n1 = lo; nq = 1; }
             else { cur = lo << (8u * (7u - o)); left = o + 1u; nq = 0; }
         }
@@ -314,12 +339,12 @@ struct QueryStream {
             if (nq) { cur = n1; n1 = n2; n2 = n3; nq--; }
             else {
                 // 32 bytes at a time when two more chunks overlap the record (a chunk that does not may lie behind the buffer)
-                uint4 a = *p, b = make_uint4(0, 0, 0, 0);
+                uint4 a = chunk(0), b = make_uint4(0, 0, 0, 0);
                 const bool two = chunks >= 2u;
-                if (two) b = rev ? p[-1] : p[1];
+                if (two) b = rev ? chunk(-1) : chunk(1);
                 uint64_t alo = u64_of(a.x, a.y), ahi = u64_of(a.z, a.w), blo = u64_of(b.x, b.y), bhi = u64_of(b.z, b.w);
-                if (!rev) { cur = alo; n1 = ahi; n2 = blo; n3 = bhi; p += two ? 2 : 1; }
-                else { cur = ahi; n1 = alo; n2 = bhi; n3 = blo; p -= two ? 2 : 1; }
+                if (!rev) { cur = alo; n1 = ahi; n2 = blo; n3 = bhi; advance(two ? 2 : 1); }
+                else { cur = ahi; n1 = alo; n2 = bhi; n3 = blo; advance(two ? -2 : -1); }
                 nq = two ? 3u : 1u;
                 chunks -= two ? 2u : 1u;
                 loads += two ? 2u : 1u;
@@ -1480,16 +1505,10 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
 // "absent": no false negatives) the item cannot emit anything and K8 skips it.  Windows holding an N count as
 // present.  One lane per item, early exit at the first present window (the matching strand of a read exits after
 // a few probes; the other strand pays ~ len/s probes instead of a full scan).
-template <bool kStats>
-__global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __restrict__ alive) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = g < A.num_items;
-    if (!kStats && !live) return;
-    if (!live) g = 0;  // diagnostic instantiation: idle lanes stay for the wave reduction at the end (they store nothing)
-    uint32_t n_probe = 0, n_qload = 0;
+template <bool kStats, bool kLds>
+__device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const ItemDesc& d, const uint4* stage,
+                                                  uint64_t stage_first, uint32_t& n_probe, uint32_t& n_qload) {
     const IndexView& ix = A.ix;
-    ItemDesc d = A.items[g];
-    if (!live) d.len = 0;
     const uint32_t k = ix.kfilter_k, L = A.min_len;
     const uint32_t s = L - k + 1u;
     uint32_t sl = d.slice_rev & 0x7FFFFFFFu;
@@ -1509,7 +1528,7 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
         const uint32_t p0 = (a + s1 - 1u) / s1 * s1;
         uint32_t pmax = (uint32_t)(((uint64_t)b + s1 - 2u < (uint64_t)(d.len - k1)) ? b + s1 - 2u : d.len - k1);
         if (p0 <= pmax) {
-            QueryStream qs;
+            QueryStream<kLds> qs;
             // third level: if the MEM is at least k+2 long it also contains the (k+2)-mer that starts at max(m, s'-2), where
             // s' is the start of the k-mer above -- one of s'-2, s'-1, s'.  For L == k+2 that makes the test exact up to the
             // filter's false positives: a strand survives only if it really shares L letters with the text.
@@ -1520,7 +1539,7 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
             uint64_t km = 0;
             uint32_t run = 0, confirm = 0, confirm2 = 0;
             uint32_t x = p0 >= 4u ? p0 - 4u : 0u;
-            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, x);
+            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, x, stage, stage_first);
             uint64_t xe64 = (uint64_t)pmax + k1 + 1u + (three ? 2u : 0u);
             const uint32_t xend = xe64 > (uint64_t)d.len - 1u ? d.len - 1u : (uint32_t)xe64;
             uint32_t wend = p0 + k1 - 1u;  // letter at which the next probed (k-2)-mer window ends
@@ -1571,8 +1590,8 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
         // last window start that can serve this slice
         const uint32_t pmax = (uint32_t)(((uint64_t)b + s - 2u < (uint64_t)(d.len - k)) ? b + s - 2u : d.len - k);
         if (p0 <= pmax) {
-            QueryStream qs;
-            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, p0);
+            QueryStream<kLds> qs;
+            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, p0, stage, stage_first);
             const uint64_t mask = (1ull << (2u * k)) - 1ull;
             uint64_t km = 0;
             uint32_t run = 0, wend = p0 + k - 1u;               // letter at which the next probed window ends
@@ -1593,6 +1612,48 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
             }
             if (kStats) n_qload += qs.loads;
         }
+    }
+    return res;
+}
+
+template <bool kStats>
+__global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __restrict__ alive) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = g < A.num_items;
+    if (!live) g = 0;  // idle lanes stay for the block's barriers and the diagnostic reduction (they store nothing)
+    uint32_t n_probe = 0, n_qload = 0;
+    ItemDesc d = A.items[g];
+    if (!live) d.len = 0;
+    uint8_t res;
+    if (kPfStageChunks != 0u) {
+        // the 16-byte chunks [lo, hi) of the query buffer that the block's strands lie in
+        __shared__ uint4 s_stage[kPfStageChunks ? kPfStageChunks : 1u];
+        __shared__ unsigned long long s_lo[4], s_hi[4];
+        unsigned long long lo = d.len ? d.base >> 4 : ~0ull, hi = d.len ? ((d.base + d.len - 1u) >> 4) + 1ull : 0ull;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if ((threadIdx.x & 63u) == 0u) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            lo = s_lo[w] < lo ? s_lo[w] : lo;
+            hi = s_hi[w] > hi ? s_hi[w] : hi;
+        }
+        if (hi > lo && hi - lo <= (unsigned long long)kPfStageChunks) {  // (the same for every lane of the block)
+            const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + lo;
+            const uint32_t n = (uint32_t)(hi - lo);
+            for (uint32_t i = threadIdx.x; i < n; i += 256u) s_stage[i] = src[i];
+            __syncthreads();
+            res = prefilter_item<kStats, true>(A, d, s_stage, lo, n_probe, n_qload);
+        } else {
+            res = prefilter_item<kStats, false>(A, d, nullptr, 0, n_probe, n_qload);
+        }
+    } else {
+        res = prefilter_item<kStats, false>(A, d, nullptr, 0, n_probe, n_qload);
     }
     if (live) alive[g] = res;
     if (kStats) {
