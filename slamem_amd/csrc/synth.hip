@@ -166,6 +166,43 @@ __global__ void __launch_bounds__(256) k_gather_modes(const uint4* __restrict__ 
     if (acc == 0x9999999999999999ull) sink[0] = acc;
 }
 
+// What several small reads of ONE random line cost (an in-line cascade of filter tests): every lane walks a chain of
+// random lines of kLineBytes and reads kLoads dwords at hashed offsets inside each, all issued before the first is used.
+template <int kLoads, int kLineBytes>
+__global__ void __launch_bounds__(256) k_gather_inline(const uint32_t* __restrict__ table, uint64_t nlines, uint32_t iters,
+                                                       uint64_t* __restrict__ sink) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s = draw(0x999u, g);
+    uint64_t acc = 0;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t* p = table + (s % nlines) * (kLineBytes / 4);
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < kLoads; k++) v ^= p[(uint32_t)(s >> (8 + 5 * k)) & (kLineBytes / 4 - 1)];
+        acc += v;
+        s = draw(s + v, it);
+    }
+    if (acc == 0x9999999999999999ull) sink[0] = acc;
+}
+
+extern "C" int slamem_gather_inline(const void* table_dev, uint64_t table_bytes, uint64_t lanes, uint32_t iters, int loads,
+                                    int line_bytes, void* sink_dev, void* stream) {
+    dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t* t = (const uint32_t*)table_dev;
+    uint64_t* sk = (uint64_t*)sink_dev;
+#define GI(L, B) hipLaunchKernelGGL((k_gather_inline<L, B>), grid, block, 0, st, t, table_bytes / B, iters, sk)
+    if (loads == 1 && line_bytes == 64) GI(1, 64);
+    else if (loads == 3 && line_bytes == 64) GI(3, 64);
+    else if (loads == 9 && line_bytes == 64) GI(9, 64);
+    else if (loads == 1 && line_bytes == 128) GI(1, 128);
+    else if (loads == 3 && line_bytes == 128) GI(3, 128);
+    else if (loads == 9 && line_bytes == 128) GI(9, 128);
+    else return -1;
+#undef GI
+    return (int)hipGetLastError();
+}
+
 extern "C" int slamem_gather_modes(const void* table_dev, uint64_t nblk, uint64_t lanes, uint32_t iters, int mode,
                                    void* sink_dev, void* stream) {
     dim3 grid((unsigned)((lanes + 255) / 256)), block(256);

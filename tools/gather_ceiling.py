@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calibrate", action="store_true", help="one launch per table size only (for --pmc runs)")
     ap.add_argument("--modes", action="store_true", help="address-path experiment: lane / quad / row cooperative reads")
+    ap.add_argument("--inline", action="store_true", help="several dword reads inside one random 64/128-byte line per step")
     a = ap.parse_args()
     S = capi.synth_lib()
     S.slamem_gather_bench.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
@@ -28,6 +29,26 @@ def main():
     dev = torch.device("cuda:0")
     sink = torch.zeros(8, dtype=torch.int64, device=dev)
     lanes = 256 * 32 * 64 * 4  # 4 full waves of the chip
+    if a.inline:
+        S.slamem_gather_inline.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        for mb in (800, 1600, 6400):
+            table = torch.randint(0, 2 ** 31, (mb * (1 << 20) // 4,), dtype=torch.int32, device=dev)
+            for occupancy_lanes in (lanes, lanes // 2):
+                for line in (64, 128):
+                    for loads in (1, 3, 9):
+                        iters = 64
+                        assert S.slamem_gather_inline(table.data_ptr(), mb << 20, occupancy_lanes, 4, loads, line, sink.data_ptr(), None) == 0
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        S.slamem_gather_inline(table.data_ptr(), mb << 20, occupancy_lanes, iters, loads, line, sink.data_ptr(), None)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ms = e0.elapsed_time(e1)
+                        print(json.dumps({"table_MB": mb, "lanes": occupancy_lanes, "line_bytes": line, "dword_loads_per_line": loads,
+                                          "ms": round(ms, 3), "Glines_per_s": round(occupancy_lanes * iters / ms / 1e6, 2)}), flush=True)
+            del table
+        return
     for mb in (2, 16, 50, 150, 1750, 8000):
         nblk = mb * (1 << 20) // 64
         table = torch.randint(0, 2 ** 31, (nblk * 16,), dtype=torch.int32, device=dev)
