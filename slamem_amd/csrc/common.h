@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 10;  // 10: k-mer occurrence bitmap; 9: K-mer jump table; 8: text-ordered groups + parent records
+constexpr uint32_t kArenaVersion = 11;  // 11: presence filter in lines keyed by the (k-2)-mer; 10: k-mer occurrence bitmap; 9: K-mer jump table; 8: text-ordered groups + parent records
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -121,8 +121,10 @@ struct IndexView {
     uint32_t kfilter_k;
 };
 
-// Presence filter: one 64-bit word per k-mer hash, two bits per k-mer inside that word (a blocked Bloom filter:
-// one memory access per query, false-positive rate ~ (2 * distinct k-mers / bits)^2).
+// Presence filter: a blocked Bloom filter in 64-byte lines of eight words.  The line is chosen by a (k-2)-mer of the
+// text; it holds that (k-2)-mer and every k-mer and (k+2)-mer of the text that contains it (three and five of them),
+// each as three bits of one word.  A cascade of tests (k-2 letters, then the k-mers around them, then the (k+2)-mers
+// around those) therefore reads ONE line from HBM: the confirmations hit the cache.
 __host__ __device__ inline uint64_t kfilter_hash(uint64_t kmer) {
     kmer ^= kmer >> 33;
     kmer *= 0xff51afd7ed558ccdull;
@@ -135,7 +137,14 @@ __host__ __device__ inline uint64_t kfilter_hash(uint64_t kmer) {
 // ones are hashed with these salts
 constexpr uint64_t kFilterShortSalt = 0x9E3779B97F4A7C15ull;
 constexpr uint64_t kFilterLongSalt = 0xD6E8FEB86659FD93ull;
-__host__ __device__ inline uint64_t kfilter_bits(uint64_t h) { return (1ull << ((h >> 52) & 63u)) | (1ull << ((h >> 58) & 63u)); }
+__host__ __device__ inline uint64_t kfilter_bits(uint64_t h) {
+    return (1ull << ((h >> 46) & 63u)) | (1ull << ((h >> 52) & 63u)) | (1ull << ((h >> 58) & 63u));
+}
+__host__ __device__ inline uint64_t kfilter_word(uint64_t h) { return (h >> 43) & 7ull; }  // word of the line
+// first word of the line of a (k-2)-mer whose salted hash is h (log2_words: 64-bit words of the whole filter)
+__host__ __device__ inline uint64_t kfilter_line(uint64_t h, uint32_t log2_words) {
+    return (h & ((1ull << (log2_words - 3u)) - 1ull)) << 3;
+}
 
 // Raw record written by the search kernel before the per-block compaction (K9).
 struct RawKey { uint32_t block; uint32_t k; };

@@ -208,33 +208,48 @@ __global__ void __launch_bounds__(256) k_rank_samples(const uint4* __restrict__ 
 
 // ------------------------------------------------------------------------------------------
 // K1b: k-mer presence filter (not in the reference: lets the search skip strands that share no k-mer with the
-// text, e.g. the wrong strand of every read).  One lane per text position; windows containing N are not entered
-// (a query window with N is treated as present, so N == N matches are never filtered out).
+// text, e.g. the wrong strand of every read).  One lane per text position p: the (k-2)-mer that starts there picks
+// the line, and the lane enters it, the k-mers that start at p-2..p and the (k+2)-mers that start at p-4..p -- all the
+// k- and (k+2)-mers of the text that contain it.  Windows containing N are not entered (a query window with N is
+// treated as present, so N == N matches are never filtered out).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
                                                        uint32_t log2_words, unsigned long long* __restrict__ filter) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i + (k - 2u) > n) return;
-    const uint64_t wmask = (1ull << log2_words) - 1ull;
-    const uint32_t kmax = k + 2u <= 32u ? k + 2u : k;
-    uint64_t km = 0;
-    for (uint32_t d = 0; d < kmax && i + d < n; d++) {
-        uint32_t c = nibble_at(pk, i + d);
-        if (c < 2u) return;  // N inside the window
-        km = (km << 2) | (uint64_t)(c - 2u);
-        if (d + 1u == k - 2u) {  // the (k-2)-mer that starts here (first level of the prefilter)
-            uint64_t h = kfilter_hash(km ^ kFilterShortSalt);
-            atomicOr(&filter[h & wmask], (unsigned long long)kfilter_bits(h));
-        }
-        if (d + 1u == k) {
-            uint64_t h = kfilter_hash(km);
-            atomicOr(&filter[h & wmask], (unsigned long long)kfilter_bits(h));
-        }
-        if (d + 1u == k + 2u) {  // third level (k + 2 <= 32: it fits the 64-bit rolling value)
-            uint64_t h = kfilter_hash(km ^ kFilterLongSalt);
-            atomicOr(&filter[h & wmask], (unsigned long long)kfilter_bits(h));
-        }
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k1 = k - 2u;
+    if (p + k1 > n) return;
+    // the letters [p-4, p+k1+4) as 2-bit values, first letter in the highest bits; ok: bit per letter, set when the
+    // letter exists and is not N
+    const uint32_t wn = k1 + 8u;
+    uint64_t w = 0, ok = 0;
+    for (uint32_t d = 0; d < wn; d++) {
+        const int64_t t = (int64_t)p - 4 + (int64_t)d;
+        uint32_t c = (t >= 0 && t < (int64_t)n) ? nibble_at(pk, (uint64_t)t) : 0u;
+        w = (w << 2) | (uint64_t)(c >= 2u ? c - 2u : 0u);
+        ok = (ok << 1) | (uint64_t)(c >= 2u);
     }
+    auto piece = [&](uint32_t first, uint32_t len, uint64_t& v) {  // letters [first, first+len) of the window
+        const uint32_t sh = wn - first - len;
+        const uint64_t all = (1ull << len) - 1ull;
+        v = (w >> (2u * sh)) & (len >= 32u ? ~0ull : (1ull << (2u * len)) - 1ull);
+        return ((ok >> sh) & all) == all;
+    };
+    uint64_t v;
+    if (!piece(4u, k1, v)) return;
+    uint64_t h = kfilter_hash(v ^ kFilterShortSalt);
+    unsigned long long* line = filter + kfilter_line(h, log2_words);
+    atomicOr(&line[kfilter_word(h)], (unsigned long long)kfilter_bits(h));
+    for (uint32_t o = 2u; o <= 4u; o++)
+        if (piece(o, k, v)) {
+            h = kfilter_hash(v);
+            atomicOr(&line[kfilter_word(h)], (unsigned long long)kfilter_bits(h));
+        }
+    if (k + 2u <= 32u)  // third level (it fits the 64-bit rolling value of the search)
+        for (uint32_t o = 0u; o <= 4u; o++)
+            if (piece(o, k + 2u, v)) {
+                h = kfilter_hash(v ^ kFilterLongSalt);
+                atomicOr(&line[kfilter_word(h)], (unsigned long long)kfilter_bits(h));
+            }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,18 +747,19 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     hdr.off_rec = off;   off = align_up(off + (R + 1) * sizeof(RowRec), 256);
     hdr.off_sa = off;    off = align_up(off + R * 4, 256);
     hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
-    {   // k-mer presence filter: 64 bits per text character (rounded up to a power of two of words), n >= k only
+    {   // k-mer presence filter: 128 bits per text character (rounded up to a power of two of words), n >= k only
         const char* kf = getenv("SLAMEM_KFILTER");
         // k grows with the text: a random k-mer occurs with probability ~ n / 4^k, which must stay well below
         // 1 / (probes per strand) for the filter to discriminate; k = ceil(log4 n) + 4 keeps it near 0.2 %
         uint32_t kf_k = 4;
         for (uint64_t v = 1; v < (uint64_t)n; v <<= 2) kf_k++;
         if (kf_k < 12) kf_k = 12;
-        if (kf_k > 31) kf_k = 31;
+        if (kf_k > 26) kf_k = 26;  // (never reached: n < 2^32 gives k <= 20; the build packs k+6 letters into 64 bits)
         bool want = !(kf && atoi(kf) == 0) && n >= kf_k;
         if (want) {
+            // two 64-bit words per text position (nine entries of three bits each per position: a sixth of the bits set)
             uint32_t lg = 10;
-            while ((1ull << lg) < (uint64_t)n && lg < 32) lg++;
+            while ((1ull << lg) < 2ull * (uint64_t)n && lg < 32) lg++;
             hdr.off_kfilter = off;
             hdr.kfilter_log2 = lg;
             hdr.kfilter_k = kf_k;

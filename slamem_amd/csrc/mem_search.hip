@@ -1515,7 +1515,6 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
     uint32_t a = sl * kSliceLen;
     uint32_t b = d.len - a < kSliceLen ? d.len : a + kSliceLen;
     uint8_t res = 0;
-    const uint64_t wmask = (1ull << ix.kfilter_log2) - 1ull;
     if (d.len >= k && d.len - a >= 1u && s <= 6u) {
         // Two levels (short minimum lengths, where one level would probe almost every window): a MEM >= L that starts
         // in [a,b) contains a (k-2)-mer window starting at a multiple of s1 = L-(k-2)+1 inside [a, b+s1-2], AND -- if m
@@ -1538,6 +1537,10 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
             const uint64_t maskk = (1ull << (2u * k)) - 1ull, mask1 = (1ull << (2u * k1)) - 1ull;
             uint64_t km = 0;
             uint32_t run = 0, confirm = 0, confirm2 = 0;
+            // line of the (k-2)-mer whose hit started the confirmations under way (every k-mer / (k+2)-mer tested behind
+            // it contains that (k-2)-mer, so the build entered it there), and of the one behind the (k+2)-mer tests
+            const uint64_t* line1 = ix.kfilter;
+            const uint64_t* line2 = ix.kfilter;
             uint32_t x = p0 >= 4u ? p0 - 4u : 0u;
             qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, x, stage, stage_first);
             uint64_t xe64 = (uint64_t)pmax + k1 + 1u + (three ? 2u : 0u);
@@ -1554,7 +1557,8 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
                     else {
                         uint64_t h = kfilter_hash((km & mask1) ^ kFilterShortSalt), bits = kfilter_bits(h);
                         if (kStats) n_probe++;
-                        if ((ix.kfilter[h & wmask] & bits) == bits) confirm = 3;  // k-mers ending at x, x+1, x+2
+                        line1 = ix.kfilter + kfilter_line(h, ix.kfilter_log2);  // the confirmations are in this line too
+                        if ((line1[kfilter_word(h)] & bits) == bits) confirm = 3;  // k-mers ending at x, x+1, x+2
                     }
                 }
                 if (confirm && !res) {
@@ -1563,9 +1567,8 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
                         if (run < k) res = 1;
                         else {
                             uint64_t h = kfilter_hash(km & maskk), bits = kfilter_bits(h);
-                            if (kStats) n_probe++;
-                        if ((ix.kfilter[h & wmask] & bits) == bits) {
-                                if (three) confirm2 = 3;        // (k+2)-mers ending at x, x+1, x+2
+                            if ((line1[kfilter_word(h)] & bits) == bits) {
+                                if (three) { confirm2 = 3; line2 = line1; }  // (k+2)-mers ending at x, x+1, x+2
                                 else res = 1;
                             }
                         }
@@ -1577,8 +1580,7 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
                         if (run < k + 2u) res = 1;
                         else {
                             uint64_t h = kfilter_hash(km ^ kFilterLongSalt), bits = kfilter_bits(h);
-                            if (kStats) n_probe++;
-                        if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
+                            if ((line2[kfilter_word(h)] & bits) == bits) res = 1;
                         }
                     }
                 }
@@ -1604,9 +1606,11 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
                     wend += s;
                     if (run < k) res = 1;                       // holds an N: cannot be ruled out
                     else {
+                        // the k-mer is in the line of each (k-2)-mer it contains: look in that of its first k-2 letters
+                        const uint64_t* line = ix.kfilter + kfilter_line(kfilter_hash((km >> 4) ^ kFilterShortSalt), ix.kfilter_log2);
                         uint64_t h = kfilter_hash(km), bits = kfilter_bits(h);
                         if (kStats) n_probe++;
-                        if ((ix.kfilter[h & wmask] & bits) == bits) res = 1;
+                        if ((line[kfilter_word(h)] & bits) == bits) res = 1;
                     }
                 }
             }

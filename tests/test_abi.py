@@ -88,7 +88,7 @@ def _arena_header(n=100_000, num_n=3, with_filter=True):
     off_kj = off; off = al(off + (8 << (2 * kj)))
     kb = 11
     off_kb = off; off = al(off + ((1 << (2 * kb)) >> 3))
-    fields = dict(magic_lo=0x4D414C53, magic_hi=0x58494845, version=10, n=n, total_bytes=off, off_fm=off_fm, off_rec=off_rec,
+    fields = dict(magic_lo=0x4D414C53, magic_hi=0x58494845, version=11, n=n, total_bytes=off, off_fm=off_fm, off_rec=off_rec,
                   off_sa=off_sa, off_nrows=off_nrows, off_kfilter=off_kf, r0=off_tg, r1=off_pr, r2=off_kj, kjump_k=kj, C=0, kbits_k=kb, z=0, off_kbits=off_kb, kfilter_log2=lg if with_filter else 0,
                   kfilter_k=k if with_filter else 0, nblocks=nblocks, dollar_row=17, num_n=num_n, max_lcp=20, sort_rounds=1)
     order = ["magic_lo", "magic_hi", "version", "n", "total_bytes", "off_fm", "off_rec", "off_sa", "off_nrows", "off_kfilter",
@@ -113,7 +113,7 @@ def test_header_validation_rejects_corrupt_arenas(tmp_path):
     f2, pack2 = _arena_header(with_filter=False)
     assert L.slamem_index_validate_header(pack2(), 4096, f2["total_bytes"]) == 0
     assert L.slamem_index_validate_header(good, len(good), f["total_bytes"] - 1) == ERR_FORMAT       # truncated file
-    bad = [dict(magic_lo=1), dict(version=9), dict(kbits_k=17), dict(kbits_k=f['kbits_k'] + 1), dict(off_kbits=f['off_kbits'] + 32), dict(kjump_k=13), dict(kjump_k=8), dict(r2=f['r2'] + 64), dict(r0=f['r0'] + 8), dict(r1=f['r1'] + 4096), dict(r0=0), dict(n=0), dict(nblocks=f["nblocks"] - 1), dict(nblocks=f["nblocks"] + 1),
+    bad = [dict(magic_lo=1), dict(version=10), dict(kbits_k=17), dict(kbits_k=f['kbits_k'] + 1), dict(off_kbits=f['off_kbits'] + 32), dict(kjump_k=13), dict(kjump_k=8), dict(r2=f['r2'] + 64), dict(r0=f['r0'] + 8), dict(r1=f['r1'] + 4096), dict(r0=0), dict(n=0), dict(nblocks=f["nblocks"] - 1), dict(nblocks=f["nblocks"] + 1),
            dict(off_fm=8192), dict(off_rec=f["off_rec"] + 64), dict(off_rec=f["off_fm"]), dict(off_sa=f["total_bytes"]),
            dict(off_sa=f["off_rec"] + 256), dict(off_nrows=f["off_sa"]), dict(off_kfilter=f["total_bytes"] - 256),
            dict(kfilter_log2=48), dict(kfilter_log2=f["kfilter_log2"] + 1), dict(kfilter_k=40), dict(num_n=f["n"] + 1),
