@@ -280,13 +280,13 @@ typedef QueryCursorT<32> QueryCursor;  // the search kernels (a 16-byte window s
 // a shift, sixteen more wait in registers, one aligned 16-byte load per 16 letters.  ~15 instructions per letter, where
 // the random-access cursor needs ~45 -- and the prefilter is bound by instruction issue (a wave64 VALU instruction
 // occupies its SIMD for four cycles).
-// 16-byte chunks of the query buffer that one block of K8a stages in LDS when the strands of its 256 items lie in a
-// span this short (128 reads of up to 160 letters): both strands of a read then cost one coalesced pass over its lines
-// instead of two scattered ones that the probes in between evict from L2 (-40 M of 417 M requests on the benchmark
-// batch).  20 KB, not more: K8a needs its 7-8 waves per SIMD to keep the memory system's request queue full (with
-// 40 KB -- four blocks per CU -- it takes 10.9 ms instead of 7.5).  0 = never stage
+// 16-byte chunks of the query buffer whose letters one block of K8a packs into LDS (2 bits per letter + one "not
+// A,C,G,T" bit) when the strands of its 256 items lie in a span this short (128 reads of up to 320 letters).  The windows
+// of both strands of a read are then cut out of the packed copy with a few shifts -- no per-letter loop (it cost ~80
+// instructions per letter: K8a was bound by instruction issue as much as by requests), and the reads' own lines are
+// fetched once, coalesced, instead of twice through probes that evict them from L2.  0 = never
 #ifndef SLAMEM_PF_STAGE_CHUNKS
-#define SLAMEM_PF_STAGE_CHUNKS 1280
+#define SLAMEM_PF_STAGE_CHUNKS 2560
 #endif
 constexpr uint32_t kPfStageChunks = SLAMEM_PF_STAGE_CHUNKS;
 
@@ -1500,6 +1500,103 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
     }
 }
 
+// ---- K8a on a packed span ------------------------------------------------------------------------------------
+// 16 letters of the query buffer -> 2-bit codes (A,C,G,T = 0..3, the first letter lowest) and a bit per letter that is
+// none of them (same classes as ascii_code_q)
+__device__ __forceinline__ void pack_chunk(const uint4& a, uint32_t& pk, uint32_t& nm) {
+    pk = 0u; nm = 0u;
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t u = (w[i >> 2] >> (8 * (i & 3))) & 0xDFu;
+        const uint32_t x = (u >> 1) & 3u, code = x ^ (x >> 1);           // A 0, C 1, G 2, T 3
+        const bool ok = ((0x54474341u >> (8u * code)) & 0xFFu) == u;    // the letter that has this code
+        pk |= (ok ? code : 0u) << (2 * i);
+        nm |= (ok ? 0u : 1u) << i;
+    }
+}
+
+// letters [q, q+len) of the packed span (len <= 24) as a number, the FIRST letter in the lowest bits
+__device__ __forceinline__ uint64_t span_letters(const uint32_t* pk, const uint16_t* nm, uint32_t q, uint32_t len, bool& has_n) {
+    const uint32_t c = q >> 4, o = q & 15u;
+    uint64_t v = ((uint64_t)pk[c] | ((uint64_t)pk[c + 1u] << 32)) >> (2u * o);
+    if (o) v |= (uint64_t)pk[c + 2u] << (64u - 2u * o);
+    const uint64_t m = (uint64_t)nm[c] | ((uint64_t)nm[c + 1u] << 16) | ((uint64_t)nm[c + 2u] << 32);
+    has_n = ((m >> o) & ((1ull << len) - 1ull)) != 0ull;
+    return v & ((1ull << (2u * len)) - 1ull);
+}
+
+// The prefilter of one item whose strand lies in the packed span (rel = span letter of the record's first letter): the
+// same windows, the same tests and the same treatment of N as prefilter_item below, each window cut out of the packed
+// letters instead of rolled letter by letter.
+template <bool kStats>
+__device__ __forceinline__ uint8_t prefilter_item_packed(const SearchArgs& A, const ItemDesc& d, const uint32_t* pk,
+                                                         const uint16_t* nm, uint32_t rel, uint32_t& n_probe) {
+    const IndexView& ix = A.ix;
+    const uint32_t k = ix.kfilter_k, L = A.min_len, s = L - k + 1u;
+    const uint32_t rev = d.slice_rev >> 31, slen = d.len;
+    const uint32_t sl = d.slice_rev & 0x7FFFFFFFu;
+    const uint32_t a = sl * kSliceLen;
+    if (!(slen >= k && slen - a >= 1u)) return 0;
+    const uint32_t b = slen - a < kSliceLen ? slen : a + kSliceLen;
+    // letters [p, p+len) of the strand as the build hashes them: the first letter in the highest bits
+    auto win = [&](uint32_t p, uint32_t len, bool& has_n) -> uint64_t {
+        const uint64_t v = span_letters(pk, nm, rel + (rev ? slen - p - len : p), len, has_n);
+        if (rev) return ~v & ((1ull << (2u * len)) - 1ull);  // complemented; its first letter is the forward strand's last
+        uint64_t r = __brevll(v) >> (64u - 2u * len);          // pairs in reverse order, the two bits of each swapped
+        return ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    };
+    auto present = [&](const uint64_t* line, uint64_t h) -> bool {
+        const uint64_t bits = kfilter_bits(h);
+        return (line[kfilter_word(h)] & bits) == bits;
+    };
+    uint8_t res = 0;
+    bool hn;
+    if (s <= 6u) {  // the cascade (see prefilter_item)
+        const uint32_t k1 = k - 2u, s1 = L - k1 + 1u;
+        const bool three = L >= k + 2u && k + 2u <= 32u;
+        const uint32_t p0 = (a + s1 - 1u) / s1 * s1;
+        const uint32_t pmax = (uint32_t)(((uint64_t)b + s1 - 2u < (uint64_t)(slen - k1)) ? b + s1 - 2u : slen - k1);
+#pragma unroll 1
+        for (uint32_t p = p0; p <= pmax && !res; p += s1) {
+            const uint64_t v1 = win(p, k1, hn);
+            if (hn) { res = 1; break; }                          // holds an N: cannot be ruled out
+            const uint64_t h1 = kfilter_hash(v1 ^ kFilterShortSalt);
+            const uint64_t* line = ix.kfilter + kfilter_line(h1, ix.kfilter_log2);
+            if (kStats) n_probe++;
+            if (!present(line, h1)) continue;
+#pragma unroll 1
+            for (uint32_t t = 0; t < 3u && !res; t++) {           // the k-mers that start at p-2, p-1, p
+                if (p + t < 2u || (uint64_t)p + t - 2u + k > slen) continue;
+                const uint32_t q = p + t - 2u;
+                const uint64_t vk = win(q, k, hn);
+                if (hn) { res = 1; break; }
+                if (!present(line, kfilter_hash(vk))) continue;
+                if (!three) { res = 1; break; }
+#pragma unroll 1
+                for (uint32_t u = 0; u < 3u && !res; u++) {       // the (k+2)-mers that start at q-2, q-1, q
+                    if (q + u < 2u || (uint64_t)q + u + k > slen) continue;
+                    const uint64_t v3 = win(q + u - 2u, k + 2u, hn);
+                    if (hn) { res = 1; break; }
+                    if (present(line, kfilter_hash(v3 ^ kFilterLongSalt))) res = 1;
+                }
+            }
+        }
+    } else {
+        const uint32_t p0 = (a + s - 1u) / s * s;
+        const uint32_t pmax = (uint32_t)(((uint64_t)b + s - 2u < (uint64_t)(slen - k)) ? b + s - 2u : slen - k);
+#pragma unroll 1
+        for (uint32_t p = p0; p <= pmax && !res; p += s) {
+            const uint64_t vk = win(p, k, hn);
+            if (hn) { res = 1; break; }
+            const uint64_t* line = ix.kfilter + kfilter_line(kfilter_hash((vk >> 4) ^ kFilterShortSalt), ix.kfilter_log2);
+            if (kStats) n_probe++;
+            if (present(line, kfilter_hash(vk))) res = 1;
+        }
+    }
+    return res;
+}
+
 // K8a: presence prefilter.  A MEM of length >= L that starts in the item's slice [a,b) contains a k-mer window
 // starting at a multiple of s = L-k+1 inside [a, b+s-2]; if none of those windows occurs in the text (filter says
 // "absent": no false negatives) the item cannot emit anything and K8 skips it.  Windows holding an N count as
@@ -1620,8 +1717,12 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
     return res;
 }
 
+// (without the second bound the compiler takes 127 registers -- four waves per SIMD -- and K8a waits for memory)
+#ifndef SLAMEM_PF_WAVES
+#define SLAMEM_PF_WAVES 8
+#endif
 template <bool kStats>
-__global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __restrict__ alive) {
+__global__ void __launch_bounds__(256, SLAMEM_PF_WAVES) k_prefilter(SearchArgs A, uint8_t* __restrict__ alive) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = g < A.num_items;
     if (!live) g = 0;  // idle lanes stay for the block's barriers and the diagnostic reduction (they store nothing)
@@ -1631,7 +1732,8 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
     uint8_t res;
     if (kPfStageChunks != 0u) {
         // the 16-byte chunks [lo, hi) of the query buffer that the block's strands lie in
-        __shared__ uint4 s_stage[kPfStageChunks ? kPfStageChunks : 1u];
+        __shared__ uint32_t s_pk[kPfStageChunks + 2u];
+        __shared__ uint16_t s_nm[kPfStageChunks + 2u];
         __shared__ unsigned long long s_lo[4], s_hi[4];
         unsigned long long lo = d.len ? d.base >> 4 : ~0ull, hi = d.len ? ((d.base + d.len - 1u) >> 4) + 1ull : 0ull;
 #pragma unroll
@@ -1650,9 +1752,17 @@ __global__ void __launch_bounds__(256) k_prefilter(SearchArgs A, uint8_t* __rest
         if (hi > lo && hi - lo <= (unsigned long long)kPfStageChunks) {  // (the same for every lane of the block)
             const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + lo;
             const uint32_t n = (uint32_t)(hi - lo);
-            for (uint32_t i = threadIdx.x; i < n; i += 256u) s_stage[i] = src[i];
+#pragma unroll 1
+            for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+                uint32_t pk, nm;
+                pack_chunk(src[i], pk, nm);
+                s_pk[i] = pk;
+                s_nm[i] = (uint16_t)nm;
+                if (kStats) n_qload++;
+            }
+            if (threadIdx.x < 2u) { s_pk[n + threadIdx.x] = 0u; s_nm[n + threadIdx.x] = 0u; }  // a window's reads run two words past it
             __syncthreads();
-            res = prefilter_item<kStats, true>(A, d, s_stage, lo, n_probe, n_qload);
+            res = prefilter_item_packed<kStats>(A, d, s_pk, s_nm, (uint32_t)(d.base - (lo << 4)), n_probe);
         } else {
             res = prefilter_item<kStats, false>(A, d, nullptr, 0, n_probe, n_qload);
         }
