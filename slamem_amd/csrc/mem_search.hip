@@ -276,10 +276,6 @@ struct QueryCursorT {
 };
 typedef QueryCursorT<32> QueryCursor;  // the search kernels (a 16-byte window saves 8 VGPRs and costs twice the loads)
 
-// Letters of a strand in ascending position order (the prefilter's scan): eight bytes in a register are consumed with
-// a shift, sixteen more wait in registers, one aligned 16-byte load per 16 letters.  ~15 instructions per letter, where
-// the random-access cursor needs ~45 -- and the prefilter is bound by instruction issue (a wave64 VALU instruction
-// occupies its SIMD for four cycles).
 // 16-byte chunks of the query buffer whose letters one block of K8a packs into LDS (2 bits per letter + one "not
 // A,C,G,T" bit) when the strands of its 256 items lie in a span this short (128 reads of up to 320 letters).  The windows
 // of both strands of a read are then cut out of the packed copy with a few shifts -- no per-letter loop (it cost ~80
@@ -290,8 +286,9 @@ typedef QueryCursorT<32> QueryCursor;  // the search kernels (a 16-byte window s
 #endif
 constexpr uint32_t kPfStageChunks = SLAMEM_PF_STAGE_CHUNKS;
 
-// kLds: the chunks come from `stage` (LDS copy of chunks [lo, lo+n) of the buffer) instead of global memory
-template <bool kLds>
+// Letters of a strand in ascending position order: the scan of K8a for the strands that are NOT in a packed span (long
+// records, slices).  Eight bytes in a register are consumed with a shift, sixteen more wait in registers, one aligned
+// 16-byte load per 16 letters.
 struct QueryStream {
     const uint4* p;          // next 16-byte chunk (forward strand: ascending addresses, reverse strand: descending)
     uint64_t cur, n1, n2, n3;  // bytes being consumed / the 8-byte pieces that follow, in consumption order
@@ -300,24 +297,13 @@ struct QueryStream {
     uint32_t chunks;         // 16-byte chunks not loaded yet that still overlap the record
     uint32_t rev;
     uint32_t loads;          // 16-byte loads issued (read by the diagnostic instantiation only; dead code otherwise)
-    const uint4* stage;      // kLds only
-    int32_t pi;              // kLds only: index in `stage` of the next chunk
-    __device__ __forceinline__ uint4 chunk(int off) const {
-        if constexpr (kLds) return stage[pi + off];
-        else return p[off];
-    }
-    __device__ __forceinline__ void advance(int by) {
-        if constexpr (kLds) pi += by;
-        else p += by;
-    }
-    __device__ __forceinline__ void init(const uint64_t* words, uint64_t base, uint32_t len, uint32_t r, uint32_t start,
-                                         const uint4* lds = nullptr, uint64_t lds_first_chunk = 0) {
+    __device__ __forceinline__ uint4 chunk(int off) const { return p[off]; }
+    __device__ __forceinline__ void advance(int by) { p += by; }
+    __device__ __forceinline__ void init(const uint64_t* words, uint64_t base, uint32_t len, uint32_t r, uint32_t start) {
         rev = r;
         loads = 1;
         uint64_t addr = base + (r ? (uint64_t)(len - 1u - start) : (uint64_t)start);  // byte offset of the first letter
         p = reinterpret_cast<const uint4*>(words) + (addr >> 4);
-        stage = lds;
-        pi = (int32_t)((addr >> 4) - lds_first_chunk);
         chunks = r ? (uint32_t)((addr >> 4) - (base >> 4)) : (uint32_t)(((base + len - 1u) >> 4) - (addr >> 4));
         uint4 a = chunk(0);
         uint64_t lo = u64_of(a.x, a.y), hi = u64_of(a.z, a.w);
@@ -1602,9 +1588,8 @@ __device__ __forceinline__ uint8_t prefilter_item_packed(const SearchArgs& A, co
 // "absent": no false negatives) the item cannot emit anything and K8 skips it.  Windows holding an N count as
 // present.  One lane per item, early exit at the first present window (the matching strand of a read exits after
 // a few probes; the other strand pays ~ len/s probes instead of a full scan).
-template <bool kStats, bool kLds>
-__device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const ItemDesc& d, const uint4* stage,
-                                                  uint64_t stage_first, uint32_t& n_probe, uint32_t& n_qload) {
+template <bool kStats>
+__device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const ItemDesc& d, uint32_t& n_probe, uint32_t& n_qload) {
     const IndexView& ix = A.ix;
     const uint32_t k = ix.kfilter_k, L = A.min_len;
     const uint32_t s = L - k + 1u;
@@ -1624,7 +1609,7 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
         const uint32_t p0 = (a + s1 - 1u) / s1 * s1;
         uint32_t pmax = (uint32_t)(((uint64_t)b + s1 - 2u < (uint64_t)(d.len - k1)) ? b + s1 - 2u : d.len - k1);
         if (p0 <= pmax) {
-            QueryStream<kLds> qs;
+            QueryStream qs;
             // third level: if the MEM is at least k+2 long it also contains the (k+2)-mer that starts at max(m, s'-2), where
             // s' is the start of the k-mer above -- one of s'-2, s'-1, s'.  For L == k+2 that makes the test exact up to the
             // filter's false positives: a strand survives only if it really shares L letters with the text.
@@ -1639,7 +1624,7 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
             const uint64_t* line1 = ix.kfilter;
             const uint64_t* line2 = ix.kfilter;
             uint32_t x = p0 >= 4u ? p0 - 4u : 0u;
-            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, x, stage, stage_first);
+            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, x);
             uint64_t xe64 = (uint64_t)pmax + k1 + 1u + (three ? 2u : 0u);
             const uint32_t xend = xe64 > (uint64_t)d.len - 1u ? d.len - 1u : (uint32_t)xe64;
             uint32_t wend = p0 + k1 - 1u;  // letter at which the next probed (k-2)-mer window ends
@@ -1689,8 +1674,8 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
         // last window start that can serve this slice
         const uint32_t pmax = (uint32_t)(((uint64_t)b + s - 2u < (uint64_t)(d.len - k)) ? b + s - 2u : d.len - k);
         if (p0 <= pmax) {
-            QueryStream<kLds> qs;
-            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, p0, stage, stage_first);
+            QueryStream qs;
+            qs.init(A.qwords, d.base, d.len, d.slice_rev >> 31, p0);
             const uint64_t mask = (1ull << (2u * k)) - 1ull;
             uint64_t km = 0;
             uint32_t run = 0, wend = p0 + k - 1u;               // letter at which the next probed window ends
@@ -1764,10 +1749,10 @@ __global__ void __launch_bounds__(256, SLAMEM_PF_WAVES) k_prefilter(SearchArgs A
             __syncthreads();
             res = prefilter_item_packed<kStats>(A, d, s_pk, s_nm, (uint32_t)(d.base - (lo << 4)), n_probe);
         } else {
-            res = prefilter_item<kStats, false>(A, d, nullptr, 0, n_probe, n_qload);
+            res = prefilter_item<kStats>(A, d, n_probe, n_qload);
         }
     } else {
-        res = prefilter_item<kStats, false>(A, d, nullptr, 0, n_probe, n_qload);
+        res = prefilter_item<kStats>(A, d, n_probe, n_qload);
     }
     if (live) alive[g] = res;
     if (kStats) {
