@@ -100,7 +100,7 @@ typedef struct {
     uint64_t wave_trips;            /* K8: loop trips summed over waves (lane_trips / (64 * wave_trips) = lane use)    */
     uint64_t positions;             /* K8: query positions consumed                                                    */
     uint64_t enum_jobs;             /* K8: wave-cooperative enumeration jobs                                           */
-    uint64_t prefilter_probes;      /* K8a: presence-filter words read                                                 */
+    uint64_t prefilter_probes;      /* K8a: presence-filter lines fetched (the tests behind a hit read the same line)  */
     uint64_t prefilter_query_loads; /* K8a: 16-byte query loads                                                        */
     uint64_t prefilter_items;       /* K8a: work items screened                                                        */
     uint64_t items;                 /* work items of the batch                                                         */

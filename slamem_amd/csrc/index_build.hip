@@ -234,22 +234,33 @@ __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restric
         v = (w >> (2u * sh)) & (len >= 32u ? ~0ull : (1ull << (2u * len)) - 1ull);
         return ((ok >> sh) & all) == all;
     };
-    uint64_t v;
+    // the nine entries: hash and whether the window lies in the text and holds no N
+    uint64_t v, hs[9];
+    bool in[9];
     if (!piece(4u, k1, v)) return;
-    uint64_t h = kfilter_hash(v ^ kFilterShortSalt);
-    unsigned long long* line = filter + kfilter_line(h, log2_words);
-    atomicOr(&line[kfilter_word(h)], (unsigned long long)kfilter_bits(h));
-    for (uint32_t o = 2u; o <= 4u; o++)
-        if (piece(o, k, v)) {
-            h = kfilter_hash(v);
-            atomicOr(&line[kfilter_word(h)], (unsigned long long)kfilter_bits(h));
-        }
-    if (k + 2u <= 32u)  // third level (it fits the 64-bit rolling value of the search)
-        for (uint32_t o = 0u; o <= 4u; o++)
-            if (piece(o, k + 2u, v)) {
-                h = kfilter_hash(v ^ kFilterLongSalt);
-                atomicOr(&line[kfilter_word(h)], (unsigned long long)kfilter_bits(h));
-            }
+    hs[0] = kfilter_hash(v ^ kFilterShortSalt);
+    in[0] = true;
+    unsigned long long* line = filter + kfilter_line(hs[0], log2_words);
+#pragma unroll
+    for (uint32_t o = 2u; o <= 4u; o++) {
+        in[o - 1u] = piece(o, k, v);
+        hs[o - 1u] = kfilter_hash(v);
+    }
+    const bool third = k + 2u <= 32u;  // third level (it fits the 64-bit rolling value of the search)
+#pragma unroll
+    for (uint32_t o = 0u; o <= 4u; o++) {
+        in[4u + o] = third && piece(o, k + 2u, v);
+        hs[4u + o] = kfilter_hash(v ^ kFilterLongSalt);
+    }
+    // one atomic per word of the line that gets bits (5.5 on average), not one per entry
+#pragma unroll
+    for (uint32_t wd = 0; wd < 8u; wd++) {
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (uint32_t e = 0; e < 9u; e++)
+            if (in[e] && kfilter_word(hs[e]) == wd) m |= (unsigned long long)kfilter_bits(hs[e]);
+        if (m) atomicOr(&line[wd], m);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

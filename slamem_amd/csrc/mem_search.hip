@@ -1577,7 +1577,16 @@ __device__ __forceinline__ uint8_t prefilter_item_packed(const SearchArgs& A, co
             if (hn) { res = 1; break; }
             const uint64_t* line = ix.kfilter + kfilter_line(kfilter_hash((vk >> 4) ^ kFilterShortSalt), ix.kfilter_log2);
             if (kStats) n_probe++;
-            if (present(line, kfilter_hash(vk))) res = 1;
+            if (!present(line, kfilter_hash(vk))) continue;
+            if (k + 2u > 32u) { res = 1; break; }
+            // (min_len >= k+6 here) a MEM around this window that starts at m also holds the (k+2)-mer that starts at
+            // max(m, p-2), one of p-2, p-1, p -- entered in the same line: a second test that costs no line of HBM
+#pragma unroll 1
+            for (uint32_t u = 0; u < 3u && !res; u++) {
+                if (p + u < 2u || (uint64_t)p + u + k > slen) continue;
+                const uint64_t v3 = win(p + u - 2u, k + 2u, hn);
+                if (hn || present(line, kfilter_hash(v3 ^ kFilterLongSalt))) res = 1;
+            }
         }
     }
     return res;
