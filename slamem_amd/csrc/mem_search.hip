@@ -1743,9 +1743,9 @@ __global__ void __launch_bounds__(256, SLAMEM_PF_WAVES) k_prefilter(SearchArgs A
             lo = s_lo[w] < lo ? s_lo[w] : lo;
             hi = s_hi[w] > hi ? s_hi[w] : hi;
         }
-        if (hi > lo && hi - lo <= (unsigned long long)kPfStageChunks) {  // (the same for every lane of the block)
-            const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + lo;
-            const uint32_t n = (uint32_t)(hi - lo);
+        // packs chunks [lo, lo+n) of the query buffer (every lane of the block helps)
+        auto pack_span = [&](unsigned long long first_chunk, uint32_t n) {
+            const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + first_chunk;
 #pragma unroll 1
             for (uint32_t i = threadIdx.x; i < n; i += 256u) {
                 uint32_t pk, nm;
@@ -1756,9 +1756,49 @@ __global__ void __launch_bounds__(256, SLAMEM_PF_WAVES) k_prefilter(SearchArgs A
             }
             if (threadIdx.x < 2u) { s_pk[n + threadIdx.x] = 0u; s_nm[n + threadIdx.x] = 0u; }  // a window's reads run two words past it
             __syncthreads();
+        };
+        if (hi > lo && hi - lo <= (unsigned long long)kPfStageChunks) {  // (the same for every lane of the block)
+            // the usual case: the strands of all 256 items (128 reads of up to 320 letters) in one span
+            pack_span(lo, (uint32_t)(hi - lo));
             res = prefilter_item_packed<kStats>(A, d, s_pk, s_nm, (uint32_t)(d.base - (lo << 4)), n_probe);
         } else {
-            res = prefilter_item<kStats>(A, d, n_probe, n_qload);
+            // longer reads: the block works in two or four parts (pairs of waves, single waves -- 64 reads of up to 640
+            // letters, 32 of up to 1280), if the span of every part fits; else (long records, slices) the letter loop
+            auto span_lo = [&](uint32_t first, uint32_t count) {
+                unsigned long long v = ~0ull;
+                for (uint32_t w = first; w < first + count; w++) v = s_lo[w] < v ? s_lo[w] : v;
+                return v;
+            };
+            auto span_hi = [&](uint32_t first, uint32_t count) {
+                unsigned long long v = 0ull;
+                for (uint32_t w = first; w < first + count; w++) v = s_hi[w] > v ? s_hi[w] : v;
+                return v;
+            };
+            uint32_t per_part = 0u;  // waves per part
+            for (uint32_t cnt = 2u; cnt >= 1u && !per_part; cnt >>= 1) {
+                bool fits = true;
+                for (uint32_t first = 0; first < 4u; first += cnt) {
+                    const unsigned long long l = span_lo(first, cnt), h = span_hi(first, cnt);
+                    if (h > l && h - l > (unsigned long long)kPfStageChunks) fits = false;
+                }
+                if (fits) per_part = cnt;
+            }
+            if (per_part && hi > lo) {
+                const uint32_t my_wave = threadIdx.x >> 6;
+                res = 0;
+#pragma unroll 1
+                for (uint32_t first = 0; first < 4u; first += per_part) {
+                    lo = span_lo(first, per_part);
+                    hi = span_hi(first, per_part);
+                    if (hi <= lo) continue;  // nothing but empty records (or no items) in these waves
+                    __syncthreads();         // the part before has been read
+                    pack_span(lo, (uint32_t)(hi - lo));
+                    if (my_wave >= first && my_wave < first + per_part)
+                        res = prefilter_item_packed<kStats>(A, d, s_pk, s_nm, (uint32_t)(d.base - (lo << 4)), n_probe);
+                }
+            } else {
+                res = prefilter_item<kStats>(A, d, n_probe, n_qload);
+            }
         }
     } else {
         res = prefilter_item<kStats>(A, d, n_probe, n_qload);

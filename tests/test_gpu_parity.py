@@ -364,6 +364,41 @@ def test_minimum_length_thresholds_of_the_search_path(eng, min_len, mam):
     idx.close()
 
 
+@pytest.mark.parametrize("read_len,min_len", [(319, 17), (320, 17), (321, 17), (500, 17), (640, 16), (641, 21), (1000, 17),
+                                              (1280, 17), (1300, 17), (2500, 40)])
+def test_prefilter_parts_for_reads_longer_than_one_span(eng, read_len, min_len):
+    """K8a packs the strands of a block into LDS in one, two or four parts (128 reads of up to 320 letters, 64 of up to
+    640, 32 of up to 1280) and falls back to its letter loop beyond; every shape equals the oracle in order.  3 Mbp text
+    (filter k = 15): min_len 17 is the three-level cascade, 16 two levels, 21 and 40 the single-level path."""
+    from oracle import pyoracle as po
+    from slamem_amd import synth
+    n, nreads = 3_000_000, 700
+    ref = synth.make_reference(n, seed=77)
+    reads = synth.make_reads(ref, 0, nreads, read_len, 0.03, seed=read_len, rc_percent=50).reshape(-1)
+    # a few records of other lengths in between, so that spans are ragged and one wave's span can exceed the others'
+    rng = np.random.default_rng(read_len)
+    lens = np.full(nreads, read_len, dtype=np.int64)
+    lens[rng.integers(0, nreads, size=40)] = rng.integers(1, read_len + 1, size=40)
+    lens[rng.integers(0, nreads, size=5)] = 0
+    pieces, pos = [], 0
+    for ln in lens:  # cut the generated letters into records of these lengths (the tail of a shortened read is dropped)
+        pieces.append(reads[pos:pos + ln])
+        pos += read_len
+    q = np.concatenate(pieces)
+    q[rng.integers(0, len(q), size=30)] = ord("N")
+    off = np.zeros(nreads + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    idx = eng.Index.build(ref)
+    o = po.OracleIndex(ref.tobytes())
+    om, obc = o.match_batch(q, off, min_len, True)
+    gm, goff = idx.find_mems(q, off, min_len, True)
+    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+    for f in ("ref_pos", "query_pos", "length"):
+        assert np.array_equal(gm[f], om[f]), f
+    assert len(gm) > nreads  # (the reads do match)
+    idx.close()
+
+
 def test_stream_large_batches_from_ordinary_and_page_locked_memory(eng):
     """Batches of 40 MB and 72 MB whose characters live in ordinary (pageable) memory, the same batches from page-locked
     memory, and slamem_find_mems_device on the same reads must agree MEM for MEM.  (Staging pageable batches through
