@@ -85,7 +85,8 @@ static int header_ok(const ArenaHeader& h, uint64_t bytes) {
     if (!bad && h.num_n > h.n) bad = "N row count";
     section(h.off_nrows, (uint64_t)(h.num_n ? h.num_n : 1) * 4, "N row list");
     if (h.off_kfilter) {
-        if (!bad && (h.kfilter_log2 < 10 || h.kfilter_log2 > 40 || h.kfilter_k < 4 || h.kfilter_k > 26)) bad = "presence filter parameters";
+        if (!bad && (h.kfilter_log2 < 10 || h.kfilter_log2 > 40 || h.kfilter_k < 4 || h.kfilter_k > 26 ||
+                     (h.kfilter_levels != 0u && h.kfilter_levels != 2u && h.kfilter_levels != 3u))) bad = "presence filter parameters";
         if (!bad) section(h.off_kfilter, 8ull << h.kfilter_log2, "presence filter");
     }
     if (h.off_tgrp || h.off_prec) {

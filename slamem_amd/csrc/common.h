@@ -94,7 +94,7 @@ struct ArenaHeader {
     uint32_t C[6];        // C[c] = number of characters of text+'$' smaller than c
     uint32_t kjump_k;     // K of the jump table (0 = none)
     uint32_t kbits_k;     // k of the occurrence bitmap (0 = none)
-    uint32_t reserved0;
+    uint32_t kfilter_levels;  // 3 (or 0): (k-2)-, k- and (k+2)-mers; 2: no (k+2)-mers (texts above 2^31 letters)
     uint64_t off_kbits;   // uint64[4^kbits_k / 64]  one bit per k-mer over A,C,G,T: does it occur in the text?
     uint32_t reserved[11];
 };
@@ -119,6 +119,7 @@ struct IndexView {
     uint32_t num_n;
     uint32_t kfilter_log2;
     uint32_t kfilter_k;
+    uint32_t kfilter_levels;  // 2 or 3
 };
 
 // Presence filter: a blocked Bloom filter in 64-byte lines of eight words.  The line is chosen by a (k-2)-mer of the

@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256) k_rank_samples(const uint4* __restrict__ 
 // treated as present, so N == N matches are never filtered out).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
-                                                       uint32_t log2_words, unsigned long long* __restrict__ filter) {
+                                                       uint32_t log2_words, uint32_t levels,
+                                                       unsigned long long* __restrict__ filter) {
     uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t k1 = k - 2u;
     if (p + k1 > n) return;
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restric
         in[o - 1u] = piece(o, k, v);
         hs[o - 1u] = kfilter_hash(v);
     }
-    const bool third = k + 2u <= 32u;  // third level (it fits the 64-bit rolling value of the search)
+    const bool third = levels >= 3u && k + 2u <= 32u;  // third level (it fits the 64-bit rolling value of the search)
 #pragma unroll
     for (uint32_t o = 0u; o <= 4u; o++) {
         in[4u + o] = third && piece(o, k + 2u, v);
@@ -685,6 +686,7 @@ void make_view(slamem_index* idx) {
     idx->view.kbits_k = h.off_kbits ? h.kbits_k : 0u;
     idx->view.kfilter_log2 = h.kfilter_log2;
     idx->view.kfilter_k = h.kfilter_k;
+    idx->view.kfilter_levels = h.kfilter_levels == 2u ? 2u : 3u;
     idx->view.n = h.n;
     idx->view.nblocks = h.nblocks;
     idx->view.dollar_row = h.dollar_row;
@@ -771,6 +773,12 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
             // two 64-bit words per text position (nine entries of three bits each per position: a sixth of the bits set)
             uint32_t lg = 10;
             while ((1ull << lg) < 2ull * (uint64_t)n && lg < 32) lg++;
+            // texts above 2^31 letters get fewer than two words per position (2^32 words is the most the line index of
+            // a hash allows here without a 64 GiB section): their filter holds no (k+2)-mers -- four entries per position
+            // instead of nine, so that a test still lets only ~0.2 % through (with all nine at 1.4 words per position it
+            // was 1.8 %: at 3.1 Gbp and -l 20, 7.3 M of 10 M strands survived instead of 6.3 M); the search then stops
+            // its cascade at the k-mers
+            hdr.kfilter_levels = (1ull << lg) < 2ull * (uint64_t)n ? 2u : 3u;
             hdr.off_kfilter = off;
             hdr.kfilter_log2 = lg;
             hdr.kfilter_k = kf_k;
@@ -942,7 +950,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         unsigned long long* d_filter = reinterpret_cast<unsigned long long*>(base + hdr.off_kfilter);
         SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));
         hipLaunchKernelGGL(k_kfilter_build, dim3(grid_for((uint64_t)n - hdr.kfilter_k + 3)), dim3(256), 0, stream,
-                           pk.as<uint64_t>(), n, hdr.kfilter_k, hdr.kfilter_log2, d_filter);
+                           pk.as<uint64_t>(), n, hdr.kfilter_k, hdr.kfilter_log2, hdr.kfilter_levels, d_filter);
         SLAMEM_HIP(hipGetLastError());
     }
 

@@ -1540,7 +1540,7 @@ __device__ __forceinline__ uint8_t prefilter_item_packed(const SearchArgs& A, co
     bool hn;
     if (s <= 6u) {  // the cascade (see prefilter_item)
         const uint32_t k1 = k - 2u, s1 = L - k1 + 1u;
-        const bool three = L >= k + 2u && k + 2u <= 32u;
+        const bool three = L >= k + 2u && k + 2u <= 32u && ix.kfilter_levels >= 3u;
         const uint32_t p0 = (a + s1 - 1u) / s1 * s1;
         const uint32_t pmax = (uint32_t)(((uint64_t)b + s1 - 2u < (uint64_t)(slen - k1)) ? b + s1 - 2u : slen - k1);
 #pragma unroll 1
@@ -1578,7 +1578,7 @@ __device__ __forceinline__ uint8_t prefilter_item_packed(const SearchArgs& A, co
             const uint64_t* line = ix.kfilter + kfilter_line(kfilter_hash((vk >> 4) ^ kFilterShortSalt), ix.kfilter_log2);
             if (kStats) n_probe++;
             if (!present(line, kfilter_hash(vk))) continue;
-            if (k + 2u > 32u) { res = 1; break; }
+            if (k + 2u > 32u || ix.kfilter_levels < 3u) { res = 1; break; }
             // (min_len >= k+6 here) a MEM around this window that starts at m also holds the (k+2)-mer that starts at
             // max(m, p-2), one of p-2, p-1, p -- entered in the same line: a second test that costs no line of HBM
 #pragma unroll 1
@@ -1622,7 +1622,7 @@ __device__ __forceinline__ uint8_t prefilter_item(const SearchArgs& A, const Ite
             // third level: if the MEM is at least k+2 long it also contains the (k+2)-mer that starts at max(m, s'-2), where
             // s' is the start of the k-mer above -- one of s'-2, s'-1, s'.  For L == k+2 that makes the test exact up to the
             // filter's false positives: a strand survives only if it really shares L letters with the text.
-            const bool three = L >= k + 2u && k + 2u <= 32u;
+            const bool three = L >= k + 2u && k + 2u <= 32u && ix.kfilter_levels >= 3u;
             const uint32_t kw = three ? k + 2u : k;  // letters kept in the rolling value
             const uint64_t mask = kw >= 32u ? ~0ull : (1ull << (2u * kw)) - 1ull;
             const uint64_t maskk = (1ull << (2u * k)) - 1ull, mask1 = (1ull << (2u * k1)) - 1ull;
