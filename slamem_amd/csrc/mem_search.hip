@@ -2232,8 +2232,14 @@ int SearchJob::launch(hipStream_t stream) {
             A.slice_state = d_states;
         }
         {   // K7q: the strands K8 will scan, packed; then (only if some record was cut into slices) all of those slices
-            uint64_t pb = (nitems * 8 + 255) / 256;
-            hipLaunchKernelGGL(k_pack_queries<8>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, false);
+#ifndef SLAMEM_K7Q_LANES
+#define SLAMEM_K7Q_LANES 8
+#endif
+#ifndef SLAMEM_K7Q_BLOCKS
+#define SLAMEM_K7Q_BLOCKS 32768  // (8192: 1.01 ms on the benchmark batch, 32768-131072: 0.93-0.96, one block per 32 items: 1.10)
+#endif
+            uint64_t pb = (nitems * SLAMEM_K7Q_LANES + 255) / 256;
+            hipLaunchKernelGGL(k_pack_queries<SLAMEM_K7Q_LANES>, dim3((unsigned)(pb < SLAMEM_K7Q_BLOCKS ? pb : SLAMEM_K7Q_BLOCKS)), dim3(256), 0, stream, A, false);
             if (nitems != num_blocks) {
                 pb = (nitems * 16 + 255) / 256;
                 hipLaunchKernelGGL(k_pack_queries<16>, dim3((unsigned)(pb < 8192 ? pb : 8192)), dim3(256), 0, stream, A, true);
