@@ -12,6 +12,7 @@ Cases (inputs: slamem_amd/synth.py generators, SURVEY.md Appendix C.2 + the repe
   config1_pair      BASELINE.json configs[0]: a 4.64 Mbp genome against a 1.5 %-diverged strain with three
                     inversions and two deletions (tests/golden_cases.py::ecoli_like_pair), -b -l 20
   config1_pair_mam  the same pair with -mam (sha256 of the reference's output file)
+  config5_first100k BASELINE.json configs[4]: 3.1 Gbp text (> 2^31 rows) with the repeat model, the first 100,000 reads, -b -l 20
   config2_mam_first200k   the 100 Mbp reference of configs[1]/[2], its first 200,000 reads, -b -l 20 -mam
 
 Every MEM the reference prints is also checked here against the texts (real match, maximal on both sides) before the
@@ -66,10 +67,20 @@ def check_rows_against_text(rows, ref, reads, strands):
     return bad
 
 
-def run_reference(args, cwd):
+def run_reference(args, cwd, timeout=None, as_gb=None):
+    """rc of the reference (or "timeout"), wall seconds.  as_gb caps the child's address space so that a run that
+    needs more memory than the build container has fails by itself instead of taking the container down."""
     t0 = time.time()
+
+    def limit():
+        if as_gb:
+            import resource
+            resource.setrlimit(resource.RLIMIT_AS, (as_gb << 30, as_gb << 30))
     with open(os.path.join(cwd, "stdout.txt"), "wb") as so:
-        rc = subprocess.run([REF_BIN] + args, cwd=cwd, stdout=so).returncode
+        try:
+            rc = subprocess.run([REF_BIN] + args, cwd=cwd, stdout=so, timeout=timeout, preexec_fn=limit).returncode
+        except subprocess.TimeoutExpired:
+            rc = "timeout"
     return rc, time.time() - t0
 
 
@@ -153,7 +164,38 @@ def case_config1_pair_mam(tmp):
             "workload": f"ecoli_like_pair(): {ref.shape[0]} bp genome vs {qry.shape[0]} bp strain, -b -l 20 -mam"}
 
 
-CASES = {"config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
+def case_config5_first100k(tmp):
+    """BASELINE.json configs[4] stand-in: the 3.1 Gbp text (> 2^31 BWT rows) WITH the repeat model and the first 100,000 of
+    its reads, -b -l 20.  One core for hours and ~30 GB in the build container; a run that does not finish (time, memory,
+    a crash of the reference at this size) is recorded as such, with the tail of its stdout."""
+    n, nreads, L, min_len = 3_100_000_000, 100_000, 150, 20
+    assert (n + 1) % 64 != 0
+    ref = synth.make_reference(n, 42)
+    planted = synth.plant_repeats(ref, 42)
+    if not os.path.exists(os.path.join(tmp, "ref.fa")):
+        synth.write_fasta_reference(os.path.join(tmp, "ref.fa"), ref)
+    reads = synth.make_reads(ref, 0, nreads, L, 0.02, 42, 50)
+    with open(os.path.join(tmp, "qry.fa"), "wb") as f:
+        f.write(b"".join(b">q%d\n" % i + reads[i].tobytes() + b"\n" for i in range(nreads)))
+    workload = (f"n={n} seed 42 + repeat model ({planted} planted letters), reads 0..{nreads - 1} of 150 bp, "
+                f"2% substitutions, 50% reverse-complemented, -b -l {min_len}")
+    hours = float(os.environ.get("REF_TIMEOUT_HOURS", "5"))
+    rc, secs = run_reference(["-b", "-l", str(min_len), "-o", "out.txt", "ref.fa", "qry.fa"], tmp,
+                             timeout=hours * 3600, as_gb=52)
+    if rc != 0:
+        tail = open(os.path.join(tmp, "stdout.txt"), "rb").read()[-600:].decode("latin1")
+        return {"reference_rc": rc, "reference_seconds": round(secs, 1), "reference_completed": False,
+                "stdout_tail": tail, "workload": workload}
+    rows = parse(os.path.join(tmp, "out.txt"), True)
+    bad = check_rows_against_text(rows, ref, reads, 2)
+    d = digest_rows(rows)
+    d.update({"reference_rc": rc, "reference_seconds": round(secs, 1), "reference_completed": True,
+              "reference_valid": bad == 0, "invalid_rows": bad,
+              "rows_beyond_2p31": int((rows[:, 1].astype(np.int64) > (1 << 31)).sum()), "workload": workload})
+    return d
+
+
+CASES = {"config5_first100k": case_config5_first100k, "config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
          "config2_mam_first200k": case_config2_mam_first200k, "config1_pair_mam": case_config1_pair_mam}
 
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def test_cli_output_file_is_byte_identical(case, tmp_path):
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     ref_fa, q_fa, exp_mems, _ = case_paths(case)
@@ -40,7 +40,7 @@ def test_cli_overlapped_loading_changes_nothing(case, tmp_path):
     the main thread's lines held back meanwhile): the output file and stdout must be those of the sequential run."""
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
     ref_fa, q_fa, exp_mems, _ = case_paths(case)
     out = str(tmp_path / "out-mems.txt")
@@ -60,7 +60,7 @@ def test_cli_without_a_valid_query_record(overlap, tmp_path):
     after it has started (queries parsed beside the search): status 255, no output file left behind."""
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
     ref_fa, _, _, _ = case_paths("acgt_l20_both")
     bad = tmp_path / "bad.fa"
@@ -76,7 +76,7 @@ def test_cli_default_output_name_and_batches(tmp_path):
     import shutil
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
     ref_fa, q_fa, exp_mems, _ = case_paths("acgt_l20_both")
     shutil.copy(ref_fa, tmp_path / "myref.fa")
@@ -93,7 +93,7 @@ def test_cli_prints_the_reference_structure_statistics(case, tmp_path):
     import re
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
     ref_fa, q_fa, _, exp_stdout = case_paths(case)
     r = subprocess.run([exe] + MANIFEST[case]["opts"] + ["-o", str(tmp_path / "o.txt"), ref_fa, q_fa] +
@@ -117,7 +117,7 @@ def test_cli_config2_full_size_output_hash(tmp_path):
     import sys
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     root = hostlib.ROOT
     gen = os.path.join(root, "tools", "gen_synth.py")
     d = str(tmp_path)
@@ -154,7 +154,7 @@ def test_cli_rccl_replication_selftest(tmp_path):
     (ncclCommInitAll + ncclBroadcast into a second arena), the search then runs on the broadcast copy."""
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
     ref_fa, q_fa, exp_mems, _ = case_paths("acgt_l20_both")
     out = str(tmp_path / "o.txt")

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 def eng():
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     from slamem_amd import engine
     return engine
 

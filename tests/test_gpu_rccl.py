@@ -14,7 +14,7 @@ def test_rccl_single_rank_rehearsal(tmp_path):
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     from slamem_amd import engine, shard
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)

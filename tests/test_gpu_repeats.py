@@ -32,7 +32,7 @@ def make_repeat_case(rng, n, unit_len, copies, divergence, nreads, read_len):
 def test_repeat_family_matches_oracle(copies, divergence, both):
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     from oracle import pyoracle as po
     from slamem_amd import engine
     rng = np.random.default_rng(copies)
@@ -57,7 +57,7 @@ def test_long_queries_sliced_across_lanes(both):
     Output must equal the oracle's whole-record scan, in order."""
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     from oracle import pyoracle as po
     from slamem_amd import engine
     rng = np.random.default_rng(77)
@@ -98,7 +98,7 @@ def test_reference_with_long_diverged_repeats_builds_exactly():
     exact 40 kbp duplication (LCP 40,000 -> 12 prefix-doubling rounds).  SA / LCP / links must equal the oracle's."""
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     from oracle import pyoracle as po
     from slamem_amd import capi, engine
     rng = np.random.default_rng(123)

@@ -52,7 +52,7 @@ def random_case(rng):
 def test_random_case_matches_oracle_in_order(seed, mam):
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     from oracle import pyoracle as po
     from slamem_amd import engine
     rng = np.random.default_rng(1000 + seed)
@@ -79,7 +79,7 @@ def test_prefilter_never_drops_a_strand_with_a_barely_long_enough_mem(l):
     strands.  k = 12 for this text, so l = 12..17 takes the two-level path, l >= 18 the one-level path."""
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     from oracle import pyoracle as po
     from slamem_amd import engine
     rng = np.random.default_rng(500 + l)
