@@ -62,8 +62,7 @@ def test_random_case_matches_oracle_in_order(seed, mam):
     off[1:] = np.cumsum([len(x) for x in qs])
     o = po.OracleIndex(text)
     om, obc = o.match_batch(q, off, l, both, mam=mam)
-    if len(om) > 3_000_000:
-        pytest.skip("degenerate case with millions of MEMs")
+    assert len(om) <= 3_000_000  # all 80 cases run: the largest of these seeds has 590,034 MEMs (checked on the CPU)
     g = engine.Index.build(text)
     gm, goff = g.find_mems(q, off, l, both, mam=mam)
     assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64)), (len(text), l, both)
