@@ -693,12 +693,160 @@ void make_view(slamem_index* idx) {
     idx->view.num_n = h.num_n;
 }
 
-int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t stream, slamem_index** out) {
+// Arena layout for a text of n letters (num_n of them N) -- the header's section offsets and sizes.
+//   layout 1 (full):    every section; ~37.5 B per letter + 16-32 B of presence filter
+//   layout 2 (compact): no text-ordered sections (K8 walks the index where it would have compared with the text) and a
+//                       presence filter of half the size (no (k+2)-mers): ~21.5 B per letter + 8-16 B of filter
+// Environment switches (experiments): SLAMEM_KFILTER=0, SLAMEM_TEXT_SECTIONS=0, SLAMEM_KJUMP=<K>, SLAMEM_KBITS / SLAMEM_SKIP.
+static void plan_arena(uint32_t n, uint32_t num_n, int layout, ArenaHeader& hdr) {
+    const uint64_t R = (uint64_t)n + 1;
+    const uint32_t nblocks = (uint32_t)((R + 1 + kFmRows - 1) >> kFmRowsLog2);  // occ(c, <= n) reads offset n+1
+    const bool compact = layout == 2;
+    hdr.magic_lo = kArenaMagicLo;
+    hdr.magic_hi = kArenaMagicHi;
+    hdr.version = kArenaVersion;
+    hdr.n = n;
+    hdr.nblocks = nblocks;
+    hdr.num_n = num_n;
+    hdr.layout = compact ? 2u : 1u;
+    uint64_t off = kHeaderBytes;
+    hdr.off_fm = off;    off = align_up(off + (uint64_t)nblocks * sizeof(FMBlock), 256);
+    hdr.off_rec = off;   off = align_up(off + (R + 1) * sizeof(RowRec), 256);
+    hdr.off_sa = off;    off = align_up(off + R * 4, 256);
+    hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
+    {   // k-mer presence filter: 128 bits per text character (rounded up to a power of two of words), n >= k only
+        const char* kf = getenv("SLAMEM_KFILTER");
+        // k grows with the text: a random k-mer occurs with probability ~ n / 4^k, which must stay well below
+        // 1 / (probes per strand) for the filter to discriminate; k = ceil(log4 n) + 4 keeps it near 0.2 %
+        uint32_t kf_k = 4;
+        for (uint64_t v = 1; v < (uint64_t)n; v <<= 2) kf_k++;
+        if (kf_k < 12) kf_k = 12;
+        if (kf_k > 26) kf_k = 26;  // (never reached: n < 2^32 gives k <= 20; the build packs k+6 letters into 64 bits)
+        bool want = !(kf && atoi(kf) == 0) && n >= kf_k;
+        if (want) {
+            // two 64-bit words per text position (nine entries of three bits each per position: a sixth of the bits set)
+            uint32_t lg = 10;
+            while ((1ull << lg) < 2ull * (uint64_t)n && lg < 32) lg++;
+            if (compact && lg > 10) lg--;  // half the words: one per position (or fewer), (k-2)- and k-mers only
+            // texts above 2^31 letters get fewer than two words per position (2^32 words is the most the line index of
+            // a hash allows here without a 64 GiB section): their filter holds no (k+2)-mers -- four entries per position
+            // instead of nine, so that a test still lets only ~0.2 % through (with all nine at 1.4 words per position it
+            // was 1.8 %: at 3.1 Gbp and -l 20, 7.3 M of 10 M strands survived instead of 6.3 M); the search then stops
+            // its cascade at the k-mers
+            hdr.kfilter_levels = (1ull << lg) < 2ull * (uint64_t)n ? 2u : 3u;
+            hdr.off_kfilter = off;
+            hdr.kfilter_log2 = lg;
+            hdr.kfilter_k = kf_k;
+            off = align_up(off + (8ull << lg), 256);
+        }
+    }
+    const uint64_t ngroups = (R >> 4) + 2;
+    {   // text-ordered sections for the direct extension of unique matches (K8); SLAMEM_TEXT_SECTIONS=0 builds without
+        const char* de = getenv("SLAMEM_TEXT_SECTIONS");
+        if (!compact && !(de && atoi(de) == 0)) {
+            hdr.off_tgrp = off; off = align_up(off + ngroups * sizeof(TextGroup), 256);
+            hdr.off_prec = off; off = align_up(off + R * sizeof(TextRec), 256);
+        }
+    }
+    {   // K-mer jump table: K = floor(log4 n) - 1, at most 12 (134 MB); SLAMEM_KJUMP=0 builds without
+        const char* kj = getenv("SLAMEM_KJUMP");
+        uint32_t K = 0;
+        for (uint64_t v = n; v >= 4; v >>= 2) K++;
+        K = K > 1 ? K - 1 : 0;
+        if (K > 12) K = 12;
+        if (kj && atoi(kj) >= 0 && (uint32_t)atoi(kj) < K) K = (uint32_t)atoi(kj);
+        if (K > 0) {
+            hdr.kjump_k = K;
+            hdr.off_kjump = off; off = align_up(off + (8ull << (2u * K)), 256);
+        }
+    }
+    {   // k-mer occurrence bitmap: k = ceil(log4 n) + 2 (at most 16: the value fits 32 bits, the bitmap 512 MB), only while
+        // fewer than a tenth of all k-mers occur -- a denser bitmap proves nothing absent.  Only the skipping states of K8
+        // read it, and they are not the default (DESIGN.md 9): built when SLAMEM_SKIP=1 (or SLAMEM_KBITS=1) is set
+        const char* kb = getenv("SLAMEM_KBITS");
+        const char* sk = getenv("SLAMEM_SKIP");
+        const bool want_kbits = !compact && ((kb && atoi(kb) != 0) || (!kb && sk && atoi(sk) != 0));
+        uint32_t k = 2;
+        for (uint64_t v = 1; v < (uint64_t)n; v <<= 2) k++;
+        if (k < 8) k = 8;
+        if (k > 16) k = 16;
+        if (want_kbits && n >= k && (uint64_t)n * 10ull <= (1ull << (2u * k))) {
+            hdr.kbits_k = k;
+            hdr.off_kbits = off; off = align_up(off + ((1ull << (2u * k)) >> 3), 256);
+        }
+    }
+    hdr.total_bytes = off;
+}
+
+// What the suffix sort borrows from the arena (regions written only after it) and what it must allocate beside it.
+// Shared by the build (which walks the same list) and by the estimate below.
+static const uint64_t kBorrowBytesPerRow[6] = {8, 4, 4, 4, 4, 4};  // keysB, valsA, valsB, tmp32, gh, posB
+static uint64_t own_scratch_bytes(const ArenaHeader& hdr) {
+    const uint64_t R = (uint64_t)hdr.n + 1;
+    uint64_t left[3] = {(R + 1) * sizeof(RowRec), hdr.off_kfilter ? (8ull << hdr.kfilter_log2) : 0ull,
+                        hdr.off_prec ? R * sizeof(TextRec) : 0ull};
+    // never borrowed: packed text, keysA (later LCP+1 and PSV), rank, two flag arrays, posA (later NSV), radix-sort scratch
+    uint64_t own = ((R + 15) / 16 + 264) * 8 + ((R + 1) * 8 + 64) + R * 4 + 2 * R + (R + 1) * 4 + R * 4 + (64ull << 20);
+    for (uint64_t per : kBorrowBytesPerRow) {
+        uint64_t bytes = align_up(R * per, 16);
+        bool fit = false;
+        for (uint64_t& l : left)
+            if (!fit && l >= bytes) { l -= bytes; fit = true; }
+        if (!fit) own += bytes;
+    }
+    return own;
+}
+
+int estimate_build_bytes(uint32_t n, int layout, uint64_t* arena_bytes, uint64_t* peak_bytes) {
+    if (n == 0 || n > 0xFFFFFFF0u || (layout != 1 && layout != 2)) {
+        set_error("slamem_index_build_bytes: n must be 1 .. 2^32-17 and layout 1 (full) or 2 (compact)");
+        return SLAMEM_ERR_ARG;
+    }
+    ArenaHeader hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    plan_arena(n, 0, layout, hdr);
+    if (arena_bytes) *arena_bytes = hdr.total_bytes;
+    if (peak_bytes) *peak_bytes = hdr.total_bytes + own_scratch_bytes(hdr);
+    return SLAMEM_OK;
+}
+
+// layout 0: full when its build peak fits the free HBM of the device (SLAMEM_HBM_BUDGET_GB caps what counts as free),
+// compact when only that fits; SLAMEM_INDEX_LAYOUT=full|compact decides for callers that pass 0.
+static int choose_layout(uint32_t n, int layout, int* chosen) {
+    if (layout == 1 || layout == 2) { *chosen = layout; return SLAMEM_OK; }
+    if (layout != 0) { set_error("slamem_index_build: layout must be 0 (auto), 1 (full) or 2 (compact)"); return SLAMEM_ERR_ARG; }
+    const char* env = getenv("SLAMEM_INDEX_LAYOUT");
+    if (env && (!strcmp(env, "full") || !strcmp(env, "1"))) { *chosen = 1; return SLAMEM_OK; }
+    if (env && (!strcmp(env, "compact") || !strcmp(env, "2"))) { *chosen = 2; return SLAMEM_OK; }
+    size_t free_b = 0, total_b = 0;
+    SLAMEM_HIP(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = free_b;
+    if ((env = getenv("SLAMEM_HBM_BUDGET_GB")) != nullptr && atof(env) > 0) {
+        uint64_t cap = (uint64_t)(atof(env) * 1073741824.0);
+        if (cap < budget) budget = cap;
+    }
+    uint64_t arena = 0, peak_full = 0, peak_compact = 0;
+    estimate_build_bytes(n, 1, &arena, &peak_full);
+    estimate_build_bytes(n, 2, &arena, &peak_compact);
+    const uint64_t margin = 256ull << 20;
+    if (peak_full + margin <= budget) { *chosen = 1; return SLAMEM_OK; }
+    if (peak_compact + margin <= budget) { *chosen = 2; return SLAMEM_OK; }
+    set_error("slamem_index_build: a text of %u letters needs %.1f GB of HBM while it is built (%.1f GB in the compact layout); "
+              "%.1f GB are free", n, (double)peak_full / 1e9, (double)peak_compact / 1e9, (double)budget / 1e9);
+    return SLAMEM_ERR_NOMEM;
+}
+
+int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t stream, int layout_arg, slamem_index** out) {
     if (!text_dev || !out || n == 0 || n > 0xFFFFFFF0u) {
         set_error("slamem_index_build: text must hold 1 .. 2^32-17 characters");
         return SLAMEM_ERR_ARG;
     }
     SLAMEM_HIP(hipSetDevice(device));
+    int layout = 0;
+    {
+        int rc = choose_layout(n, layout_arg, &layout);
+        if (rc != SLAMEM_OK) return rc;
+    }
     const uint32_t rows = n + 1;
     const uint64_t R = rows;
     constexpr uint64_t kPackSlack = 264;  // zero words behind the text: window16() reads one word ahead, wave_extend_lcp up to 4096 letters more
@@ -746,81 +894,11 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     // ---- arena ------------------------------------------------------------------------------
     ArenaHeader hdr;
     memset(&hdr, 0, sizeof(hdr));
-    hdr.magic_lo = kArenaMagicLo;
-    hdr.magic_hi = kArenaMagicHi;
-    hdr.version = kArenaVersion;
-    hdr.n = n;
-    hdr.nblocks = nblocks;
-    hdr.num_n = num_n;
+    plan_arena(n, num_n, layout, hdr);
     hdr.C[0] = 0;
     hdr.C[1] = 1;
     for (int c = 2; c < 6; c++) hdr.C[c] = hdr.C[c - 1] + h_scal[c - 1];
-    uint64_t off = kHeaderBytes;
-    hdr.off_fm = off;    off = align_up(off + (uint64_t)nblocks * sizeof(FMBlock), 256);
-    hdr.off_rec = off;   off = align_up(off + (R + 1) * sizeof(RowRec), 256);
-    hdr.off_sa = off;    off = align_up(off + R * 4, 256);
-    hdr.off_nrows = off; off = align_up(off + (uint64_t)(num_n ? num_n : 1) * 4, 256);
-    {   // k-mer presence filter: 128 bits per text character (rounded up to a power of two of words), n >= k only
-        const char* kf = getenv("SLAMEM_KFILTER");
-        // k grows with the text: a random k-mer occurs with probability ~ n / 4^k, which must stay well below
-        // 1 / (probes per strand) for the filter to discriminate; k = ceil(log4 n) + 4 keeps it near 0.2 %
-        uint32_t kf_k = 4;
-        for (uint64_t v = 1; v < (uint64_t)n; v <<= 2) kf_k++;
-        if (kf_k < 12) kf_k = 12;
-        if (kf_k > 26) kf_k = 26;  // (never reached: n < 2^32 gives k <= 20; the build packs k+6 letters into 64 bits)
-        bool want = !(kf && atoi(kf) == 0) && n >= kf_k;
-        if (want) {
-            // two 64-bit words per text position (nine entries of three bits each per position: a sixth of the bits set)
-            uint32_t lg = 10;
-            while ((1ull << lg) < 2ull * (uint64_t)n && lg < 32) lg++;
-            // texts above 2^31 letters get fewer than two words per position (2^32 words is the most the line index of
-            // a hash allows here without a 64 GiB section): their filter holds no (k+2)-mers -- four entries per position
-            // instead of nine, so that a test still lets only ~0.2 % through (with all nine at 1.4 words per position it
-            // was 1.8 %: at 3.1 Gbp and -l 20, 7.3 M of 10 M strands survived instead of 6.3 M); the search then stops
-            // its cascade at the k-mers
-            hdr.kfilter_levels = (1ull << lg) < 2ull * (uint64_t)n ? 2u : 3u;
-            hdr.off_kfilter = off;
-            hdr.kfilter_log2 = lg;
-            hdr.kfilter_k = kf_k;
-            off = align_up(off + (8ull << lg), 256);
-        }
-    }
     const uint64_t ngroups = (R >> 4) + 2;
-    {   // text-ordered sections for the direct extension of unique matches (K8); SLAMEM_TEXT_SECTIONS=0 builds without
-        const char* de = getenv("SLAMEM_TEXT_SECTIONS");
-        if (!(de && atoi(de) == 0)) {
-            hdr.off_tgrp = off; off = align_up(off + ngroups * sizeof(TextGroup), 256);
-            hdr.off_prec = off; off = align_up(off + R * sizeof(TextRec), 256);
-        }
-    }
-    {   // K-mer jump table: K = floor(log4 n) - 1, at most 12 (134 MB); SLAMEM_KJUMP=0 builds without
-        const char* kj = getenv("SLAMEM_KJUMP");
-        uint32_t K = 0;
-        for (uint64_t v = n; v >= 4; v >>= 2) K++;
-        K = K > 1 ? K - 1 : 0;
-        if (K > 12) K = 12;
-        if (kj && atoi(kj) >= 0 && (uint32_t)atoi(kj) < K) K = (uint32_t)atoi(kj);
-        if (K > 0) {
-            hdr.kjump_k = K;
-            hdr.off_kjump = off; off = align_up(off + (8ull << (2u * K)), 256);
-        }
-    }
-    {   // k-mer occurrence bitmap: k = ceil(log4 n) + 2 (at most 16: the value fits 32 bits, the bitmap 512 MB), only while
-        // fewer than a tenth of all k-mers occur -- a denser bitmap proves nothing absent.  Only the skipping states of K8
-        // read it, and they are not the default (DESIGN.md 9): built when SLAMEM_SKIP=1 (or SLAMEM_KBITS=1) is set
-        const char* kb = getenv("SLAMEM_KBITS");
-        const char* sk = getenv("SLAMEM_SKIP");
-        const bool want_kbits = (kb && atoi(kb) != 0) || (!kb && sk && atoi(sk) != 0);
-        uint32_t k = 2;
-        for (uint64_t v = 1; v < (uint64_t)n; v <<= 2) k++;
-        if (k < 8) k = 8;
-        if (k > 16) k = 16;
-        if (want_kbits && n >= k && (uint64_t)n * 10ull <= (1ull << (2u * k))) {
-            hdr.kbits_k = k;
-            hdr.off_kbits = off; off = align_up(off + ((1ull << (2u * k)) >> 3), 256);
-        }
-    }
-    hdr.total_bytes = off;
 
     // ---- memory plan -------------------------------------------------------------------------------------------
     // The arena is allocated FIRST and lends its row-record and filter regions to the suffix sort (they are written

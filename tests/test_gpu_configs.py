@@ -76,6 +76,47 @@ def check_sampled_mems(rows, ref_h, reads_h, L, min_len, sample, seed=0):
     return bad, len(sel)
 
 
+def read_starts(n, L, count, seed=42):
+    """Text position every synthetic read was drawn from (slamem_amd/synth.py draw layout)."""
+    from slamem_amd import synth
+    base = np.uint64(n) + np.arange(count, dtype=np.uint64) * np.uint64(L + 2)
+    return (synth.splitmix64_at(seed, base) % np.uint64(n - L + 1)).astype(np.int64)
+
+
+def verifier_sample(n, L, count, seed, n_random, n_high, n_repeat):
+    """Reads for the definitional verifier: random ones, ones drawn from beyond text position 2^31 (when the text is that
+    long) and ones drawn from inside a planted repeat (source or copy), all seeded."""
+    from slamem_amd import synth
+    p = read_starts(n, L, count, seed)
+    rng = np.random.default_rng(12345)
+    picks = [rng.choice(count, size=min(count, n_random), replace=False)]
+    high = np.nonzero(p >= (1 << 31))[0]
+    if len(high):
+        picks.append(rng.choice(high, size=min(len(high), n_high), replace=False))
+    segs = np.array([(ln, src, dst) for _, ln, src, dst in synth.repeat_segments(n, seed)], dtype=np.int64)
+    inside = np.zeros(count, dtype=bool)
+    for col in (1, 2):
+        o = np.argsort(segs[:, col])
+        st, ln = segs[o, col], segs[o, 0]
+        i = np.searchsorted(st, p, "right") - 1
+        ok = i >= 0
+        inside[ok] |= p[ok] + L <= st[i[ok]] + ln[i[ok]]
+    rep = np.nonzero(inside)[0]
+    picks.append(rng.choice(rep, size=min(len(rep), n_repeat), replace=False))
+    return np.unique(np.concatenate(picks)), int((p[picks[-1]] >= 0).sum()), (int(len(picks[1])) if len(high) else 0)
+
+
+def check_complete(ref_h, ref_dev, reads_h, rows, sample, min_len, label):
+    """Set equality, on the sampled reads, of the engine's MEMs with the index-independent definitional set
+    (tests/mem_verifier.py; semantics of slamem.c:139-193)."""
+    import mem_verifier as mv
+    res = mv.verify_sample(ref_h, ref_dev, reads_h, sample, rows, min_len, True)
+    note(label, {k: v for k, v in res.items() if k not in ("missing", "extra")})
+    assert res["missing_count"] == 0 and res["extra_count"] == 0 and res["engine_duplicates"] == 0, res
+    assert res["definitional_mems"] > 0
+    return res
+
+
 def check_sampled_rows(idx, ref_h, rows_to_check):
     """Suffixes of neighbouring BWT rows are in the index's letter order ($ < N < A < C < G < T)."""
     n = ref_h.shape[0]
@@ -201,6 +242,10 @@ def test_config4_chr1_sized_known_answer(eng):
     assert bad == 0 and checked == 30_000
     rr = np.random.default_rng(1).integers(1, n + 1, size=1500)
     assert check_sampled_rows(idx, ref_h, rr) == 0
+    # completeness: the definitional MEM set of 2,500 sampled reads (500 of them drawn from planted repeats) == the engine's
+    sample, in_repeats, _ = verifier_sample(n, L, share, 42, 2000, 0, 500)
+    assert in_repeats >= 400
+    check_complete(ref_h, ref, reads_h, rows, sample, min_len, "config4_share_verifier")
     note("config4_share_engine", got)
     assert got == {k: KNOWN["config4_share_engine"][k] for k in DIGEST_KEYS}, got
     idx.close()
@@ -243,6 +288,13 @@ def test_config5_grch38_sized_full_size_properties(eng):
     bad, checked = check_sampled_mems(rows, ref_h, reads_h, L, min_len, 30_000)
     assert bad == 0 and checked == 30_000
     assert int(rows[:, 1].max()) > (1 << 31)  # matches beyond text position 2^31 are found
+    # completeness beyond 2^31 rows: the definitional MEM set (every maximal match >= l, from the text and the reads alone,
+    # no index) of 2,600 sampled reads -- 1,500 random, 600 drawn from beyond position 2^31, 500 from planted repeats --
+    # equals the engine's output for those reads as a set
+    sample, in_repeats, high = verifier_sample(n, L, share, 42, 1500, 600, 500)
+    assert in_repeats >= 400 and high == 600
+    res = check_complete(ref_h, ref, reads_h, rows, sample, min_len, "config5_share_verifier")
+    assert res["definitional_beyond_2p31"] > 500
     rr = np.random.default_rng(2).integers(1, n + 1, size=1500)
     assert check_sampled_rows(idx, ref_h, rr) == 0
     note("config5_share_engine", got)
