@@ -290,7 +290,8 @@ def main():
                                    f"{a.sub:.0%} substitutions, {a.rc_percent}% reverse-complemented, "
                                    f"{'-b ' if both else ''}-l {a.min_len}",
                        "ref_len": n, "reads_total": r["reads"], "read_len": L, "min_len": a.min_len, "both_strands": both,
-                       "parallelism": f"query shards x{world}, index replicated by RCCL broadcast"},
+                       "parallelism": f"query shards x{world}, " + ("one GPU, no replication" if world == 1 else
+                                       f"index replicated by {'RCCL' if a.backend == 'nccl' else a.backend + ' (host-staged)'} broadcast")},
             "queries_per_sec": r["reads"] / per_step,
             "mems_per_step": r["mems"],
             "index_build_s": build_s,

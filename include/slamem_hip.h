@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SLAMEM_ABI_VERSION 2
+#define SLAMEM_ABI_VERSION 3
 
 enum {
     SLAMEM_OK = 0,
@@ -63,8 +63,19 @@ typedef struct {
     int32_t device;
     int32_t owns_arena;
     uint32_t filter_k;     /* k of the k-mer presence filter (0 = the index has none); no reference counterpart */
-    uint32_t reserved;
+    uint32_t layout;       /* SLAMEM_LAYOUT_FULL or SLAMEM_LAYOUT_COMPACT: what the build chose (ABI 2: reserved, 0)   */
 } slamem_index_info;
+
+/* Index layouts (no reference counterpart: the reference has one layout of 3.3 B per letter made for CPU caches,
+ * bwtindex.c:33-37 + lcparray.c:46-57; here HBM is spent to cut dependent random reads).
+ *   FULL     every section: ~37.5 B per text letter + 16-32 B of presence filter (6.0 GB at 100 Mbp, 151 GB at 3.1 Gbp)
+ *   COMPACT  no text-ordered sections (the search walks the index where it would have compared with the text) and a
+ *            presence filter of half the size: ~21.5 B per letter + 8-16 B (3.3 GB at 100 Mbp, 81 GB at 3.1 Gbp); same
+ *            results, slower search (DESIGN.md 2 has the measured cost)
+ *   AUTO     FULL when its build peak fits the HBM that is free on the device, else COMPACT, else SLAMEM_ERR_NOMEM with
+ *            the numbers in the message.  SLAMEM_INDEX_LAYOUT=full|compact in the environment decides instead;
+ *            SLAMEM_HBM_BUDGET_GB caps what counts as free. */
+enum { SLAMEM_LAYOUT_AUTO = 0, SLAMEM_LAYOUT_FULL = 1, SLAMEM_LAYOUT_COMPACT = 2 };
 
 /* Per-phase device times of the last build / search on this thread's most recent
  * call, in milliseconds, measured with HIP events on the stream the kernels ran on. */
@@ -130,6 +141,9 @@ int slamem_device_warmup(int device);
 /* PCI address of `device` ("0000:c1:00.0"): a front end reads /sys/bus/pci/devices/<address>/local_cpulist to keep its host
  * threads on the GPU's NUMA node.  No reference counterpart. */
 int slamem_device_pci_bus_id(int device, char *out, int out_bytes);
+/* Free and total HBM of `device` in bytes (hipMemGetInfo): a front end that starts right behind another GPU job waits
+ * for the memory its index needs (slamem_index_build_bytes) instead of failing.  No reference counterpart. */
+int slamem_device_mem_info(int device, uint64_t *free_out, uint64_t *total_out);
 int slamem_get_timings(slamem_timings *out);
 int slamem_reset_timings(void);
 /* on != 0: the NEXT slamem_find_mems_device calls of this thread run the diagnostic kernel instantiations (same results,
@@ -150,6 +164,13 @@ int slamem_get_search_clock(double *us_to_empty_list, double *us_tail, double *u
  * BWT bit-planes + rank samples, exact LCP, PSV/NSV links. */
 int slamem_index_build(const char *text_host, uint32_t n, int device, slamem_index **out);
 int slamem_index_build_device(const void *text_dev, uint32_t n, int device, void *stream, slamem_index **out);
+/* The same with the layout stated (SLAMEM_LAYOUT_*; the two entry points above pass SLAMEM_LAYOUT_AUTO). */
+int slamem_index_build_layout(const char *text_host, uint32_t n, int device, int layout, slamem_index **out);
+int slamem_index_build_device_layout(const void *text_dev, uint32_t n, int device, void *stream, int layout,
+                                     slamem_index **out);
+/* HBM a text of n letters takes in `layout` (SLAMEM_LAYOUT_FULL / _COMPACT): the arena that stays, and the peak while
+ * it is built (arena + suffix-sort scratch).  Host arithmetic only. */
+int slamem_index_build_bytes(uint32_t n, int layout, uint64_t *arena_bytes_out, uint64_t *peak_bytes_out);
 /* Replaces FMI_FreeIndex() + FreeSampledSuffixArray() (slamem.c:208-209). */
 int slamem_index_free(slamem_index *idx);
 int slamem_index_get_info(const slamem_index *idx, slamem_index_info *out);

@@ -23,12 +23,14 @@ SLAMEM_ERR_IO = 6
 SLAMEM_ERR_NO_DEVICE = 7
 
 ARRAY_SA, ARRAY_BWT, ARRAY_LCP, ARRAY_PSV, ARRAY_NSV = range(5)
+LAYOUT_AUTO, LAYOUT_FULL, LAYOUT_COMPACT = 0, 1, 2
 
 # every symbol include/slamem_hip.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = (
     "slamem_abi_version", "slamem_strerror", "slamem_last_error_message", "slamem_device_count",
     "slamem_get_timings", "slamem_reset_timings", "slamem_device_warmup", "slamem_device_pci_bus_id",
-    "slamem_index_build", "slamem_index_build_device", "slamem_index_free", "slamem_index_get_info",
+    "slamem_index_build", "slamem_index_build_device", "slamem_index_build_layout", "slamem_index_build_device_layout",
+    "slamem_index_build_bytes", "slamem_device_mem_info", "slamem_index_free", "slamem_index_get_info",
     "slamem_index_arena", "slamem_index_export", "slamem_index_attach", "slamem_index_adopt_arena", "slamem_index_save", "slamem_index_load",
     "slamem_index_validate_header", "slamem_search_stats_enable", "slamem_get_search_stats", "slamem_get_search_clock",
     "slamem_index_download", "slamem_index_sampled_lcp_stats",
@@ -55,7 +57,7 @@ class IndexInfo(C.Structure):
     _fields_ = [("text_length", C.c_uint32), ("bwt_size", C.c_uint32), ("num_n_rows", C.c_uint32),
                 ("dollar_row", C.c_uint32), ("max_lcp", C.c_uint32), ("sort_rounds", C.c_uint32),
                 ("arena_bytes", C.c_uint64), ("device", C.c_int32), ("owns_arena", C.c_int32),
-                ("filter_k", C.c_uint32), ("reserved", C.c_uint32)]
+                ("filter_k", C.c_uint32), ("layout", C.c_uint32)]
 
 
 class SslcpStats(C.Structure):
@@ -102,6 +104,10 @@ def _declare(L):
     L.slamem_get_timings.argtypes = [C.POINTER(Timings)]
     L.slamem_index_build.argtypes = [C.c_char_p, u32, i32, C.POINTER(vp)]
     L.slamem_index_build_device.argtypes = [vp, u32, i32, vp, C.POINTER(vp)]
+    L.slamem_index_build_layout.argtypes = [C.c_char_p, u32, i32, i32, C.POINTER(vp)]
+    L.slamem_index_build_device_layout.argtypes = [vp, u32, i32, vp, i32, C.POINTER(vp)]
+    L.slamem_index_build_bytes.argtypes = [u32, i32, C.POINTER(u64), C.POINTER(u64)]
+    L.slamem_device_mem_info.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
     L.slamem_index_free.argtypes = [vp]
     L.slamem_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     L.slamem_index_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
@@ -161,7 +167,7 @@ def lib():
         _load_torch_runtime_first()
         L = C.CDLL(LIB_PATH)
         _declare(L)
-        if L.slamem_abi_version() != 2:
+        if L.slamem_abi_version() != 3:
             raise ImportError("libslamem_hip.so ABI version mismatch")
         _LIB = L
     return _LIB

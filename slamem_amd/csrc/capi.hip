@@ -185,13 +185,37 @@ int slamem_reset_timings(void) {
     return SLAMEM_OK;
 }
 
-int slamem_index_build_device(const void* text_dev, uint32_t n, int device, void* stream, slamem_index** out) {
+int slamem_device_mem_info(int device, uint64_t* free_out, uint64_t* total_out) {
     int rc = check_device(device);
     if (rc) return rc;
-    return build_index_device(text_dev, n, device, static_cast<hipStream_t>(stream), out);
+    SLAMEM_HIP(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    SLAMEM_HIP(hipMemGetInfo(&f, &t));
+    if (free_out) *free_out = f;
+    if (total_out) *total_out = t;
+    return SLAMEM_OK;
+}
+
+int slamem_index_build_bytes(uint32_t n, int layout, uint64_t* arena_bytes_out, uint64_t* peak_bytes_out) {
+    return estimate_build_bytes(n, layout, arena_bytes_out, peak_bytes_out);
+}
+
+int slamem_index_build_device(const void* text_dev, uint32_t n, int device, void* stream, slamem_index** out) {
+    return slamem_index_build_device_layout(text_dev, n, device, stream, SLAMEM_LAYOUT_AUTO, out);
+}
+
+int slamem_index_build_device_layout(const void* text_dev, uint32_t n, int device, void* stream, int layout,
+                                     slamem_index** out) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    return build_index_device(text_dev, n, device, static_cast<hipStream_t>(stream), layout, out);
 }
 
 int slamem_index_build(const char* text_host, uint32_t n, int device, slamem_index** out) {
+    return slamem_index_build_layout(text_host, n, device, SLAMEM_LAYOUT_AUTO, out);
+}
+
+int slamem_index_build_layout(const char* text_host, uint32_t n, int device, int layout, slamem_index** out) {
     if (!text_host || !out || n == 0) { set_error("slamem_index_build: empty text"); return SLAMEM_ERR_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
@@ -200,7 +224,7 @@ int slamem_index_build(const char* text_host, uint32_t n, int device, slamem_ind
     SLAMEM_HIP(hipMalloc(&d, (size_t)n + 16));
     hipError_t e = hipMemcpy(d, text_host, n, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(text)", __FILE__, __LINE__); }
-    rc = build_index_device(d, n, device, nullptr, out);
+    rc = build_index_device(d, n, device, nullptr, layout, out);
     (void)hipFree(d);
     return rc;
 }
@@ -227,7 +251,7 @@ int slamem_index_get_info(const slamem_index* idx, slamem_index_info* out) {
     out->device = idx->device;
     out->owns_arena = idx->owns_arena;
     out->filter_k = idx->hdr.off_kfilter ? idx->hdr.kfilter_k : 0u;
-    out->reserved = 0;
+    out->layout = idx->hdr.layout == 2u ? SLAMEM_LAYOUT_COMPACT : SLAMEM_LAYOUT_FULL;
     return SLAMEM_OK;
 }
 

@@ -96,7 +96,8 @@ struct ArenaHeader {
     uint32_t kbits_k;     // k of the occurrence bitmap (0 = none)
     uint32_t kfilter_levels;  // 3 (or 0): (k-2)-, k- and (k+2)-mers; 2: no (k+2)-mers (texts above 2^31 letters)
     uint64_t off_kbits;   // uint64[4^kbits_k / 64]  one bit per k-mer over A,C,G,T: does it occur in the text?
-    uint32_t reserved[11];
+    uint32_t layout;      // 1 = full, 2 = compact (no text-ordered sections, half-size presence filter); 0 in arenas of older builds = full
+    uint32_t reserved[10];
 };
 static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 
@@ -181,7 +182,8 @@ struct slamem_index {
 
 namespace slamem {
 void make_view(slamem_index* idx);
-int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t stream, slamem_index** out);
+int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t stream, int layout, slamem_index** out);
+int estimate_build_bytes(uint32_t n, int layout, uint64_t* arena_bytes, uint64_t* peak_bytes);
 int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
                      uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
                      slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,

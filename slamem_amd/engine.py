@@ -53,8 +53,9 @@ class Index:
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
-    def build(cls, text, device="cuda:0") -> "Index":
-        """text: bytes / numpy uint8 / torch uint8 tensor (host or device) of A,C,G,T,N."""
+    def build(cls, text, device="cuda:0", layout: int = capi.LAYOUT_AUTO) -> "Index":
+        """text: bytes / numpy uint8 / torch uint8 tensor (host or device) of A,C,G,T,N.  layout: capi.LAYOUT_AUTO (full
+        when its build peak fits the free HBM, else compact), LAYOUT_FULL or LAYOUT_COMPACT (include/slamem_hip.h)."""
         dev = _require_gpu(device)
         L = capi.lib()
         if isinstance(text, (bytes, bytearray)):
@@ -68,7 +69,7 @@ class Index:
         h = C.c_void_p()
         with torch.cuda.device(dev):
             stream = _stream_handle(dev)
-            capi.check(L.slamem_index_build_device(_ptr(text), n, dev.index, stream, C.byref(h)))
+            capi.check(L.slamem_index_build_device_layout(_ptr(text), n, dev.index, stream, int(layout), C.byref(h)))
         return cls(h.value, dev)
 
     @classmethod
@@ -391,6 +392,13 @@ def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len
                              "note": "reads and record offsets in pinned host memory -> MEMs in pinned host memory through slamem_stream_* "
                                      "(uploads, kernels and downloads of neighbouring batches overlap); best of "
                                      f"{steps} passes over the same {count} reads"}}
+
+
+def build_bytes(n: int, layout: int = capi.LAYOUT_FULL) -> tuple[int, int]:
+    """(arena bytes, build peak bytes) of a text of n letters in `layout` (slamem_index_build_bytes; host arithmetic)."""
+    a, p = C.c_uint64(), C.c_uint64()
+    capi.check(capi.lib().slamem_index_build_bytes(int(n), int(layout), C.byref(a), C.byref(p)))
+    return int(a.value), int(p.value)
 
 
 def timings() -> dict:

@@ -11,9 +11,13 @@
  * SLAMEM_BATCH_MB bounds the query characters sent to the GPU per batch (default 256); SLAMEM_OVERLAP_MB (default 256):
  * query files above this size in total are parsed in pieces of SLAMEM_PIECE_MB (128) beside the search, -1 = never;
  * SLAMEM_NO_BIND=1 leaves the host threads where the scheduler puts them (default: on the CPUs local to the GPU);
- * SLAMEM_FULL_TEARDOWN=1 frees every buffer and the index before returning (default: the work runs in a forked worker,
- * the command returns as soon as the results are written and the worker ends with _exit; SLAMEM_FOREGROUND=1 keeps
- * it in one process).
+ * SLAMEM_FULL_TEARDOWN=1 frees every buffer and the index before returning (default: one process that ends with _exit
+ * once the results are written -- the command returns when its GPU memory is back, so a job started right behind it
+ * finds the device free, and schedulers see the job end when it ends).  SLAMEM_DETACH_TEARDOWN=1 (opt-in): the work runs
+ * in a forked worker and the command returns as soon as the results are written, while the worker still gives back its
+ * HBM and pinned memory behind the caller's back (0.3-0.4 s for the reference-sized run); never use it under a profiler
+ * (the fork would follow the profiler's GPU initialisation).  SLAMEM_WAIT_HBM_S (default 30): how long start-up waits
+ * for the HBM the index needs to become free (the tail of such a detached worker, or any other job) before it builds.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -248,9 +252,37 @@ typedef struct {
     char err[512];
 } build_job;
 
+/* A job that starts right behind another one (a detached worker still giving back its arena, any other tenant of the
+ * GPU) finds less HBM free than it will have a moment later: wait, with a bound, until the full layout's build peak
+ * fits -- or the compact layout's when the device could never hold the full one -- instead of failing or silently
+ * taking the slower layout.  The reference frees before it reports (slamem.c:208-216); this is the other half. */
+static void wait_for_hbm(const build_job *b) {
+    uint64_t arena = 0, peak_full = 0, peak_compact = 0, free_b = 0, total_b = 0, want;
+    const char *env = getenv("SLAMEM_WAIT_HBM_S");
+    double limit = env ? atof(env) : 30.0, t0 = now_s();
+    int told = 0;
+    if (limit <= 0) return;
+    if (slamem_index_build_bytes(b->n, SLAMEM_LAYOUT_FULL, &arena, &peak_full) != SLAMEM_OK) return;
+    if (slamem_index_build_bytes(b->n, SLAMEM_LAYOUT_COMPACT, &arena, &peak_compact) != SLAMEM_OK) return;
+    for (;;) {
+        if (slamem_device_mem_info(b->device, &free_b, &total_b) != SLAMEM_OK) return;
+        want = (peak_full + (1ull << 30) <= total_b ? peak_full : peak_compact) + (256ull << 20);
+        if (free_b >= want || want > total_b || now_s() - t0 > limit) break;
+        if (!told) {
+            fprintf(stderr, "> Waiting for HBM on GPU %d: %.1f GB free, %.1f GB needed to build the index (another job is still releasing its memory?)\n",
+                    b->device, (double)free_b / 1e9, (double)want / 1e9);
+            told = 1;
+        }
+        usleep(50000);
+    }
+    if (told) fprintf(stderr, "> Waited %.2f s for HBM (%.1f GB free now)\n", now_s() - t0, (double)free_b / 1e9);
+}
+
 static void *build_run(void *arg) {
     build_job *b = (build_job *)arg;
-    double t0 = now_s();
+    double t0;
+    wait_for_hbm(b);
+    t0 = now_s();
     b->rc = slamem_index_build(b->text, b->n, b->device, &b->idx);
     if (b->rc == SLAMEM_OK) {
         slamem_index_get_info(b->idx, &b->info);
@@ -409,6 +441,14 @@ static void bind_to_gpu_node(int device) {
     if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
     CPU_AND(&both, &local, &allowed);
     if (CPU_COUNT(&both) == 0 || CPU_COUNT(&both) == CPU_COUNT(&allowed)) return; /* nothing local allowed / already local */
+    {   /* not onto a handful of CPUs: the loader and formatter threads need room (a cpuset that leaves one or two local
+           CPUs would serialise them), and a mask the user narrowed on purpose is left alone */
+        int want = slh_thread_count(), half = CPU_COUNT(&allowed) / 2;
+        long online = sysconf(_SC_NPROCESSORS_ONLN);
+        if (want > half) want = half;
+        if (CPU_COUNT(&both) < want) return;
+        if (online > 0 && CPU_COUNT(&allowed) < (int)online && getenv("SLAMEM_BIND") == NULL) return;
+    }
     d = opendir("/proc/self/task");
     if (!d) { (void)sched_setaffinity(0, sizeof(both), &both); return; }
     while ((e = readdir(d)) != NULL)
@@ -416,8 +456,9 @@ static void bind_to_gpu_node(int device) {
     closedir(d);
 }
 
+static int g_warm_ok = 0;
 static void *warmup_run(void *arg) { /* HIP runtime + context start-up, hidden behind the parsing of the reference file */
-    if (slamem_device_warmup(*(int *)arg) == SLAMEM_OK) bind_to_gpu_node(*(int *)arg);
+    g_warm_ok = slamem_device_warmup(*(int *)arg) == SLAMEM_OK;
     return NULL;
 }
 
@@ -432,10 +473,14 @@ static pid_t g_child = 0;
 static void forward_signal(int sig) {
     if (g_child > 0) kill(g_child, sig);
 }
+/* has the process that forked us gone already?  (PR_SET_PDEATHSIG only covers a death AFTER the prctl call.)  Compared
+ * with the pid the front had before the fork: getppid() == 1 says nothing when the front itself is pid 1 of a container,
+ * and never happens under a subreaper. */
+static int front_is_gone(pid_t front) { return getppid() != front; }
 static void split_off_worker(void) {
     int pfd[2];
-    pid_t pid;
-    if (getenv("SLAMEM_FOREGROUND") != NULL || pipe(pfd) != 0) return;
+    pid_t pid, front = getpid();
+    if (getenv("SLAMEM_DETACH_TEARDOWN") == NULL || getenv("SLAMEM_FOREGROUND") != NULL || pipe(pfd) != 0) return;
     fflush(stdout);
     fflush(stderr);
     pid = fork();
@@ -444,7 +489,7 @@ static void split_off_worker(void) {
         close(pfd[0]);
         g_done_fd = pfd[1];
         prctl(PR_SET_PDEATHSIG, SIGTERM); /* no worker without its front */
-        if (getppid() == 1) _exit(255);
+        if (front_is_gone(front)) _exit(255);
         return;
     }
     close(pfd[1]);
@@ -463,6 +508,7 @@ static void split_off_worker(void) {
     }
 }
 static void leave_now(void) { /* results complete: tell the front, then end without returning memory piece by piece */
+    const char *linger = getenv("SLAMEM_TEST_LINGER_MS"); /* tests: hold the GPU memory this long after "done" */
     fflush(stdout);
     fflush(stderr);
     if (g_done_fd >= 0) {
@@ -470,6 +516,7 @@ static void leave_now(void) { /* results complete: tell the front, then end with
         close(1);
         close(2);
         if (write(g_done_fd, &c, 1) != 1) _exit(255);
+        if (linger && atoi(linger) > 0) usleep((useconds_t)atoi(linger) * 1000u);
     }
     _exit(0);
 }
@@ -609,6 +656,7 @@ int main(int argc, char **argv) {
     if (build_async) pthread_join(build_tid, NULL); /* before any exit: never leave the process with a build in flight */
     else build_run(&bj);
     join_warmup();
+    if (g_warm_ok) bind_to_gpu_node(device); /* from the main thread, before the worker threads below exist: they inherit the mask */
     double t_join = now_s() - t_join0, t_streams = 0;
     if (!overlap) {
         if (ld->ready == 0) exit_message("No query files provided"); /* slamem.c:648 */
@@ -644,7 +692,8 @@ int main(int argc, char **argv) {
         say("> Suffix sort + BWT + LCP + parent links on GPU %d ... OK (%.3f s, overlapped with the loading of the queries; device %.1f ms: sort %.1f, BWT %.1f, LCP %.1f, links %.1f; %u doubling rounds)\n",
                device, bj.seconds, tm.build_total_ms, tm.build_sort_ms, tm.build_bwt_ms, tm.build_lcp_ms, tm.build_links_ms,
                info.sort_rounds);
-        say(":: Index size = %.1f MB in HBM (FM blocks + 16 B per row)\n", (double)info.arena_bytes / 1e6);
+        say(":: Index size = %.1f MB in HBM (%s layout)\n", (double)info.arena_bytes / 1e6,
+            info.layout == SLAMEM_LAYOUT_COMPACT ? "compact" : "full");
         {   /* the statistics lines of BuildSampledLCPArray (lcparray.c:709-711, 999-1000), from the per-row records */
             slamem_sslcp_stats st = bj.st;
             unsigned bwt_len = info.bwt_size;
@@ -662,6 +711,7 @@ int main(int argc, char **argv) {
     /* SLAMEM_GPUS=N: replicate the index to N GPUs (device, device+1, ...) with one RCCL broadcast of its arena over
        xGMI; every batch is then split by bases into N contiguous shares, one per GPU (no data-path collective). */
     gpus[0] = idx;
+    int logical = 0; /* SLAMEM_LOGICAL_GPUS=N (self-test): N "GPUs" that are all this device, each with its own copy of the index */
     if ((env = getenv("SLAMEM_GPUS")) != NULL) {
         int avail = 0;
         slamem_device_count(&avail);
@@ -669,11 +719,14 @@ int main(int argc, char **argv) {
         if (ngpu < 1) ngpu = 1;
         if (ngpu > 16) ngpu = 16;
         if (device + ngpu > avail) exit_message("SLAMEM_GPUS asks for more GPUs than are visible");
+    } else if ((env = getenv("SLAMEM_LOGICAL_GPUS")) != NULL && atoi(env) > 1) {
+        ngpu = atoi(env) > 16 ? 16 : atoi(env);
+        logical = 1;
     }
     if (ngpu > 1 || getenv("SLAMEM_REPLICATE_SELFTEST") != NULL) {
         int devs[16], g;
         double tr = now_s();
-        for (g = 0; g < ngpu; g++) devs[g] = device + g;
+        for (g = 0; g < ngpu; g++) devs[g] = logical ? device : device + g;
         {   /* libslamem_rccl.so (and RCCL behind it, hundreds of MB of code) is loaded only when it is needed: a
                one-GPU run never pays for it at start-up */
             typedef int (*replicate_fn)(const slamem_index *, const int *, int, int, slamem_index **);
@@ -685,11 +738,16 @@ int main(int argc, char **argv) {
                 join_warmup();
                 exit(-1);
             }
-            rc = fn(idx, devs, ngpu, ngpu == 1, gpus);
+            if (logical) { /* one one-rank broadcast into a fresh arena per logical GPU: the scheduling below is the real N-GPU one */
+                for (g = 1, rc = SLAMEM_OK; g < ngpu && rc == SLAMEM_OK; g++) rc = fn(idx, devs, 1, 1, &gpus[g]);
+            } else {
+                rc = fn(idx, devs, ngpu, ngpu == 1, gpus);
+            }
         }
         if (rc != SLAMEM_OK) gpu_fail("index replication over RCCL", rc);
         if (ngpu == 1) { slamem_index_free(idx); idx = gpus[0]; } /* self-test: search on the broadcast copy */
-        say("> Index replicated to %d GPU%s by RCCL broadcast ... OK (%.3f s)\n", ngpu, ngpu == 1 ? " (self-test copy)" : "s", now_s() - tr);
+        say("> Index replicated to %d %sGPU%s by RCCL broadcast ... OK (%.3f s)\n", ngpu, logical ? "logical " : "",
+            ngpu == 1 ? " (self-test copy)" : "s", now_s() - tr);
     }
     t_build = bj.seconds + (now_s() - t0);
     free(ref.chars); /* the reference frees the text here too (slamem.c:75-77) */

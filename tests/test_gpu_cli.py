@@ -169,3 +169,110 @@ def test_cli_rccl_replication_selftest(tmp_path):
     # asking for more GPUs than exist fails loudly
     r = subprocess.run([exe, "-o", out, ref_fa, q_fa], stdout=subprocess.PIPE, env=dict(os.environ, SLAMEM_GPUS="64"))
     assert r.returncode == 255
+
+
+def _sha(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def test_cli_n_gpu_schedule_on_logical_gpus(tmp_path):
+    """The N-GPU path of the C front end (batch b on GPU b mod N, results collected in order; shard rule slamem.c:90-95:
+    records are independent) with N = 2 and N = 3 LOGICAL GPUs mapped onto the one device of the test box
+    (SLAMEM_LOGICAL_GPUS: every logical GPU gets its own RCCL-broadcast copy of the index and its own slamem_stream).
+    20 Mbp reference, 200,000 reads in ~17 batches, -b -l 20: the output file must be the N = 1 file byte for byte."""
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
+    gen = os.path.join(hostlib.ROOT, "tools", "gen_synth.py")
+    d = str(tmp_path)
+    g = subprocess.run([sys.executable, gen, "20000000", "200000", "150", "0.02", "7", "50", d], stdout=subprocess.PIPE)
+    assert g.returncode == 0
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    base = dict(os.environ, SLAMEM_BATCH_MB="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    shas = {}
+    for n in (1, 2, 3):
+        out = os.path.join(d, f"out{n}.txt")
+        env = dict(base) if n == 1 else dict(base, SLAMEM_LOGICAL_GPUS=str(n))
+        r = subprocess.run([exe, "-b", "-l", "20", "-o", out, os.path.join(d, "ref.fa"), os.path.join(d, "qry.fa")],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+        if n > 1:
+            assert b"replicated to %d logical GPUs by RCCL broadcast ... OK" % n in r.stdout
+        shas[n] = (_sha(out), os.path.getsize(out))
+    assert shas[1][1] > 10_000_000
+    assert shas[2] == shas[1] and shas[3] == shas[1]
+
+
+def test_cli_back_to_back_large_runs(tmp_path):
+    """Two large jobs in a row on one GPU.  The first runs with SLAMEM_DETACH_TEARDOWN=1 (returns when its results are
+    written; its worker still holds the 132 GB index, here for 4 more seconds: SLAMEM_TEST_LINGER_MS); the second starts
+    at once, needs a 181 GB build peak on the 288 GB device, and must WAIT for the memory instead of failing
+    (wait_for_hbm in host/main.c; the reference frees before it reports, slamem.c:208-216).  Both exit 0 with identical
+    output files.  2.2 Gbp text, 100,000 reads, -b -l 20."""
+    import time
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
+    from slamem_amd import engine, synth
+    n, nreads, L = 2_200_000_000, 100_000, 150
+    ref = engine.synth_reference(n, 42, "cuda:0")
+    reads = engine.synth_reads(ref, 0, nreads, L, 0.02, 42, 50)[: nreads * L].cpu().numpy().reshape(nreads, L)
+    ref_h = ref.cpu().numpy()
+    del ref
+    torch.cuda.empty_cache()
+    d = str(tmp_path)
+    synth.write_fasta_reference(os.path.join(d, "ref.fa"), ref_h)
+    del ref_h
+    synth.write_fasta_reads(os.path.join(d, "qry.fa"), reads)
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    cmd = lambda o: [exe, "-b", "-l", "20", "-o", os.path.join(d, o), os.path.join(d, "ref.fa"), os.path.join(d, "qry.fa")]
+    t0 = time.time()
+    r1 = subprocess.run(cmd("o1.txt"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                        env=dict(os.environ, SLAMEM_DETACH_TEARDOWN="1", SLAMEM_TEST_LINGER_MS="4000"))
+    t1 = time.time()
+    r2 = subprocess.run(cmd("o2.txt"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    t2 = time.time()
+    assert r1.returncode == 0, (r1.stdout[-2000:], r1.stderr[-2000:])
+    assert r2.returncode == 0, (r2.stdout[-2000:], r2.stderr[-2000:])
+    assert b"Waiting for HBM" in r2.stderr and b"Waited " in r2.stderr, r2.stderr[-2000:]
+    assert b"full layout" in r2.stdout
+    assert _sha(os.path.join(d, "o1.txt")) == _sha(os.path.join(d, "o2.txt"))
+    assert os.path.getsize(os.path.join(d, "o1.txt")) > 1_000_000
+    try:
+        with open(os.path.join(hostlib.ROOT, "gpurun_out", "back_to_back.txt"), "a") as f:
+            f.write(f"2.2 Gbp, 100k reads: first run (detached teardown, worker lingers 4 s) returned after {t1 - t0:.2f} s; "
+                    f"second run (default: returns when its memory is back) {t2 - t1:.2f} s; stderr of the second: "
+                    f"{r2.stderr.decode(errors='replace').strip()}\n")
+    except OSError:
+        pass
+
+
+def test_cli_detached_worker_when_the_front_is_pid_1(tmp_path):
+    """SLAMEM_DETACH_TEARDOWN=1 forks a worker that must not mistake a front end that IS pid 1 (a container entry point)
+    for a front end that has died (host/main.c front_is_gone).  Runs the binary as pid 1 of a new pid namespace when the
+    box allows unprivileged namespaces; the detached mode itself is checked either way."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
+    exe = os.path.join(hostlib.HOST_DIR, "slaMEM-hip")
+    ref_fa, q_fa, exp_mems, _ = case_paths("acgt_l20_both")
+    out = str(tmp_path / "o.txt")
+    env = dict(os.environ, SLAMEM_DETACH_TEARDOWN="1")
+    r = subprocess.run([exe, "-b", "-l", "20", "-o", out, ref_fa, q_fa], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    assert r.returncode == 0 and open(out, "rb").read() == open(exp_mems, "rb").read()
+    probe = subprocess.run(["unshare", "-U", "-r", "-p", "-f", "--mount-proc", "sh", "-c", "echo $$"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE)
+    if probe.returncode != 0 or probe.stdout.strip() != b"1":
+        pytest.skip("this box does not allow unprivileged pid namespaces (the pid-1 case needs one)")
+    os.remove(out)
+    r = subprocess.run(["unshare", "-U", "-r", "-p", "-f", "--mount-proc", exe, "-b", "-l", "20", "-o", out, ref_fa, q_fa],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    assert open(out, "rb").read() == open(exp_mems, "rb").read()
