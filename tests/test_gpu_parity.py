@@ -554,3 +554,72 @@ def test_skip_variant_is_exact(eng):
     assert out["config3_digest_equal"]
     assert all(out[c]["equal_in_order"] for c in ("random", "repeats", "dense_subs", "l30"))
     assert out["random"]["skips"] > 1000 and out["l30"]["skips"] > 100
+
+
+@pytest.mark.parametrize("mam", [False, True], ids=["mem", "mam"])
+@pytest.mark.parametrize("alpha,n,repeats,nrun,l,both", [
+    ("ACGT", 3000, 3, 0, 20, True), ("ACGTN", 2500, 2, 120, 8, True), ("ACGT", 200000, 40, 0, 15, True),
+    ("AC", 1500, 2, 0, 10, False)])
+def test_compact_layout_matches_oracle_in_order(eng, alpha, n, repeats, nrun, l, both, mam):
+    """SLAMEM_LAYOUT_COMPACT (no text-ordered sections, half-size presence filter): the same MEMs / MAMs in the same order
+    as the oracle (slamem.c:114-199), in a smaller arena than the full layout's; long records (slices) included."""
+    from oracle import pyoracle as po
+    from slamem_amd import capi
+    rng = np.random.default_rng(3 * n + l)
+    text = rand_text(rng, n, alpha, repeats, nrun=nrun)
+    qs = make_queries(rng, text, 60, alpha) + [b"", b"N" * 25, text[:30], text[-30:], text[: min(n, 9000)]]
+    q, off = pack(qs)
+    o = po.OracleIndex(text)
+    om, obc = o.match_batch(q, off, l, both, mam=mam)
+    full = eng.Index.build(text, layout=capi.LAYOUT_FULL)
+    g = eng.Index.build(text, layout=capi.LAYOUT_COMPACT)
+    assert g.info.layout == capi.LAYOUT_COMPACT and full.info.layout == capi.LAYOUT_FULL
+    assert g.info.arena_bytes < full.info.arena_bytes
+    assert eng.build_bytes(n, capi.LAYOUT_COMPACT)[0] == g.info.arena_bytes or "N" in alpha  # the estimate (no N rows counted)
+    gm, goff = g.find_mems(q, off, l, both, mam=mam)
+    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+    for f in ("ref_pos", "query_pos", "length"):
+        assert np.array_equal(gm[f], om[f]), f
+    # an exported compact arena attaches like any other
+    g2 = eng.Index.attach(g.export_arena())
+    assert g2.info.layout == capi.LAYOUT_COMPACT
+    gm2, _ = g2.find_mems(q, off, l, both, mam=mam)
+    assert np.array_equal(gm2, gm)
+    g2.close()
+    g.close()
+    full.close()
+
+
+def test_auto_layout_follows_the_free_hbm(eng, monkeypatch):
+    """SLAMEM_LAYOUT_AUTO: full when its build peak fits what is free (SLAMEM_HBM_BUDGET_GB caps that), compact when only
+    that fits, SLAMEM_ERR_NOMEM with the numbers otherwise -- never a failed hipMalloc halfway through a build."""
+    from slamem_amd import capi
+    n = 40_000_000
+    ref = eng.synth_reference(n, 9, "cuda:0")
+    a_full, p_full = eng.build_bytes(n, capi.LAYOUT_FULL)
+    a_comp, p_comp = eng.build_bytes(n, capi.LAYOUT_COMPACT)
+    assert a_comp < 0.62 * a_full and p_comp < p_full
+    monkeypatch.delenv("SLAMEM_INDEX_LAYOUT", raising=False)
+    monkeypatch.delenv("SLAMEM_HBM_BUDGET_GB", raising=False)
+    g = eng.Index.build(ref)
+    assert g.info.layout == capi.LAYOUT_FULL and g.info.arena_bytes == a_full
+    g.close()
+    monkeypatch.setenv("SLAMEM_HBM_BUDGET_GB", f"{(p_comp + p_full) / 2 / 2**30:.3f}")
+    g = eng.Index.build(ref)
+    assert g.info.layout == capi.LAYOUT_COMPACT and g.info.arena_bytes == a_comp
+    reads = eng.synth_reads(ref, 0, 20_000, 150, 0.02, 9, 50)
+    import torch
+    offsets = torch.arange(20_001, dtype=torch.int64, device="cuda:0") * 150
+    m = g.matcher(20_000, True, 200_000, 3_000_000)
+    t_compact = m.run(reads, offsets, 20)
+    g.close()
+    monkeypatch.setenv("SLAMEM_HBM_BUDGET_GB", f"{p_comp / 2 / 2**30:.3f}")
+    with pytest.raises(capi.SlamemError) as ei:
+        eng.Index.build(ref)
+    assert ei.value.code == capi.SLAMEM_ERR_NOMEM and "compact layout" in str(ei.value)
+    monkeypatch.setenv("SLAMEM_INDEX_LAYOUT", "full")  # the environment decides for AUTO callers
+    g = eng.Index.build(ref)
+    assert g.info.layout == capi.LAYOUT_FULL
+    m = g.matcher(20_000, True, 200_000, 3_000_000)
+    assert m.run(reads, offsets, 20) == t_compact > 20_000
+    g.close()
