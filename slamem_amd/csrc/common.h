@@ -189,4 +189,19 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
                      slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
                      uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out);
 uint64_t find_mems_workspace_bytes(uint64_t num_queries, int both_strands, uint64_t query_bytes, uint64_t mems_capacity);
+// One batch through the search in steps that may be issued apart and on different streams (mem_search.hip; used by stream.hip):
+// tables (one small sync) -> prep (K8a, work list, K7q; asynchronous) -> search (K8, K9, scalars to host_scalars; asynchronous)
+// -> collect (after the search stream has finished the batch: totals, capacity check, timings of the calling thread).
+// host_scalars: nine 64-bit words, pinned if possible (nullptr: the job's own).
+struct SearchJob;
+SearchJob* search_job_new();
+void search_job_delete(SearchJob* j);
+int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev, uint32_t num_queries,
+                    uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type, slamem_mem* mems_dev,
+                    uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev, uint64_t workspace_bytes,
+                    unsigned long long* host_scalars);
+int search_job_tables(SearchJob* j, hipStream_t stream);
+int search_job_prep(SearchJob* j, hipStream_t stream);
+int search_job_search(SearchJob* j, hipStream_t stream);
+int search_job_collect(SearchJob* j, uint64_t* total_out);
 }  // namespace slamem

@@ -1846,21 +1846,27 @@ __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__
     if (cnt > 3u && off + 3u < capacity) out[off + 3u] = slamem_mem{p3, r3.pos, r3.len & 0x7FFFFFFFu};
 }
 
+// (the number of listed records stays on the device -- *listed, written by K8's atomics -- so that K9 is launched right
+//  behind K8 without a host round trip in between; the grid is fixed and strides over the list)
 __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict__ key, const slamem_mem* __restrict__ raw,
-                                                        uint64_t count, const uint64_t* __restrict__ item_off,
+                                                        const unsigned long long* __restrict__ listed,
+                                                        const uint64_t* __restrict__ item_off,
                                                         const uint8_t* __restrict__ item_attempt,
                                                         const uint32_t* __restrict__ sa, uint64_t capacity,
                                                         slamem_mem* __restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    RawKey kk = key[i];
-    if ((kk.k >> 28) != item_attempt[kk.block]) return;  // written by an attempt that was abandoned
-    slamem_mem m = raw[i];
-    uint64_t pos = item_off[kk.block] + (kk.k & 0x0FFFFFFFu);
-    if (pos >= capacity) return;
-    if (m.length >> 31) m.length &= 0x7FFFFFFFu;  // ref_pos already is the text position
-    else m.ref_pos = sa[m.ref_pos];
-    out[pos] = m;
+    uint64_t count = *listed;
+    if (count > capacity) count = capacity;  // (records beyond the capacity were never stored: emit3_at)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        RawKey kk = key[i];
+        if ((kk.k >> 28) != item_attempt[kk.block]) continue;  // written by an attempt that was abandoned
+        slamem_mem m = raw[i];
+        uint64_t pos = item_off[kk.block] + (kk.k & 0x0FFFFFFFu);
+        if (pos >= capacity) continue;
+        if (m.length >> 31) m.length &= 0x7FFFFFFFu;  // ref_pos already is the text position
+        else m.ref_pos = sa[m.ref_pos];
+        out[pos] = m;
+    }
 }
 
 // ---- work items ------------------------------------------------------------------------------------------
@@ -2040,25 +2046,29 @@ struct SearchJob {
     void* workspace_dev = nullptr;
     WorkspaceLayout w;
     SearchArgs A;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // before K8a, after K8, after K9, after K8a, before K8
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // before K8a, after K8, after K9, after K8a, before K8, after K7q
     bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
     bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
+    unsigned long long scal_own[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long* h_scal = scal_own;  // where search() has the scalars copied: [0..7] the scalar block, [8] all MEMs; pinned memory if the caller has some
     ~SearchJob();
     int init(const slamem_index* idx_, const void* queries_dev_, const uint64_t* offsets_dev_, uint32_t num_queries_,
              uint64_t query_bytes_, uint32_t min_len_, int both_strands_, int match_type_, slamem_mem* mems_dev_,
              uint64_t mems_capacity_, uint64_t* block_offsets_dev_, void* workspace_dev_, uint64_t workspace_bytes_);
     int tables(hipStream_t stream);
-    int launch(hipStream_t stream);
-    int finish(hipStream_t stream);
+    int prep(hipStream_t stream);
+    int search(hipStream_t stream);
+    int collect();
 };
 
-// One batch through the search, in three steps that a caller may issue apart (slamem_stream_* does: tables in the upload
-// stage, launch for batch b+1 BEFORE finish of batch b, so that the kernels of b+1 are queued on the GPU when the last
-// waves of K8(b) drain and nothing waits for a host round trip):
+// One batch through the search, in steps that a caller may issue apart and on different streams (slamem_stream_* does: the
+// preparation of batches b+1, b+2 runs on its own stream and fills the GPU while the last waves of K8(b) drain; K8 and K9 of
+// all batches follow each other on the search stream with no host round trip in between):
 //   tables()  work-item counts and offsets (one small sync: the number of items sizes the grids)
-//   launch()  K8a prefilter, work-list compaction, K7q packing, K8 search -- asynchronous
-//   finish()  per-item counts -> offsets, capacity check, K9 placement; synchronous with respect to the stream
-// find_mems_device() runs the three in a row.
+//   prep()    K8a prefilter, work-list compaction, slice states, K7q packing -- asynchronous
+//   search()  K8 search, per-item counts -> offsets, K9 placement, the batch's scalars to the host -- asynchronous
+//   collect() AFTER the search stream has finished those: totals, capacity check, timings
+// find_mems_device() runs them in a row on one stream.
 int SearchJob::init(const slamem_index* idx_, const void* queries_dev_, const uint64_t* offsets_dev_, uint32_t num_queries_,
                     uint64_t query_bytes_, uint32_t min_len_, int both_strands_, int match_type_, slamem_mem* mems_dev_,
                     uint64_t mems_capacity_, uint64_t* block_offsets_dev_, void* workspace_dev_, uint64_t workspace_bytes_) {
@@ -2091,13 +2101,13 @@ int SearchJob::init(const slamem_index* idx_, const void* queries_dev_, const ui
         return SLAMEM_ERR_ARG;
     }
     want_stats = search_stats_wanted();
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 6; i++)
         if (!ev[i]) SLAMEM_HIP(hipEventCreate(&ev[i]));
     return SLAMEM_OK;
 }
 
 SearchJob::~SearchJob() {
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 6; i++)
         if (ev[i]) (void)hipEventDestroy(ev[i]);
 }
 
@@ -2193,7 +2203,7 @@ int SearchJob::tables(hipStream_t stream) {
     return SLAMEM_OK;
 }
 
-int SearchJob::launch(hipStream_t stream) {
+int SearchJob::prep(hipStream_t stream) {
     SLAMEM_HIP(hipSetDevice(idx->device));
     char* ws = static_cast<char*>(workspace_dev);
     unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
@@ -2246,6 +2256,17 @@ int SearchJob::launch(hipStream_t stream) {
             }
         }
         STEP(hipGetLastError(), "k_pack_queries");
+    }
+    (void)hipEventRecord(ev[5], stream);
+    return SLAMEM_OK;
+}
+
+int SearchJob::search(hipStream_t stream) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    char* ws = static_cast<char*>(workspace_dev);
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
+    launched = true;
+    if (nitems && (match_type != 1 || mam_v3)) {
         // persistent waves: as many as the chip holds (256 CUs x 16 waves), fewer for small batches
         uint64_t waves = (nitems + kFetch - 1) / kFetch;
         static const uint64_t env_waves = [] { const char* v = getenv("SLAMEM_K8_WAVES"); return v ? (uint64_t)atoll(v) : 0ull; }();
@@ -2338,29 +2359,38 @@ int SearchJob::launch(hipStream_t stream) {
         }
     }
     (void)hipEventRecord(ev[1], stream);
-    return SLAMEM_OK;
-}
-
-int SearchJob::finish(hipStream_t stream) {
-    SLAMEM_HIP(hipSetDevice(idx->device));
-    char* ws = static_cast<char*>(workspace_dev);
-    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
+    // ---- K9, right behind K8: per-item counts -> offsets, strand-block offsets, placement.  Nothing here needs a number from
+    // the host: the grids cover the items, the list of overflow records is walked by a fixed grid up to the device-side count,
+    // and every store is bounds-checked against the capacity (a batch that does not fit is reported by collect()).
     uint32_t* d_first = reinterpret_cast<uint32_t*>(ws + w.off_first);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
     uint64_t* d_itemoff = reinterpret_cast<uint64_t*>(ws + w.off_itemoff);
-    Timings& tm = thread_timings();
     size_t need = w.scan_bytes;
     STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need, d_counts, d_itemoff, nitems, stream), "scan");
     hipLaunchKernelGGL(k_block_offsets, dim3(grid_for(num_blocks + 1)), dim3(256), 0, stream, d_first, d_itemoff,
                        num_queries, strands, nitems, block_offsets_dev);
     STEP(hipGetLastError(), "k_block_offsets");
-    unsigned long long listed = 0, tot = 0;  // listed: records in the atomic list; tot: all MEMs
-    unsigned long long scal[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] listed; u32 word 8: survivors of K8a, word 9: ordinal overflow flag
-    STEP(hipMemcpyAsync(scal, d_total, sizeof(scal), hipMemcpyDeviceToHost, stream), "memcpy");
-    STEP(hipMemcpyAsync(&tot, d_itemoff + nitems, 8, hipMemcpyDeviceToHost, stream), "memcpy");
-    STEP(hipStreamSynchronize(stream), "k_find_mems (sync)");
-    listed = scal[0];
-    total = tot;
+    if (nitems && mems_capacity) {
+        hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
+                           d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);
+        STEP(hipGetLastError(), "k_place_inline");
+        const uint64_t ob = (mems_capacity + 255) / 256;
+        hipLaunchKernelGGL(k_place_overflow, dim3((unsigned)(ob < 2048 ? ob : 2048)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
+                           (const unsigned long long*)d_total, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev);
+        STEP(hipGetLastError(), "k_place_overflow");
+    }
+    (void)hipEventRecord(ev[2], stream);
+    // [0] listed; u32 word 8: survivors of K8a, word 9: ordinal overflow flag; [8] all MEMs
+    STEP(hipMemcpyAsync(h_scal, d_total, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "memcpy");
+    STEP(hipMemcpyAsync(h_scal + 8, d_itemoff + nitems, 8, hipMemcpyDeviceToHost, stream), "memcpy");
+    return SLAMEM_OK;
+}
+
+int SearchJob::collect() {
+    Timings& tm = thread_timings();
+    const unsigned long long* scal = h_scal;
+    const unsigned long long listed = scal[0];  // records in the atomic list
+    total = scal[8];                            // all MEMs
     if ((uint32_t)(scal[4] >> 32) != 0u) {
         // (not SLAMEM_ERR_CAPACITY: callers answer that one by asking again with more room)
         set_error("slamem_find_mems_device: one work item emits 2^28 or more MEMs (a 4096-position slice against a highly "
@@ -2392,6 +2422,23 @@ int SearchJob::finish(hipStream_t stream) {
         o.overflow_records = listed;
         o.valid = match_type != 1 ? 1 : 0;
     }
+    // device times of the batch.  prep and search may have run on different streams (slamem_stream_*): the kernel time is the
+    // sum of the two parts, not the span from the first event to the last (which would include the wait in between)
+    float ms = 0, ms_prep = 0, ms_k8 = 0;
+    if (hipEventElapsedTime(&ms, ev[0], ev[5]) == hipSuccess) ms_prep = ms;
+    if (timed_k8 && hipEventElapsedTime(&ms, ev[4], ev[1]) == hipSuccess) {  // K8 alone
+        ms_k8 = ms;
+        tm.t.k8_ms = ms;
+        tm.t.k8_ms_sum += ms;
+    } else if (hipEventElapsedTime(&ms, ev[5], ev[1]) == hipSuccess) ms_k8 = ms;  // (-mam over slices: everything behind the preparation)
+    tm.t.search_kernel_ms = ms_prep + ms_k8;
+    tm.t.search_kernel_ms_sum += ms_prep + ms_k8;
+    tm.t.search_launches++;
+    if (prefiltered && hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) {  // K8a
+        tm.t.prefilter_ms = ms;
+        tm.t.prefilter_ms_sum += ms;
+    }
+    if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) tm.t.search_total_ms = ms_prep + ms_k8 + ms;
     if (total > mems_capacity || listed > mems_capacity) {
         // the atomic list also holds the records of abandoned slice attempts: ask for room for those too
         if (listed > total) total = listed;
@@ -2399,33 +2446,6 @@ int SearchJob::finish(hipStream_t stream) {
                   (unsigned long long)mems_capacity);
         return SLAMEM_ERR_CAPACITY;
     }
-    if (total) {
-        hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
-                           d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);
-        STEP(hipGetLastError(), "k_place_inline");
-    }
-    if (listed) {
-        hipLaunchKernelGGL(k_place_overflow, dim3(grid_for(listed)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                           (uint64_t)listed, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev);
-        STEP(hipGetLastError(), "k_place_overflow");
-    }
-    (void)hipEventRecord(ev[2], stream);
-    STEP(hipStreamSynchronize(stream), "K9 (sync)");
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
-        tm.t.search_kernel_ms = ms;
-        tm.t.search_kernel_ms_sum += ms;
-        tm.t.search_launches++;
-    }
-    if (prefiltered && hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) {  // K8a
-        tm.t.prefilter_ms = ms;
-        tm.t.prefilter_ms_sum += ms;
-    }
-    if (timed_k8 && hipEventElapsedTime(&ms, ev[4], ev[1]) == hipSuccess) {    // K8 alone
-        tm.t.k8_ms = ms;
-        tm.t.k8_ms_sum += ms;
-    }
-    if (hipEventElapsedTime(&ms, ev[0], ev[2]) == hipSuccess) tm.t.search_total_ms = ms;
     return SLAMEM_OK;
 }
 #undef STEP
@@ -2439,10 +2459,34 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
     int rc = job.init(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev,
                       mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes);
     if (rc == SLAMEM_OK) rc = job.tables(stream);
-    if (rc == SLAMEM_OK) rc = job.launch(stream);
-    if (rc == SLAMEM_OK) rc = job.finish(stream);
-    else if (job.launched) (void)hipStreamSynchronize(stream);  // never return with kernels of this call in flight
+    if (rc == SLAMEM_OK) rc = job.prep(stream);
+    if (rc == SLAMEM_OK) rc = job.search(stream);
+    if (job.launched) {  // never return with kernels of this call in flight
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess && rc == SLAMEM_OK) rc = hip_fail(e, "MEM search (sync)", __FILE__, __LINE__);
+    }
+    if (rc == SLAMEM_OK) rc = job.collect();
     *total_out = job.total;
+    return rc;
+}
+
+// The same steps for a caller that issues them apart (stream.hip): an opaque job per batch slot.
+SearchJob* search_job_new() { return new (std::nothrow) SearchJob(); }
+void search_job_delete(SearchJob* j) { delete j; }
+int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev, uint32_t num_queries,
+                    uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type, slamem_mem* mems_dev,
+                    uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev, uint64_t workspace_bytes,
+                    unsigned long long* host_scalars) {
+    j->h_scal = host_scalars ? host_scalars : j->scal_own;
+    return j->init(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev,
+                   mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes);
+}
+int search_job_tables(SearchJob* j, hipStream_t stream) { return j->tables(stream); }
+int search_job_prep(SearchJob* j, hipStream_t stream) { return j->prep(stream); }
+int search_job_search(SearchJob* j, hipStream_t stream) { return j->search(stream); }
+int search_job_collect(SearchJob* j, uint64_t* total_out) {
+    int rc = j->collect();
+    if (total_out) *total_out = j->total;
     return rc;
 }
 

@@ -2,14 +2,22 @@
 // front end with its reads in HOST memory calls.  SURVEY.md 8(d) defines the path's metric on exactly this boundary
 // ("reads resident in host memory -> MEM triples in host memory").
 //
-// A slamem_stream is a three-stage pipeline over `slots` (2-8) sets of buffers: an UPLOAD thread copies a batch's
-// characters to the device (straight from the caller's memory: at full PCIe rate when that memory is pinned,
-// slamem_pinned_alloc), a SEARCH thread runs slamem_find_mems_device on it, a DOWNLOAD thread copies the MEMs into pinned
-// host memory -- each stage on its own HIP stream, each taking the batches in submission order.  With enough batches in
-// flight the copy engines move batch b+1 up and batch b-1 down while the search kernels of batch b have the whole GPU,
-// so the sustained rate is the kernels' rate, not kernels + PCIe.  (One thread per SLOT doing upload, search and download
-// in turn was measured first: the slots fall into lockstep -- all upload together, then all search together -- and
-// nothing overlaps: 62 ms where this pipeline takes 37.)  No CPU fallback: every batch is searched on the GPU.
+// A slamem_stream is a four-stage pipeline over `slots` (2-8) sets of buffers, each stage a host thread with its own HIP
+// stream, each taking the batches in submission order:
+//   UPLOAD    the batch's characters and offsets to the device (straight from the caller's memory: at full PCIe rate when
+//             that memory is pinned, slamem_pinned_alloc)
+//   PREPARE   work-item tables (the stage's one host round trip), K8a prefilter, work list, K7q packing
+//   SEARCH    K8 and K9 of ALL batches back to back on one stream, with no host round trip in between: the thread only
+//             enqueues (the preparation is awaited on the device, hipStreamWaitEvent) and never waits for a result
+//   DOWNLOAD  waits for the batch's K9 (event), reads its totals, copies MEMs and block offsets into pinned host memory
+// K8 is a persistent kernel that takes every wave slot of the chip; what it leaves idle is its tail (the last strands of
+// its waves, ~1 ms whatever the batch size).  The preparation of the NEXT batches runs on its own stream, so the hardware
+// puts its workgroups exactly where K8's waves retire, and the next K8 is already queued behind K9.  (Round 2 ran each
+// batch's whole chain, with three host round trips, on one of two alternating search threads: the second thread's small
+// kernels and memsets sat behind the first one's K8 until its tail and the chain after them was exposed -- 3.7 ms per
+// million-read batch where the kernels need 2.9; measured with rocprofv3 --kernel-trace, profiles/r03_host_leg_timeline.txt.
+// One thread per SLOT doing everything in turn was measured before that: the slots fall into lockstep, 62 ms.)
+// No CPU fallback: every batch is searched on the GPU.
 #include "common.h"
 
 #include <chrono>
@@ -24,10 +32,10 @@ namespace slamem {
 
 namespace {
 
-enum SlotState { FREE = 0, QUEUED = 1, UPLOADED = 2, COMPUTED = 3, DONE = 4, RETURNED = 5 };
+enum SlotState { FREE = 0, QUEUED = 1, UPLOADED = 2, PREPARED = 3, LAUNCHED = 4, DONE = 5, RETURNED = 6 };
 constexpr int kMaxSlots = 8;
-constexpr int kMaxSearch = 4;
-constexpr int kMaxThreads = kMaxSearch + 2;
+constexpr int kThreads = 4;  // upload, prepare, search, download
+enum { T_UP = 0, T_PREP = 1, T_SEARCH = 2, T_DOWN = 3 };
 
 struct Slot {
     int state = FREE;
@@ -54,6 +62,11 @@ struct Slot {
     int rc = SLAMEM_OK;
     char err[512] = "";
     slamem_timings tm;
+    // the batch on its way through the search (mem_search.hip), the events the stages hand it over with, and the pinned
+    // words K9's stream copies the batch's totals into
+    SearchJob* job = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_done = nullptr;
+    unsigned long long* h_scal = nullptr;
 };
 
 }  // namespace
@@ -68,12 +81,12 @@ struct slamem_stream {
     uint64_t max_chars = 0;
     uint32_t max_q = 0;
     Slot slot[kMaxSlots];
-    // thread 0 uploads, threads 1..nsearch search (batch b on thread 1 + b mod nsearch), the last one downloads
-    std::thread th[kMaxThreads];
-    hipStream_t st[kMaxThreads] = {};
+    std::thread th[kThreads];
+    hipStream_t st[kThreads] = {};
     hipStream_t st_up2 = nullptr;  // second copy stream of the upload stage (SLAMEM_STREAM_UPLOAD_SPLIT)
     int upload_split = 1;
-    int nsearch = 2, nthreads = 4;
+    int nthreads = kThreads;
+    double mems_per_char = 0;  // the densest batch so far: sizes a slot's first output buffers (written by the download stage)
     std::mutex mu;
     std::condition_variable cv;
     uint64_t submitted = 0, returned = 0;  // batches handed in / handed back
@@ -119,7 +132,8 @@ int stage_upload(slamem_stream* s, Slot& sl) {
         if (sl.d_boff) (void)hipFree(sl.d_boff);
         if (sl.d_mems) (void)hipFree(sl.d_mems);
         if (sl.d_ws) (void)hipFree(sl.d_ws);
-        sl.d_q = nullptr; sl.d_off = nullptr; sl.d_boff = nullptr; sl.d_mems = nullptr; sl.d_ws = nullptr;  // (the search stage sizes its own)
+        sl.d_q = nullptr; sl.d_off = nullptr; sl.d_boff = nullptr; sl.d_mems = nullptr; sl.d_ws = nullptr;  // (the prepare stage sizes its own)
+        sl.cap_chars = 0; sl.cap_q = 0;  // until all three are there: a failed allocation must not leave stale room behind
         SLAMEM_HIP(hipMalloc(&sl.d_q, nchars + 2 * kFront + 32));
         SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_off), ((uint64_t)nrec + 1) * 8));
         SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_boff), (nb + 1) * 8));
@@ -141,31 +155,67 @@ int stage_upload(slamem_stream* s, Slot& sl) {
     return SLAMEM_OK;
 }
 
-// stage 1: K8a + K7q + K8 + K9 (synchronous with respect to its stream).  Two threads share this stage, one for the even
-// and one for the odd batches, each on its own stream: the head of batch b+1 (work-item tables, prefilter) fills the GPU
-// while the last waves of batch b's search drain, and the launch gaps of one hide behind the kernels of the other.
-int stage_search(slamem_stream* s, Slot& sl, hipStream_t st) {
+// stage 1: work-item tables (one small host round trip on this stage's stream), then K8a, the work list and K7q, asynchronous
+int job_setup(slamem_stream* s, Slot& sl) {
     const uint64_t qbytes = sl.offs[sl.nq] - sl.offs[0];
-    int rc = SLAMEM_OK;
-    if (!sl.d_ws) {  // first guess of the room for MEMs: grown when a batch needs more (SLAMEM_ERR_CAPACITY tells how much)
+    if (!sl.d_ws) {
+        // first guess of the room for MEMs: what the densest batch so far would need, and never less than a MEM per 32
+        // characters; grown when a batch needs more (SLAMEM_ERR_CAPACITY tells how much)
         const uint64_t nb = (uint64_t)sl.cap_q * (s->both ? 2 : 1);
-        rc = grow_outputs(s, sl, sl.cap_chars / 32 + nb + 1024);
+        uint64_t guess = sl.cap_chars / 32 + nb + 1024;
+        const uint64_t seen = (uint64_t)(1.25 * s->mems_per_char * (double)sl.cap_chars) + 1024;
+        int rc = grow_outputs(s, sl, seen > guess ? seen : guess);
         if (rc != SLAMEM_OK) return rc;
     }
-    (void)slamem_reset_timings();
-    for (int attempt = 0; attempt < 3; attempt++) {
-        rc = find_mems_device(s->idx, device_queries(sl), sl.d_off, sl.nq, qbytes, sl.min_len, s->both, s->match_type, sl.d_mems, sl.cap,
-                              sl.d_boff, sl.d_ws, sl.ws_bytes, st, &sl.total);
-        if (rc != SLAMEM_ERR_CAPACITY || sl.total <= sl.cap) break;
-        int g = grow_outputs(s, sl, sl.total + sl.total / 8 + 1024);  // rare: the first guess was too small
-        if (g != SLAMEM_OK) return g;
-    }
-    (void)slamem_get_timings(&sl.tm);
+    if (!sl.job && !(sl.job = search_job_new())) { set_error("out of host memory"); return SLAMEM_ERR_NOMEM; }
+    if (!sl.ev_prep) SLAMEM_HIP(hipEventCreateWithFlags(&sl.ev_prep, hipEventDisableTiming));
+    if (!sl.ev_done) SLAMEM_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+    if (!sl.h_scal) SLAMEM_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_scal), 16 * sizeof(unsigned long long), hipHostMallocDefault));
+    return search_job_init(sl.job, s->idx, device_queries(sl), sl.d_off, sl.nq, qbytes, sl.min_len, s->both, s->match_type, sl.d_mems,
+                           sl.cap, sl.d_boff, sl.d_ws, sl.ws_bytes, sl.h_scal);
+}
+int stage_prepare(slamem_stream* s, Slot& sl) {
+    int rc = job_setup(s, sl);
+    if (rc == SLAMEM_OK) rc = search_job_tables(sl.job, s->st[T_PREP]);
+    if (rc == SLAMEM_OK) rc = search_job_prep(sl.job, s->st[T_PREP]);
+    if (rc == SLAMEM_OK) SLAMEM_HIP(hipEventRecord(sl.ev_prep, s->st[T_PREP]));
     return rc;
 }
 
-// stage 2: MEMs and block offsets to pinned host memory
+// stage 2: K8 + K9 behind the preparation, enqueued only: the search stream holds the K8s and K9s of all batches in flight,
+// one behind the other
+int stage_search(slamem_stream* s, Slot& sl) {
+    SLAMEM_HIP(hipStreamWaitEvent(s->st[T_SEARCH], sl.ev_prep, 0));
+    int rc = search_job_search(sl.job, s->st[T_SEARCH]);
+    // (recorded even after a failed launch: the download stage waits for whatever did get onto the stream)
+    SLAMEM_HIP(hipEventRecord(sl.ev_done, s->st[T_SEARCH]));
+    return rc;
+}
+
+// stage 3: the batch's totals, then MEMs and block offsets to pinned host memory
 int stage_download(slamem_stream* s, Slot& sl) {
+    hipStream_t st = s->st[T_DOWN];
+    (void)slamem_reset_timings();
+    SLAMEM_HIP(hipEventSynchronize(sl.ev_done));
+    int rc = search_job_collect(sl.job, &sl.total);
+    for (int attempt = 0; rc == SLAMEM_ERR_CAPACITY && sl.total > sl.cap && attempt < 2; attempt++) {
+        // rare (the first guess was too small): more room, and the batch once more, start to end, on this stage's stream
+        rc = grow_outputs(s, sl, sl.total + sl.total / 8 + 1024);
+        if (rc == SLAMEM_OK) rc = job_setup(s, sl);
+        if (rc == SLAMEM_OK) rc = search_job_tables(sl.job, st);
+        if (rc == SLAMEM_OK) rc = search_job_prep(sl.job, st);
+        if (rc == SLAMEM_OK) rc = search_job_search(sl.job, st);
+        SLAMEM_HIP(hipStreamSynchronize(st));
+        if (rc == SLAMEM_OK) rc = search_job_collect(sl.job, &sl.total);
+    }
+    (void)slamem_get_timings(&sl.tm);
+    if (rc != SLAMEM_OK) return rc;
+    {
+        const uint64_t chars = sl.offs[sl.nq] - sl.offs[0];
+        const double d = chars ? (double)sl.total / (double)chars : 0.0;
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (d > s->mems_per_char) s->mems_per_char = d;
+    }
     const uint64_t nb = (uint64_t)sl.nq * (s->both ? 2 : 1);
     if (!sl.h_boff || sl.h_boff_cap < nb + 1) {
         if (sl.h_boff) (void)hipHostFree(sl.h_boff);
@@ -180,22 +230,20 @@ int stage_download(slamem_stream* s, Slot& sl) {
         SLAMEM_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_mems), sl.cap * sizeof(slamem_mem) + 16, hipHostMallocDefault));
         sl.h_cap = sl.cap;
     }
-    hipStream_t st = s->st[s->nthreads - 1];
     if (sl.total) SLAMEM_HIP(hipMemcpyAsync(sl.h_mems, sl.d_mems, sl.total * sizeof(slamem_mem), hipMemcpyDeviceToHost, st));
     SLAMEM_HIP(hipMemcpyAsync(sl.h_boff, sl.d_boff, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
     SLAMEM_HIP(hipStreamSynchronize(st));
     return SLAMEM_OK;
 }
 
-// thread 0 uploads, threads 1 and 2 search the even / odd batches, thread 3 downloads; each takes its batches in
-// submission order
+// one thread per stage; each takes its batches in submission order
 void worker(slamem_stream* s, int t) {
-    const bool up = t == 0, down = t == s->nthreads - 1;
-    const int want = up ? QUEUED : down ? COMPUTED : UPLOADED;
-    const int done = up ? UPLOADED : down ? DONE : COMPUTED;
-    const uint64_t first = (up || down) ? 0 : (uint64_t)(t - 1), step = (up || down) ? 1 : (uint64_t)s->nsearch;
+    static const int kWant[kThreads] = {QUEUED, UPLOADED, PREPARED, LAUNCHED};
+    static const int kDone[kThreads] = {UPLOADED, PREPARED, LAUNCHED, DONE};
+    static const char* const kName[kThreads] = {"upload", "prepare", "search", "download"};
+    const int want = kWant[t], done = kDone[t];
     (void)hipSetDevice(s->idx->device);
-    for (uint64_t seq = first;; seq += step) {
+    for (uint64_t seq = 0;; seq++) {
         Slot& sl = s->slot[seq % (uint64_t)s->nslots];
         {
             std::unique_lock<std::mutex> lk(s->mu);
@@ -205,13 +253,15 @@ void worker(slamem_stream* s, int t) {
         int rc = sl.rc;  // a batch that failed in an earlier stage passes through untouched
         const auto t_begin = std::chrono::steady_clock::now();
         if (rc == SLAMEM_OK) {
-            rc = up ? stage_upload(s, sl) : down ? stage_download(s, sl) : stage_search(s, sl, s->st[t]);
+            rc = t == T_UP ? stage_upload(s, sl) : t == T_PREP ? stage_prepare(s, sl) : t == T_SEARCH ? stage_search(s, sl)
+                                                                                                    : stage_download(s, sl);
             if (rc != SLAMEM_OK) snprintf(sl.err, sizeof(sl.err), "%s", slamem_last_error_message());  // the text is per thread
+        } else if (t == T_DOWN && sl.ev_done) {
+            (void)hipEventSynchronize(sl.ev_done);  // nothing of a failed batch may still run when its slot is handed back
         }
         if (s->trace) {  // SLAMEM_STREAM_TRACE=1: when every stage worked on every batch (ms since the stream was created)
             const auto t_end = std::chrono::steady_clock::now();
-            fprintf(stderr, "[stream] batch %3llu %-8s %9.3f .. %9.3f ms\n", (unsigned long long)seq,
-                    up ? "upload" : down ? "download" : "search",
+            fprintf(stderr, "[stream] batch %3llu %-8s %9.3f .. %9.3f ms\n", (unsigned long long)seq, kName[t],
                     std::chrono::duration<double, std::milli>(t_begin - s->t0).count(),
                     std::chrono::duration<double, std::milli>(t_end - s->t0).count());
         }
@@ -232,6 +282,10 @@ void free_slot(Slot& sl) {
     if (sl.d_ws) (void)hipFree(sl.d_ws);
     if (sl.h_boff) (void)hipHostFree(sl.h_boff);
     if (sl.h_mems) (void)hipHostFree(sl.h_mems);
+    if (sl.h_scal) (void)hipHostFree(sl.h_scal);
+    if (sl.ev_prep) (void)hipEventDestroy(sl.ev_prep);
+    if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    if (sl.job) search_job_delete(sl.job);
 }
 
 }  // namespace
@@ -258,7 +312,8 @@ int slamem_stream_destroy(slamem_stream* s) {
         // batches in flight finish first: never tear buffers down under a running kernel
         s->cv.wait(lk, [&] {
             for (int k = 0; k < s->nslots; k++)
-                if (s->slot[k].state == QUEUED || s->slot[k].state == UPLOADED || s->slot[k].state == COMPUTED) return false;
+                if (s->slot[k].state == QUEUED || s->slot[k].state == UPLOADED || s->slot[k].state == PREPARED ||
+                    s->slot[k].state == LAUNCHED) return false;
             return true;
         });
         s->stop = true;
@@ -268,7 +323,7 @@ int slamem_stream_destroy(slamem_stream* s) {
         if (s->th[k].joinable()) s->th[k].join();
     (void)hipSetDevice(s->idx->device);
     for (int k = 0; k < s->nslots; k++) free_slot(s->slot[k]);
-    for (int k = 0; k < kMaxThreads; k++)
+    for (int k = 0; k < kThreads; k++)
         if (s->st[k]) (void)hipStreamDestroy(s->st[k]);
     if (s->st_up2) (void)hipStreamDestroy(s->st_up2);
     delete s;
@@ -294,11 +349,6 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
     s->max_chars = max_batch_chars;
     s->max_q = max_batch_queries;
     int rc = SLAMEM_OK;
-    {   // SLAMEM_STREAM_SEARCH=1..4 search threads (default 2)
-        const char* v = getenv("SLAMEM_STREAM_SEARCH");
-        if (v && atoi(v) >= 1 && atoi(v) <= kMaxSearch) s->nsearch = atoi(v);
-        s->nthreads = s->nsearch + 2;
-    }
     for (int k = 0; k < s->nthreads; k++) {
         hipError_t e = hipStreamCreateWithFlags(&s->st[k], hipStreamNonBlocking);
         if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
@@ -314,7 +364,7 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
     if (rc != SLAMEM_OK) {
         if (s->st_up2) (void)hipStreamDestroy(s->st_up2);
         for (int k = 0; k < slots; k++) free_slot(s->slot[k]);
-        for (int k = 0; k < kMaxThreads; k++)
+        for (int k = 0; k < kThreads; k++)
             if (s->st[k]) (void)hipStreamDestroy(s->st[k]);
         delete s;
         return rc;

@@ -515,6 +515,7 @@ static void leave_now(void) { /* results complete: tell the front, then end with
         char c = 0;
         close(1);
         close(2);
+        if (linger && atoi(linger) > 0) prctl(PR_SET_PDEATHSIG, 0); /* (the front's exit would end the worker at once) */
         if (write(g_done_fd, &c, 1) != 1) _exit(255);
         if (linger && atoi(linger) > 0) usleep((useconds_t)atoi(linger) * 1000u);
     }
@@ -767,7 +768,7 @@ int main(int argc, char **argv) {
         uint64_t max_chars = 1;
         uint32_t max_recs = 1;
         int inflight[16], g;
-        const int slots = 4;
+        const int slots = 6; /* upload, prepare, search and download of four batches beside the one being formatted */
         int sets_seen = 0, sets_reaped = 0, sets_ready = ld->ready; /* !overlap: everything is there */
 #define ADD_RANGES_OF_NEW_SETS()                                                                                              \
         for (; sets_seen < sets_ready; sets_seen++) {                                                                          \

@@ -12,6 +12,8 @@ Cases (inputs: slamem_amd/synth.py generators, SURVEY.md Appendix C.2 + the repe
   config1_pair      BASELINE.json configs[0]: a 4.64 Mbp genome against a 1.5 %-diverged strain with three
                     inversions and two deletions (tests/golden_cases.py::ecoli_like_pair), -b -l 20
   config1_pair_mam  the same pair with -mam (sha256 of the reference's output file)
+  config1_dups_pair / config1_dups_pair_mam   the pair with exact repeats in the genome (ecoli_like_pair(duplicates=True)):
+                    -mem and -mam print different files there
   config5_first100k BASELINE.json configs[4]: 3.1 Gbp text (> 2^31 rows) with the repeat model, the first 100,000 reads, -b -l 20
   config2_mam_first200k   the 100 Mbp reference of configs[1]/[2], its first 200,000 reads, -b -l 20 -mam
 
@@ -195,7 +197,31 @@ def case_config5_first100k(tmp):
     return d
 
 
-CASES = {"config5_first100k": case_config5_first100k, "config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
+def _pair_dups(tmp, mam):
+    from golden_cases import ecoli_like_pair
+    import hashlib
+    ref, qry = ecoli_like_pair(duplicates=True)
+    synth.write_fasta_reference(os.path.join(tmp, "ref.fa"), ref, "ecoli_like_ref")
+    synth.write_fasta_reference(os.path.join(tmp, "qry.fa"), qry, "ecoli_like_strain")
+    rc, secs = run_reference(["-b", "-l", "20", "-o", "out.txt", "ref.fa", "qry.fa"] + (["-mam"] if mam else []), tmp)
+    data = open(os.path.join(tmp, "out.txt"), "rb").read()
+    lines = sum(1 for ln in data.split(b"\n") if ln and ln[:1] != b">")
+    return {"file_bytes": len(data), "file_sha256": hashlib.sha256(data).hexdigest(), "lines": lines, "reference_rc": rc,
+            "reference_seconds": round(secs, 1),
+            "workload": f"ecoli_like_pair(duplicates=True): {ref.shape[0]} bp genome with 7 x 5000 bp and 20 x 1300 bp exact "
+                        f"repeats vs {qry.shape[0]} bp strain, -b -l 20" + (" -mam" if mam else "")}
+
+
+def case_config1_dups_pair(tmp):
+    return _pair_dups(tmp, False)
+
+
+def case_config1_dups_pair_mam(tmp):
+    return _pair_dups(tmp, True)
+
+
+CASES = {"config1_dups_pair": case_config1_dups_pair, "config1_dups_pair_mam": case_config1_dups_pair_mam,
+         "config5_first100k": case_config5_first100k, "config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
          "config2_mam_first200k": case_config2_mam_first200k, "config1_pair_mam": case_config1_pair_mam}
 
 

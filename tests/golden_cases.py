@@ -18,8 +18,13 @@ def case_paths(name):
         os.path.join(d, "expected-stdout.txt")
 
 
-def ecoli_like_pair():
-    """BASELINE.json configs[0] stand-in (the real E. coli FASTAs are not available offline):
+def ecoli_like_pair(duplicates: bool = False):
+    """duplicates=True: the genome additionally carries exact repeats the way a real one does -- seven copies of a
+    5,000 bp element (rRNA operons) and twenty copies of a 1,300 bp element (insertion sequences), planted BEFORE the strain is
+    derived -- so that matches inside them occupy several BWT rows and -mam (unique in the reference, slamem.c:131) prints
+    a different file than -mem.
+
+    BASELINE.json configs[0] stand-in (the real E. coli FASTAs are not available offline):
     a 4,641,652 bp random genome and a 'strain' of it with 1.5 % substitutions, three 40 kbp inversions and two
     deletions.  Fully determined by splitmix64 streams (no library RNG), so the build container and the GPU box make
     the same bytes.  Returns (reference, query) uint8 ASCII arrays."""
@@ -27,6 +32,15 @@ def ecoli_like_pair():
     from slamem_amd import synth
     n = 4_641_652
     ref = synth.make_reference(n, seed=11)
+    if duplicates:
+        d = synth.splitmix64_at(0xD0B1E5, np.arange(64, dtype=np.uint64))
+        at = 0
+        for copies, ln in ((7, 5000), (20, 1300)):
+            src = int(d[at] % np.uint64(n - ln)); at += 1
+            elem = ref[src:src + ln].copy()
+            for _ in range(copies - 1):
+                dst = int(d[at] % np.uint64(n - ln)); at += 1
+                ref[dst:dst + ln] = elem
     q = ref.copy()
     x = synth.splitmix64_at(0xEC011, np.arange(n, dtype=np.uint64))
     mut = (x & np.uint64(0xFFFFFFFF)) < np.uint64(int(0.015 * 4294967296.0))

@@ -300,3 +300,25 @@ def test_config5_grch38_sized_full_size_properties(eng):
     note("config5_share_engine", got)
     assert got == {k: KNOWN["config5_share_engine"][k] for k in DIGEST_KEYS}, got
     idx.close()
+
+
+@pytest.mark.parametrize("mam", [False, True], ids=["mem", "mam"])
+def test_genome_pair_with_exact_repeats_mem_and_mam_cli(eng, tmp_path, mam):
+    """The genome pair with exact repeats in the genome (7 x 5,000 bp, 20 x 1,300 bp: ecoli_like_pair(duplicates=True)) -- an
+    input on which -mem and -mam print DIFFERENT files (58,125 against 49,965 lines; on the plain pair they are the same
+    file, so that pin cannot tell the modes apart).  Both through the slaMEM-hip command line, each byte-identical to the file
+    the REAL reference wrote (known_answers.json: config1_dups_pair, config1_dups_pair_mam; slamem.c:131,657)."""
+    from golden_cases import ecoli_like_pair
+    from slamem_amd import synth
+    known = KNOWN["config1_dups_pair_mam" if mam else "config1_dups_pair"]
+    assert KNOWN["config1_dups_pair_mam"]["file_sha256"] != KNOWN["config1_dups_pair"]["file_sha256"]
+    ref, qry = ecoli_like_pair(duplicates=True)
+    synth.write_fasta_reference(str(tmp_path / "ref.fa"), ref, "ecoli_like_ref")
+    synth.write_fasta_reference(str(tmp_path / "qry.fa"), qry, "ecoli_like_strain")
+    exe = os.path.join(ROOT, "slamem_amd", "host", "slaMEM-hip")
+    r = subprocess.run([exe, "-b", "-l", "20", "-o", "out.txt", "ref.fa", "qry.fa"] + (["-mam"] if mam else []),
+                       cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-2000:]
+    data = (tmp_path / "out.txt").read_bytes()
+    assert len(data) == known["file_bytes"]
+    assert hashlib.sha256(data).hexdigest() == known["file_sha256"]
