@@ -200,6 +200,10 @@ int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_d
                     uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type, slamem_mem* mems_dev,
                     uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev, uint64_t workspace_bytes,
                     unsigned long long* host_scalars);
+// (between init and tables) the number of slices of the batch when the caller knows it -- no record longer than a slice: one
+// per record -- which saves tables() its host round trip
+void search_job_slices_hint(SearchJob* j, uint32_t slices);
+constexpr uint32_t kSearchSliceLen = 4096;
 int search_job_tables(SearchJob* j, hipStream_t stream);
 int search_job_prep(SearchJob* j, hipStream_t stream);
 int search_job_search(SearchJob* j, hipStream_t stream);

@@ -213,12 +213,12 @@ __global__ void __launch_bounds__(256) k_rank_samples(const uint4* __restrict__ 
 // k- and (k+2)-mers of the text that contain it.  Windows containing N are not entered (a query window with N is
 // treated as present, so N == N matches are never filtered out).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
-                                                       uint32_t log2_words, uint32_t levels,
-                                                       unsigned long long* __restrict__ filter) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// The entries of text position p: hash of the (k-2)-mer that starts there (-> the line) and the bits of every entry in the
+// line's eight words.  false: the (k-2)-mer does not lie in the text or holds an N (nothing is entered).
+__device__ __forceinline__ bool kfilter_entries(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k, uint32_t levels,
+                                                uint64_t p, uint64_t& h0, unsigned long long (&words)[8]) {
     const uint32_t k1 = k - 2u;
-    if (p + k1 > n) return;
+    if (p + k1 > n) return false;
     // the letters [p-4, p+k1+4) as 2-bit values, first letter in the highest bits; ok: bit per letter, set when the
     // letter exists and is not N
     const uint32_t wn = k1 + 8u;
@@ -238,10 +238,10 @@ __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restric
     // the nine entries: hash and whether the window lies in the text and holds no N
     uint64_t v, hs[9];
     bool in[9];
-    if (!piece(4u, k1, v)) return;
+    if (!piece(4u, k1, v)) return false;
     hs[0] = kfilter_hash(v ^ kFilterShortSalt);
     in[0] = true;
-    unsigned long long* line = filter + kfilter_line(hs[0], log2_words);
+    h0 = hs[0];
 #pragma unroll
     for (uint32_t o = 2u; o <= 4u; o++) {
         in[o - 1u] = piece(o, k, v);
@@ -253,15 +253,102 @@ __global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restric
         in[4u + o] = third && piece(o, k + 2u, v);
         hs[4u + o] = kfilter_hash(v ^ kFilterLongSalt);
     }
-    // one atomic per word of the line that gets bits (5.5 on average), not one per entry
 #pragma unroll
     for (uint32_t wd = 0; wd < 8u; wd++) {
         unsigned long long m = 0ull;
 #pragma unroll
         for (uint32_t e = 0; e < 9u; e++)
             if (in[e] && kfilter_word(hs[e]) == wd) m |= (unsigned long long)kfilter_bits(hs[e]);
-        if (m) atomicOr(&line[wd], m);
+        words[wd] = m;
     }
+    return true;
+}
+
+// The direct form: one atomic per word of the line that gets bits (5.5 on average per position, 550 M random atomics at
+// 100 Mbp: 21.8 ms, 40 % of round 2's build).  Kept as the checker of the sorted form below (SLAMEM_KFILTER_ATOMIC=1; the
+// filter's content does not depend on the order of the entries) and for texts too short to be worth a sort.
+__global__ void __launch_bounds__(256) k_kfilter_build(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
+                                                       uint32_t log2_words, uint32_t levels,
+                                                       unsigned long long* __restrict__ filter) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t h0;
+    unsigned long long words[8];
+    if (!kfilter_entries(pk, n, k, levels, p, h0, words)) return;
+    unsigned long long* line = filter + kfilter_line(h0, log2_words);
+#pragma unroll
+    for (uint32_t wd = 0; wd < 8u; wd++)
+        if (words[wd]) atomicOr(&line[wd], words[wd]);
+}
+
+// The sorted form.  A line of the filter is written ONCE, whole, by the lane that owns it: (1) every text position gets the
+// key "line of its (k-2)-mer" (positions without one sort behind all lines), (2) the positions are sorted by that key on the
+// hand-written radix sort -- sequential passes over 12 bytes per position instead of 5.5 random read-modify-writes --,
+// (3) the first position of every run of equal keys gathers the entries of its whole run (three positions on average) in
+// registers and stores the line's 64 bytes.  The region is zeroed beforehand for the lines that get nothing.
+__global__ void __launch_bounds__(256) k_kfilter_keys(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
+                                                      uint32_t log2_words, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (uint64_t)n) return;
+    const uint32_t k1 = k - 2u;
+    uint64_t key = 1ull << (log2_words - 3u);  // behind every line
+    if (p + k1 <= n) {
+        uint64_t v = 0;
+        bool ok = true;
+        for (uint32_t d = 0; d < k1; d++) {
+            const uint32_t c = nibble_at(pk, p + d);
+            ok = ok && c >= 2u;
+            v = (v << 2) | (uint64_t)(c >= 2u ? c - 2u : 0u);
+        }
+        if (ok) key = kfilter_line(kfilter_hash(v ^ kFilterShortSalt), log2_words) >> 3;
+    }
+    keys[p] = key;
+    vals[p] = (uint32_t)p;
+}
+
+// (runs longer than kFilterRun -- the same (k-2)-mer thousands of times: satellites, homopolymers -- are not walked by one
+//  lane: positions from the kFilterRun-th of a run on enter their bits themselves with atomics, as the direct form does,
+//  and the owner of such a run uses atomics too)
+constexpr uint32_t kFilterRun = 32;
+__global__ void __launch_bounds__(256) k_kfilter_fill(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
+                                                      uint32_t log2_words, uint32_t levels,
+                                                      const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                      unsigned long long* __restrict__ filter) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)n) return;
+    const uint64_t key = keys[i], none = 1ull << (log2_words - 3u);
+    if (key == none) return;  // no (k-2)-mer here
+    unsigned long long* line = filter + (key << 3);
+    uint64_t h0;
+    unsigned long long words[8];
+    if (i >= kFilterRun && keys[i - kFilterRun] == key) {  // deep inside a long run: on its own
+        if (kfilter_entries(pk, n, k, levels, (uint64_t)vals[i], h0, words)) {
+#pragma unroll
+            for (uint32_t wd = 0; wd < 8u; wd++)
+                if (words[wd]) atomicOr(&line[wd], words[wd]);
+        }
+        return;
+    }
+    if (i != 0 && keys[i - 1] == key) return;  // not the first of its run
+    unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    uint64_t j = i;
+    for (; j < (uint64_t)n && j < i + kFilterRun && keys[j] == key; j++) {
+        if (kfilter_entries(pk, n, k, levels, (uint64_t)vals[j], h0, words)) {
+#pragma unroll
+            for (uint32_t wd = 0; wd < 8u; wd++) acc[wd] |= words[wd];
+        }
+    }
+    if (j < (uint64_t)n && keys[j] == key) {  // the run goes on: others write this line too
+#pragma unroll
+        for (uint32_t wd = 0; wd < 8u; wd++)
+            if (acc[wd]) atomicOr(&line[wd], acc[wd]);
+        return;
+    }
+    uint4* l4 = reinterpret_cast<uint4*>(line);
+    l4[0] = make_uint4((uint32_t)acc[0], (uint32_t)(acc[0] >> 32), (uint32_t)acc[1], (uint32_t)(acc[1] >> 32));
+    l4[1] = make_uint4((uint32_t)acc[2], (uint32_t)(acc[2] >> 32), (uint32_t)acc[3], (uint32_t)(acc[3] >> 32));
+    l4[2] = make_uint4((uint32_t)acc[4], (uint32_t)(acc[4] >> 32), (uint32_t)acc[5], (uint32_t)(acc[5] >> 32));
+    l4[3] = make_uint4((uint32_t)acc[6], (uint32_t)(acc[6] >> 32), (uint32_t)acc[7], (uint32_t)(acc[7] >> 32));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1026,9 +1113,26 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
     if (hdr.off_kfilter) {
         unsigned long long* d_filter = reinterpret_cast<unsigned long long*>(base + hdr.off_kfilter);
-        SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));
-        hipLaunchKernelGGL(k_kfilter_build, dim3(grid_for((uint64_t)n - hdr.kfilter_k + 3)), dim3(256), 0, stream,
-                           pk.as<uint64_t>(), n, hdr.kfilter_k, hdr.kfilter_log2, hdr.kfilter_levels, d_filter);
+        static const bool env_atomic = [] { const char* v = getenv("SLAMEM_KFILTER_ATOMIC"); return v && atoi(v) != 0; }();
+        if (env_atomic || n < (1u << 16)) {
+            SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));
+            hipLaunchKernelGGL(k_kfilter_build, dim3(grid_for((uint64_t)n - hdr.kfilter_k + 3)), dim3(256), 0, stream,
+                               pk.as<uint64_t>(), n, hdr.kfilter_k, hdr.kfilter_log2, hdr.kfilter_levels, d_filter);
+        } else {
+            // the suffix sort's buffers are free: keys in keysA / keysB, positions in valsA / valsB.  valsB (and nothing else
+            // of these) may have been borrowed from the filter's own region: the result is asked for in the A buffers, and
+            // the region is zeroed only after the sort is through with the B buffers (same stream: in order)
+            hipLaunchKernelGGL(k_kfilter_keys, dim3(grid_for(n)), dim3(256), 0, stream, pk.as<uint64_t>(), n, hdr.kfilter_k,
+                               hdr.kfilter_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>());
+            SLAMEM_HIP(hipGetLastError());
+            need = tmp_bytes;
+            SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysB.as<uint64_t>(), keysA.as<uint64_t>(), valsB.as<uint32_t>(),
+                                          valsA.as<uint32_t>(), n, 0, (int)hdr.kfilter_log2 - 3 + 1, stream));
+            SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));
+            hipLaunchKernelGGL(k_kfilter_fill, dim3(grid_for(n)), dim3(256), 0, stream, pk.as<uint64_t>(), n, hdr.kfilter_k,
+                               hdr.kfilter_log2, hdr.kfilter_levels, (const uint64_t*)keysA.as<uint64_t>(),
+                               (const uint32_t*)valsA.as<uint32_t>(), d_filter);
+        }
         SLAMEM_HIP(hipGetLastError());
     }
 

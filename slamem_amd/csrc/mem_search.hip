@@ -213,6 +213,7 @@ constexpr uint32_t kFetch = 64;         // v3: work items a wave takes from the 
 // scheme -- scan from b + warm-up, restart with four times the warm-up when a match of the slice reaches the scan's
 // start, attempt tag in the records -- for a slice that comes without a state.)
 constexpr uint32_t kSliceLen = 4096;
+static_assert(kSliceLen == kSearchSliceLen, "stream.hip tells the slice count of a batch from this length");
 constexpr uint32_t kWarmUp = 1024;
 constexpr uint32_t kMaxAttempt = 7;
 struct __attribute__((aligned(16))) ItemDesc {
@@ -2050,6 +2051,7 @@ struct SearchJob {
     bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
     bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
     unsigned long long scal_own[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t slices_hint = 0xFFFFFFFFu;  // a caller that has the offsets on the host and knows the slice count (no record longer than a slice: one per record) saves tables() its round trip
     unsigned long long* h_scal = scal_own;  // where search() has the scalars copied: [0..7] the scalar block, [8] all MEMs; pinned memory if the caller has some
     ~SearchJob();
     int init(const slamem_index* idx_, const void* queries_dev_, const uint64_t* offsets_dev_, uint32_t num_queries_,
@@ -2129,13 +2131,14 @@ int SearchJob::tables(hipStream_t stream) {
                        num_queries, (match_type == 1 && mam_whole_strands()) ? 0u : kSliceLen, d_cnt, d_wps);
     STEP(hipGetLastError(), "k_item_counts");
     STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
-    uint32_t slices = 0;
-    STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
+    uint32_t slices = slices_hint;
+    const bool ask = slices_hint == 0xFFFFFFFFu;
+    if (ask) STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
     {   // packed strands: offsets of the strand blocks
         size_t need3 = w.scan_bytes;
         STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need3, d_wps, d_wscan, (uint64_t)num_queries, stream), "scan");
     }
-    STEP(hipStreamSynchronize(stream), "item count (sync)");
+    if (ask) STEP(hipStreamSynchronize(stream), "item count (sync)");
     nitems = (uint64_t)slices * strands;
     {   // -mam: reads go through K8 (kMam); batches with a record longer than a slice through k_find_mams_sliced
         static const bool env_v3 = [] { const char* v = getenv("SLAMEM_MAM_V3"); return !(v && atoi(v) == 0); }();
@@ -2478,9 +2481,11 @@ int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_d
                     uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev, uint64_t workspace_bytes,
                     unsigned long long* host_scalars) {
     j->h_scal = host_scalars ? host_scalars : j->scal_own;
+    j->slices_hint = 0xFFFFFFFFu;
     return j->init(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev,
                    mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes);
 }
+void search_job_slices_hint(SearchJob* j, uint32_t slices) { j->slices_hint = slices; }
 int search_job_tables(SearchJob* j, hipStream_t stream) { return j->tables(stream); }
 int search_job_prep(SearchJob* j, hipStream_t stream) { return j->prep(stream); }
 int search_job_search(SearchJob* j, hipStream_t stream) { return j->search(stream); }

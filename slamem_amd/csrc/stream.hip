@@ -57,6 +57,7 @@ struct Slot {
     const char* chars = nullptr;
     const uint64_t* offs = nullptr;
     uint32_t nq = 0, min_len = 0;
+    bool all_short = false;  // no record longer than a slice (seen by the upload stage while the copy engines work)
     // its result
     uint64_t total = 0;
     int rc = SLAMEM_OK;
@@ -83,9 +84,11 @@ struct slamem_stream {
     Slot slot[kMaxSlots];
     std::thread th[kThreads];
     hipStream_t st[kThreads] = {};
-    hipStream_t st_up2 = nullptr;  // second copy stream of the upload stage (SLAMEM_STREAM_UPLOAD_SPLIT)
-    int upload_split = 1;
+    hipStream_t st_upx[3] = {nullptr, nullptr, nullptr};  // more copy streams of the upload stage (SLAMEM_STREAM_UPLOAD_SPLIT = 2..4)
+    int upload_split = 2;
     int nthreads = kThreads;
+    hipStream_t st_search2 = nullptr;  // SLAMEM_STREAM_SEARCH_STREAMS=2: odd batches' K8 + K9 on a second stream (their K8 starts in the tail of the even one's)
+    int search_streams = 1;
     double mems_per_char = 0;  // the densest batch so far: sizes a slot's first output buffers (written by the download stage)
     std::mutex mu;
     std::condition_variable cv;
@@ -142,16 +145,29 @@ int stage_upload(slamem_stream* s, Slot& sl) {
     }
     char* dst = static_cast<char*>(sl.d_q) + kFront + (base & 15u);
     const char* src = sl.chars + base;
-    uint64_t first = qbytes;
-    const bool split = s->upload_split > 1 && s->st_up2 && qbytes >= (8u << 20);
-    if (split) {  // two copy engines: the second half of the characters goes up beside the first
-        first = (qbytes / 2) & ~(uint64_t)4095;
-        SLAMEM_HIP(hipMemcpyAsync(dst + first, src + first, qbytes - first, hipMemcpyHostToDevice, s->st_up2));
+    // Beside K8 -- which keeps the memory system at its random-request ceiling -- ONE copy engine moves 42 GB/s instead of the
+    // link's 57 (measured: 3.56 ms per 158 MB instead of 2.76, which made the upload the pipeline's period); the pieces of a
+    // batch go up on `upload_split` copy streams side by side
+    const int ways = (s->upload_split > 1 && qbytes >= (8u << 20)) ? s->upload_split : 1;
+    uint64_t at = 0;
+    for (int wy = 0; wy < ways; wy++) {
+        const uint64_t end = wy + 1 == ways ? qbytes : ((qbytes * (uint64_t)(wy + 1) / (uint64_t)ways) & ~(uint64_t)4095);
+        hipStream_t cs = wy == 0 ? s->st[0] : s->st_upx[wy - 1];
+        if (end > at) SLAMEM_HIP(hipMemcpyAsync(dst + at, src + at, end - at, hipMemcpyHostToDevice, cs));
+        at = end;
     }
-    if (first) SLAMEM_HIP(hipMemcpyAsync(dst, src, first, hipMemcpyHostToDevice, s->st[0]));
     SLAMEM_HIP(hipMemcpyAsync(sl.d_off, sl.offs, ((uint64_t)sl.nq + 1) * 8, hipMemcpyHostToDevice, s->st[0]));
+    {   // while the copy engines work: is any record longer than a slice?  (if not, the prepare stage knows the number of work
+        // items without asking the device -- its one host round trip per batch goes away)
+        uint64_t longest = 0;
+        for (uint32_t i = 0; i < sl.nq; i++) {
+            const uint64_t len = sl.offs[i + 1] - sl.offs[i];
+            longest = len > longest ? len : longest;
+        }
+        sl.all_short = longest <= kSearchSliceLen;
+    }
     SLAMEM_HIP(hipStreamSynchronize(s->st[0]));
-    if (split) SLAMEM_HIP(hipStreamSynchronize(s->st_up2));
+    for (int wy = 1; wy < ways; wy++) SLAMEM_HIP(hipStreamSynchronize(s->st_upx[wy - 1]));
     return SLAMEM_OK;
 }
 
@@ -176,6 +192,7 @@ int job_setup(slamem_stream* s, Slot& sl) {
 }
 int stage_prepare(slamem_stream* s, Slot& sl) {
     int rc = job_setup(s, sl);
+    if (rc == SLAMEM_OK && sl.all_short) search_job_slices_hint(sl.job, sl.nq);
     if (rc == SLAMEM_OK) rc = search_job_tables(sl.job, s->st[T_PREP]);
     if (rc == SLAMEM_OK) rc = search_job_prep(sl.job, s->st[T_PREP]);
     if (rc == SLAMEM_OK) SLAMEM_HIP(hipEventRecord(sl.ev_prep, s->st[T_PREP]));
@@ -185,10 +202,11 @@ int stage_prepare(slamem_stream* s, Slot& sl) {
 // stage 2: K8 + K9 behind the preparation, enqueued only: the search stream holds the K8s and K9s of all batches in flight,
 // one behind the other
 int stage_search(slamem_stream* s, Slot& sl) {
-    SLAMEM_HIP(hipStreamWaitEvent(s->st[T_SEARCH], sl.ev_prep, 0));
-    int rc = search_job_search(sl.job, s->st[T_SEARCH]);
+    hipStream_t st = (s->search_streams > 1 && (sl.seq & 1u)) ? s->st_search2 : s->st[T_SEARCH];
+    SLAMEM_HIP(hipStreamWaitEvent(st, sl.ev_prep, 0));
+    int rc = search_job_search(sl.job, st);
     // (recorded even after a failed launch: the download stage waits for whatever did get onto the stream)
-    SLAMEM_HIP(hipEventRecord(sl.ev_done, s->st[T_SEARCH]));
+    SLAMEM_HIP(hipEventRecord(sl.ev_done, st));
     return rc;
 }
 
@@ -325,7 +343,9 @@ int slamem_stream_destroy(slamem_stream* s) {
     for (int k = 0; k < s->nslots; k++) free_slot(s->slot[k]);
     for (int k = 0; k < kThreads; k++)
         if (s->st[k]) (void)hipStreamDestroy(s->st[k]);
-    if (s->st_up2) (void)hipStreamDestroy(s->st_up2);
+    for (int k = 0; k < 3; k++)
+        if (s->st_upx[k]) (void)hipStreamDestroy(s->st_upx[k]);
+    if (s->st_search2) (void)hipStreamDestroy(s->st_search2);
     delete s;
     return SLAMEM_OK;
 }
@@ -349,20 +369,35 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
     s->max_chars = max_batch_chars;
     s->max_q = max_batch_queries;
     int rc = SLAMEM_OK;
-    for (int k = 0; k < s->nthreads; k++) {
-        hipError_t e = hipStreamCreateWithFlags(&s->st[k], hipStreamNonBlocking);
-        if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
+    {
+        int lo = 0, hi = 0;  // (numerically lower = higher priority)
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* v = getenv("SLAMEM_STREAM_PREP_PRIORITY");
+        const bool prio = v && atoi(v) != 0;
+        for (int k = 0; k < s->nthreads; k++) {
+            // the preparation's workgroups go first where K8's waves retire (it is what the next K8 waits for)
+            hipError_t e = (prio && k == T_PREP) ? hipStreamCreateWithPriority(&s->st[k], hipStreamNonBlocking, hi)
+                                                 : hipStreamCreateWithFlags(&s->st[k], hipStreamNonBlocking);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
+        }
+        v = getenv("SLAMEM_STREAM_SEARCH_STREAMS");
+        if (rc == SLAMEM_OK && v && atoi(v) == 2) {
+            hipError_t e = hipStreamCreateWithFlags(&s->st_search2, hipStreamNonBlocking);
+            if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+            else s->search_streams = 2;
+        }
     }
     {
         const char* v = getenv("SLAMEM_STREAM_UPLOAD_SPLIT");
-        if (v && atoi(v) >= 1) s->upload_split = atoi(v);
-        if (rc == SLAMEM_OK && s->upload_split > 1) {
-            hipError_t e = hipStreamCreateWithFlags(&s->st_up2, hipStreamNonBlocking);
+        if (v && atoi(v) >= 1 && atoi(v) <= 4) s->upload_split = atoi(v);
+        for (int k = 0; rc == SLAMEM_OK && k + 1 < s->upload_split; k++) {
+            hipError_t e = hipStreamCreateWithFlags(&s->st_upx[k], hipStreamNonBlocking);
             if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
         }
     }
     if (rc != SLAMEM_OK) {
-        if (s->st_up2) (void)hipStreamDestroy(s->st_up2);
+        for (int k = 0; k < 3; k++)
+            if (s->st_upx[k]) (void)hipStreamDestroy(s->st_upx[k]);
         for (int k = 0; k < slots; k++) free_slot(s->slot[k]);
         for (int k = 0; k < kThreads; k++)
             if (s->st[k]) (void)hipStreamDestroy(s->st[k]);

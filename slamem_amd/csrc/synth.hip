@@ -18,13 +18,14 @@ __global__ void k_ref(uint8_t* out, uint64_t n, uint64_t seed) {
 
 // one thread per read base; reads stored back to back, `length` bytes each
 __global__ void k_reads(const uint8_t* ref, uint64_t n, uint8_t* out, uint64_t first, uint64_t count, uint32_t length,
-                        uint32_t sub_thr, uint64_t seed, uint32_t rc_percent) {
+                        uint32_t sub_thr, uint64_t seed, uint32_t rc_percent, uint64_t avoid_at, uint64_t avoid_len) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count * length) return;
     uint64_t r = t / length;
     uint32_t i = (uint32_t)(t - r * length);
     uint64_t base = n + (first + r) * (uint64_t)(length + 2);
     uint64_t p = draw(seed, base) % (n - length + 1);
+    if (avoid_len && p + length > avoid_at && p < avoid_at + avoid_len) p += avoid_len + length;  // not out of a block of N
     bool flip = (draw(seed, base + 1 + length) % 100) < rc_percent;
     uint8_t c = ref[p + i];
     uint64_t x = draw(seed, base + 1 + i);
@@ -45,13 +46,19 @@ extern "C" int slamem_synth_reference(void* out_dev, uint64_t n, uint64_t seed, 
     return (int)hipGetLastError();
 }
 
-extern "C" int slamem_synth_reads(const void* ref_dev, uint64_t n, void* out_dev, uint64_t first, uint64_t count,
-                                  uint32_t length, double sub, uint64_t seed, uint32_t rc_percent, void* stream) {
+extern "C" int slamem_synth_reads_avoid(const void* ref_dev, uint64_t n, void* out_dev, uint64_t first, uint64_t count,
+                                        uint32_t length, double sub, uint64_t seed, uint32_t rc_percent, uint64_t avoid_at,
+                                        uint64_t avoid_len, void* stream) {
     uint32_t thr = (uint32_t)(uint64_t)(sub * 4294967296.0);
     uint64_t total = count * length;
     hipLaunchKernelGGL(k_reads, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)ref_dev, n, (uint8_t*)out_dev, first, count, length, thr, seed, rc_percent);
+                       (const uint8_t*)ref_dev, n, (uint8_t*)out_dev, first, count, length, thr, seed, rc_percent, avoid_at, avoid_len);
     return (int)hipGetLastError();
+}
+
+extern "C" int slamem_synth_reads(const void* ref_dev, uint64_t n, void* out_dev, uint64_t first, uint64_t count,
+                                  uint32_t length, double sub, uint64_t seed, uint32_t rc_percent, void* stream) {
+    return slamem_synth_reads_avoid(ref_dev, n, out_dev, first, count, length, sub, seed, rc_percent, 0, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -98,6 +105,57 @@ extern "C" int slamem_synth_plant_repeats(void* text_dev, uint64_t n, uint64_t s
         planted += len;
     }
     if (planted_out) *planted_out = planted;
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "Genome-like" repeat load (round 3; an extra model beside SURVEY.md 8(d)'s; same values as slamem_amd/synth.py::
+// plant_genome_like): one interspersed family of n / 2480 copies of a 300 bp consensus, each 5-15 % diverged from it and
+// confined to its own stretch of the text (no overlaps: the result does not depend on the order of writes); a satellite
+// array of 10^4 units of 171 bp, 2 % diverged each; a block of N of min(n / 8, 30 M) letters in the middle.
+// ---------------------------------------------------------------------------------------------------
+static const uint64_t kGenomeSalt = 0x67656E6F6D652121ull;
+constexpr uint32_t kFamilyLen = 300, kSatUnit = 171, kSatCopies = 10000;
+
+__global__ void k_plant_family(uint8_t* text, uint64_t sf, uint64_t copies, uint64_t stride) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= copies * kFamilyLen) return;
+    uint64_t k = t / kFamilyLen;
+    uint32_t i = (uint32_t)(t - k * kFamilyLen);
+    uint64_t dst = k * stride + draw(sf + 1, k) % (stride - kFamilyLen);
+    uint64_t thr = (500ull + draw(sf + 2, k) % 1001ull) * 429497ull;
+    uint32_t code = (uint32_t)(draw(sf, i) & 3u);
+    uint64_t x = draw(sf + 3, k * 512ull + i);
+    uint8_t c = "ACGT"[code];
+    if ((x & 0xFFFFFFFFull) < thr) c = "CGTAGTACTACG"[code * 3 + (uint32_t)((x >> 32) % 3)];
+    text[dst + i] = c;
+}
+
+__global__ void k_plant_satellite(uint8_t* text, uint64_t sf, uint64_t at, uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint32_t code = (uint32_t)(draw(sf + 4, i % kSatUnit) & 3u);
+    uint64_t x = draw(sf + 5, i);
+    uint8_t c = "ACGT"[code];
+    if ((uint32_t)x < (uint32_t)(uint64_t)(0.02 * 4294967296.0)) c = "CGTAGTACTACG"[code * 3 + (uint32_t)((x >> 32) % 3)];
+    text[at + i] = c;
+}
+
+__global__ void k_plant_n(uint8_t* text, uint64_t at, uint64_t len) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) text[at + i] = 'N';
+}
+
+extern "C" int slamem_synth_plant_genome_like(void* text_dev, uint64_t n, uint64_t seed, void* stream) {
+    if (n < 10000000ull) return -1;
+    const uint64_t copies = n / 2480, stride = n / copies, sat_at = n / 3, n_at = n / 2;
+    const uint64_t n_len = n / 8 < 30000000ull ? n / 8 : 30000000ull;
+    const uint64_t sf = seed + kGenomeSalt, sat = (uint64_t)kSatUnit * kSatCopies;
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* t = (uint8_t*)text_dev;
+    hipLaunchKernelGGL(k_plant_family, dim3((unsigned)((copies * kFamilyLen + 255) / 256)), dim3(256), 0, st, t, sf, copies, stride);
+    hipLaunchKernelGGL(k_plant_satellite, dim3((unsigned)((sat + 255) / 256)), dim3(256), 0, st, t, sf, sat_at, sat);
+    hipLaunchKernelGGL(k_plant_n, dim3((unsigned)((n_len + 255) / 256)), dim3(256), 0, st, t, n_at, n_len);
     return (int)hipGetLastError();
 }
 

@@ -478,12 +478,21 @@ def synth_plant_repeats(ref: torch.Tensor, seed: int = 42) -> int:
     return int(planted.value)
 
 
+def synth_plant_genome_like(ref: torch.Tensor, seed: int = 42) -> None:
+    """The genome-like repeat load (interspersed family, satellite array, block of N) applied in place; same values as
+    slamem_amd.synth.plant_genome_like."""
+    rc = capi.synth_lib().slamem_synth_plant_genome_like(_ptr(ref), ref.numel(), seed, _stream_handle(ref.device))
+    if rc:
+        raise RuntimeError(f"synth kernel launch failed: hip error {rc}")
+
+
 def synth_reads(ref: torch.Tensor, first: int, count: int, length: int = 150, sub: float = 0.02, seed: int = 42,
-                rc_percent: int = 0) -> torch.Tensor:
+                rc_percent: int = 0, avoid: tuple = (0, 0)) -> torch.Tensor:
+    """avoid = (at, len): reads that would touch text[at, at+len) are drawn behind it (slamem_amd.synth.make_reads)."""
     dev = ref.device
     out = torch.zeros(count * length + 16, dtype=torch.uint8, device=dev)
-    rc = capi.synth_lib().slamem_synth_reads(_ptr(ref), ref.numel(), _ptr(out), first, count, length, float(sub), seed,
-                                             rc_percent, _stream_handle(dev))
+    rc = capi.synth_lib().slamem_synth_reads_avoid(_ptr(ref), ref.numel(), _ptr(out), first, count, length, float(sub), seed,
+                                                   rc_percent, int(avoid[0]), int(avoid[1]), _stream_handle(dev))
     if rc:
         raise RuntimeError(f"synth kernel launch failed: hip error {rc}")
     return out

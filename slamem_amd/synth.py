@@ -50,14 +50,19 @@ def make_reference(n: int, seed: int = 42, chunk: int = 1 << 24) -> np.ndarray:
 
 
 def make_reads(ref: np.ndarray, first: int, count: int, length: int = 150, sub: float = 0.02,
-               seed: int = 42, rc_percent: int = 0) -> np.ndarray:
-    """Reads ``first .. first+count-1`` as a (count, length) uint8 array."""
+               seed: int = 42, rc_percent: int = 0, avoid: tuple = (0, 0)) -> np.ndarray:
+    """Reads ``first .. first+count-1`` as a (count, length) uint8 array.  avoid = (at, len): a read that would touch
+    text[at, at+len) (the block of N of the genome-like model: sequencers do not read it) is drawn at its start + len + length
+    instead."""
     n = ref.shape[0]
     L = length
     thr = np.uint64(int(sub * 4294967296.0) & 0xFFFFFFFF)
     r = np.arange(first, first + count, dtype=np.uint64)
     base = np.uint64(n) + r * np.uint64(L + 2)
     p = splitmix64_at(seed, base) % np.uint64(n - L + 1)
+    if avoid[1]:
+        hit = (p + np.uint64(L) > np.uint64(avoid[0])) & (p < np.uint64(avoid[0] + avoid[1]))
+        p = np.where(hit, p + np.uint64(avoid[1] + L), p)
     idx = p[:, None].astype(np.int64) + np.arange(L, dtype=np.int64)[None, :]
     c = ref[idx]
     x = splitmix64_at(seed, base[:, None] + np.uint64(1) + np.arange(L, dtype=np.uint64)[None, :])
@@ -108,6 +113,55 @@ def plant_repeats(ref: np.ndarray, seed: int = 42) -> int:
         ref[dst:dst + ln] = np.where((x & np.uint64(0xFFFFFFFF)) < thr, alt, _ACGT[code])
         planted += ln
     return planted
+
+
+# ---- "genome-like" repeat load (round 3; an extra model beside SURVEY.md 8(d)'s, same values as csrc/synth.hip) -----------
+# What real chromosomes add to the mild model above: ONE interspersed family of n // 2480 copies (10^5 at 248 Mbp, 1.25 M at
+# 3.1 Gbp) of a 300 bp consensus, each copy 5-15 % diverged from it; a satellite array of 10^4 units of 171 bp, each unit 2 %
+# diverged from the unit consensus; and a block of N of min(n // 8, 30 M) letters.  Copies never overlap (copy k lies in
+# the k-th stretch of n // copies letters), so the text does not depend on the order of writes.
+GENOME_SALT = 0x67656E6F6D652121
+FAMILY_LEN, SAT_UNIT, SAT_COPIES = 300, 171, 10_000
+
+
+def genome_like_layout(n: int):
+    copies = n // 2480
+    stride = n // copies
+    sat_at = n // 3
+    n_len = min(n // 8, 30_000_000)
+    n_at = n // 2
+    return copies, stride, sat_at, n_at, n_len
+
+
+def plant_genome_like(ref: np.ndarray, seed: int = 42) -> dict:
+    """Apply the genome-like model in place (after plant_repeats, if both are wanted).  Returns its layout."""
+    n = ref.shape[0]
+    if n < 10_000_000:
+        raise ValueError("genome-like model needs n >= 10^7")
+    copies, stride, sat_at, n_at, n_len = genome_like_layout(n)
+    sf = (seed + GENOME_SALT) & 0xFFFFFFFFFFFFFFFF
+    cons = (splitmix64_at(sf, np.arange(FAMILY_LEN, dtype=np.uint64)) & np.uint64(3)).astype(np.int64)
+    step = 1 << 16
+    for k0 in range(0, copies, step):
+        k = np.arange(k0, min(copies, k0 + step), dtype=np.uint64)
+        dst = k * np.uint64(stride) + splitmix64_at(sf + 1, k) % np.uint64(stride - FAMILY_LEN)
+        thr = ((np.uint64(500) + splitmix64_at(sf + 2, k) % np.uint64(1001)) * np.uint64(429497)).astype(np.uint64)  # (5..15 %) * 2^32
+        x = splitmix64_at(sf + 3, k[:, None] * np.uint64(512) + np.arange(FAMILY_LEN, dtype=np.uint64)[None, :])
+        sub = (x & np.uint64(0xFFFFFFFF)) < thr[:, None]
+        alt = _ALT[cons[None, :].repeat(k.shape[0], 0), ((x >> np.uint64(32)) % np.uint64(3)).astype(np.int64)]
+        letters = np.where(sub, alt, _ACGT[cons][None, :])
+        idx = dst[:, None].astype(np.int64) + np.arange(FAMILY_LEN, dtype=np.int64)[None, :]
+        ref[idx] = letters
+    unit = (splitmix64_at(sf + 4, np.arange(SAT_UNIT, dtype=np.uint64)) & np.uint64(3)).astype(np.int64)
+    tot = SAT_UNIT * SAT_COPIES
+    i = np.arange(tot, dtype=np.uint64)
+    x = splitmix64_at(sf + 5, i)
+    code = unit[(i % np.uint64(SAT_UNIT)).astype(np.int64)]
+    sub = (x & np.uint64(0xFFFFFFFF)) < np.uint64(int(0.02 * 4294967296.0))
+    ref[sat_at:sat_at + tot] = np.where(sub, _ALT[code, ((x >> np.uint64(32)) % np.uint64(3)).astype(np.int64)], _ACGT[code])
+    ref[n_at:n_at + n_len] = ord("N")
+    return {"family_copies": copies, "family_stride": stride, "satellite_at": sat_at, "satellite_letters": tot,
+            "n_block_at": n_at, "n_block_letters": n_len}
 
 
 def write_fasta_reference(path: str, ref: np.ndarray, name: str | None = None, width: int = 80) -> None:

@@ -12,6 +12,8 @@ Cases (inputs: slamem_amd/synth.py generators, SURVEY.md Appendix C.2 + the repe
   config1_pair      BASELINE.json configs[0]: a 4.64 Mbp genome against a 1.5 %-diverged strain with three
                     inversions and two deletions (tests/golden_cases.py::ecoli_like_pair), -b -l 20
   config1_pair_mam  the same pair with -mam (sha256 of the reference's output file)
+  config4_genome_like_first100k   248 Mbp text with the genome-like repeat load (10^5-copy family, satellite, 30 Mbp of N),
+                    the first 100,000 reads, -b -l 50
   config1_dups_pair / config1_dups_pair_mam   the pair with exact repeats in the genome (ecoli_like_pair(duplicates=True)):
                     -mem and -mam print different files there
   config5_first100k BASELINE.json configs[4]: 3.1 Gbp text (> 2^31 rows) with the repeat model, the first 100,000 reads, -b -l 20
@@ -197,6 +199,32 @@ def case_config5_first100k(tmp):
     return d
 
 
+def case_config4_genome_like_first100k(tmp):
+    """The chr1-sized text with the GENOME-LIKE repeat load on top of SURVEY's model (slamem_amd/synth.py::plant_genome_like:
+    100,000 copies of a 300 bp family at 5-15 % divergence, a 171 bp x 10^4 satellite array, a 30 Mbp block of N), the first
+    100,000 reads (none drawn from the block of N), -b -l 50."""
+    n, nreads, L, min_len = 248_000_000, 100_000, 150, 50
+    ref = synth.make_reference(n, 42)
+    synth.plant_repeats(ref, 42)
+    lay = synth.plant_genome_like(ref, 42)
+    synth.write_fasta_reference(os.path.join(tmp, "ref.fa"), ref)
+    reads = synth.make_reads(ref, 0, nreads, L, 0.02, 42, 50, avoid=(lay["n_block_at"], lay["n_block_letters"]))
+    with open(os.path.join(tmp, "qry.fa"), "wb") as f:
+        f.write(b"".join(b">q%d\n" % i + reads[i].tobytes() + b"\n" for i in range(nreads)))
+    rc, secs = run_reference(["-b", "-l", str(min_len), "-o", "out.txt", "ref.fa", "qry.fa"], tmp, timeout=4 * 3600, as_gb=24)
+    if rc != 0:
+        tail = open(os.path.join(tmp, "stdout.txt"), "rb").read()[-600:].decode("latin1")
+        return {"reference_rc": rc, "reference_seconds": round(secs, 1), "reference_completed": False, "stdout_tail": tail}
+    rows = parse(os.path.join(tmp, "out.txt"), True)
+    bad = check_rows_against_text(rows, ref, reads, 2)
+    d = digest_rows(rows)
+    d.update({"reference_rc": rc, "reference_seconds": round(secs, 1), "reference_valid": bad == 0, "invalid_rows": bad,
+              "layout": lay,
+              "workload": f"n={n} seed 42 + repeat model + genome-like load, reads 0..{nreads - 1} of 150 bp (none from the "
+                          f"block of N), 2% substitutions, 50% reverse-complemented, -b -l {min_len}"})
+    return d
+
+
 def _pair_dups(tmp, mam):
     from golden_cases import ecoli_like_pair
     import hashlib
@@ -220,7 +248,7 @@ def case_config1_dups_pair_mam(tmp):
     return _pair_dups(tmp, True)
 
 
-CASES = {"config1_dups_pair": case_config1_dups_pair, "config1_dups_pair_mam": case_config1_dups_pair_mam,
+CASES = {"config4_genome_like_first100k": case_config4_genome_like_first100k, "config1_dups_pair": case_config1_dups_pair, "config1_dups_pair_mam": case_config1_dups_pair_mam,
          "config5_first100k": case_config5_first100k, "config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
          "config2_mam_first200k": case_config2_mam_first200k, "config1_pair_mam": case_config1_pair_mam}
 

@@ -211,17 +211,17 @@ def test_cli_n_gpu_schedule_on_logical_gpus(tmp_path):
 
 def test_cli_back_to_back_large_runs(tmp_path):
     """Two large jobs in a row on one GPU.  The first runs with SLAMEM_DETACH_TEARDOWN=1 (returns when its results are
-    written; its worker still holds the 132 GB index, here for 12 more seconds: SLAMEM_TEST_LINGER_MS); the second starts
-    at once, needs a 181 GB build peak on the 288 GB device, and must WAIT for the memory instead of failing
+    written; its worker still holds the 135 GB index, here for 12 more seconds: SLAMEM_TEST_LINGER_MS); the second starts
+    at once, needs a 197 GB build peak on the 288 GiB (309 GB) device, and must WAIT for the memory instead of failing
     (wait_for_hbm in host/main.c; the reference frees before it reports, slamem.c:208-216).  Both exit 0 with identical
-    output files.  2.2 Gbp text, 100,000 reads, -b -l 20."""
+    output files.  2.7 Gbp text, 100,000 reads, -b -l 20."""
     import time
     import numpy as np
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need an MI355X (there is no CPU path)")
     from slamem_amd import engine, synth
-    n, nreads, L = 2_200_000_000, 100_000, 150
+    n, nreads, L = 2_700_000_000, 100_000, 150
     ref = engine.synth_reference(n, 42, "cuda:0")
     reads = engine.synth_reads(ref, 0, nreads, L, 0.02, 42, 50)[: nreads * L].cpu().numpy().reshape(nreads, L)
     ref_h = ref.cpu().numpy()
@@ -247,7 +247,7 @@ def test_cli_back_to_back_large_runs(tmp_path):
     assert os.path.getsize(os.path.join(d, "o1.txt")) > 1_000_000
     try:
         with open(os.path.join(hostlib.ROOT, "gpurun_out", "back_to_back.txt"), "a") as f:
-            f.write(f"2.2 Gbp, 100k reads: first run (detached teardown, worker lingers 12 s) returned after {t1 - t0:.2f} s; "
+            f.write(f"2.7 Gbp, 100k reads: first run (detached teardown, worker lingers 12 s) returned after {t1 - t0:.2f} s; "
                     f"second run (default: returns when its memory is back) {t2 - t1:.2f} s; stderr of the second: "
                     f"{r2.stderr.decode(errors='replace').strip()}\n")
     except OSError:

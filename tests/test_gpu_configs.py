@@ -322,3 +322,67 @@ def test_genome_pair_with_exact_repeats_mem_and_mam_cli(eng, tmp_path, mam):
     data = (tmp_path / "out.txt").read_bytes()
     assert len(data) == known["file_bytes"]
     assert hashlib.sha256(data).hexdigest() == known["file_sha256"]
+
+
+def test_genome_like_generator_gpu_equals_numpy(eng):
+    """csrc/synth.hip and slamem_amd/synth.py make the same genome-like text (family, satellite, block of N) and the same reads
+    (none drawn from the block of N)."""
+    import torch
+    from slamem_amd import synth
+    n, L = 12_000_000, 150
+    ref_h = synth.make_reference(n, 5)
+    synth.plant_repeats(ref_h, 5)
+    lay = synth.plant_genome_like(ref_h, 5)
+    ref_d = eng.synth_reference(n, 5, "cuda:0")
+    eng.synth_plant_repeats(ref_d, 5)
+    eng.synth_plant_genome_like(ref_d, 5)
+    assert np.array_equal(ref_d.cpu().numpy(), ref_h)
+    avoid = (lay["n_block_at"], lay["n_block_letters"])
+    rh = synth.make_reads(ref_h, 100, 30_000, L, 0.02, 5, 50, avoid=avoid)
+    rd = eng.synth_reads(ref_d, 100, 30_000, L, 0.02, 5, 50, avoid=avoid)[: 30_000 * L].cpu().numpy().reshape(30_000, L)
+    assert np.array_equal(rd, rh)
+    assert not (rh == ord("N")).any() and (ref_h == ord("N")).sum() == lay["n_block_letters"]
+
+
+def test_config4_genome_like_repeat_load_known_answer(eng):
+    """A realistic repeat load on the chr1-sized text: 100,000 copies of a 300 bp family at 5-15 % divergence, a 171 bp x 10^4
+    satellite array and a 30 Mbp block of N on top of SURVEY's repeat model; the first 100,000 reads, -b -l 50, against the
+    digest of what the REAL reference printed (known_answers.json: config4_genome_like_first100k; slamem.c:139-193), plus the
+    definitional verifier on 400 of the reads (at least 100 of them drawn from family copies)."""
+    import torch
+    from slamem_amd import synth
+    if "config4_genome_like_first100k" not in KNOWN:
+        pytest.fail("tests/golden/known_answers.json has no config4_genome_like_first100k (tests/golden/make_known_answers.py)")
+    known = KNOWN["config4_genome_like_first100k"]
+    assert known["reference_valid"]
+    n, nreads, L, min_len = 248_000_000, 100_000, 150, 50
+    dev = "cuda:0"
+    ref = eng.synth_reference(n, 42, dev)
+    eng.synth_plant_repeats(ref, 42)
+    eng.synth_plant_genome_like(ref, 42)
+    copies, stride, sat_at, n_at, n_len = synth.genome_like_layout(n)
+    idx = eng.Index.build(ref, dev)
+    assert idx.info.num_n_rows == n_len
+    reads = eng.synth_reads(ref, 0, nreads, L, 0.02, 42, 50, avoid=(n_at, n_len))
+    offsets = torch.arange(nreads + 1, dtype=torch.int64, device=dev) * L
+    m = idx.matcher(nreads, True, 64 * nreads, nreads * L)
+    total = m.run(reads, offsets, min_len)
+    got, rows = digest_of(m, total, 2 * nreads)
+    note("config4_genome_like_first100k", got)
+    assert got == {k: known[k] for k in DIGEST_KEYS}, got
+    # completeness on reads drawn from family copies (their matches spread over thousands of BWT rows) and random ones
+    p = read_starts(n, L, nreads, 42)
+    hit = (p + L > n_at) & (p < n_at + n_len)
+    p = np.where(hit, p + n_len + L, p)
+    dst = (np.arange(copies, dtype=np.uint64) * np.uint64(stride)
+           + synth.splitmix64_at((42 + synth.GENOME_SALT + 1) & 0xFFFFFFFFFFFFFFFF, np.arange(copies, dtype=np.uint64)) % np.uint64(stride - 300)).astype(np.int64)
+    k = np.minimum(p // stride, copies - 1)
+    fam = np.nonzero((p + L > dst[k]) & (p < dst[k] + 300))[0]
+    rng = np.random.default_rng(77)
+    # (a family read's 21-letter seeds hit ~10^5 text positions: 100 + ~40 of them keep the host-side join to seconds)
+    sample = np.unique(np.concatenate([rng.choice(nreads, 300, replace=False), rng.choice(fam, 100, replace=False)]))
+    assert len(fam) >= 5000
+    ref_h = ref.cpu().numpy()
+    reads_h = reads[: nreads * L].cpu().numpy().reshape(nreads, L)
+    check_complete(ref_h, ref, reads_h, rows, sample, min_len, "config4_genome_like_verifier")
+    idx.close()
