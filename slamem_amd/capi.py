@@ -188,7 +188,7 @@ def synth_lib():
         S.slamem_synth_plant_repeats.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
         S.slamem_synth_reads_avoid.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
                                                C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
-        S.slamem_synth_plant_genome_like.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        S.slamem_synth_plant_genome_like.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         _SYNTH = S
     return _SYNTH
 

@@ -206,6 +206,14 @@ void search_job_slices_hint(SearchJob* j, uint32_t slices);
 constexpr uint32_t kSearchSliceLen = 4096;
 int search_job_tables(SearchJob* j, hipStream_t stream);
 int search_job_prep(SearchJob* j, hipStream_t stream);
-int search_job_search(SearchJob* j, hipStream_t stream);
+int search_job_search(SearchJob* j, hipStream_t stream);   // = search_job_k8(j, stream, nullptr, 0) + search_job_place
+// K8 without its tail: search_job_k8(..., carry_out = 1) ends when the batch's work list is empty and passes
+// its unfinished lanes on; the next batch's search_job_k8(next, stream, j, ...) -- or search_job_flush(j) when none follows --
+// finishes them; search_job_place (K9 + scalars) of a batch comes after that.
+int search_job_can_carry_into(const SearchJob* j, const SearchJob* next);
+int search_job_k8(SearchJob* j, hipStream_t stream, SearchJob* carry_from, int carry_out);
+int search_job_carried_out(const SearchJob* j);
+int search_job_flush(SearchJob* j, hipStream_t stream);
+int search_job_place(SearchJob* j, hipStream_t stream);
 int search_job_collect(SearchJob* j, uint64_t* total_out);
 }  // namespace slamem

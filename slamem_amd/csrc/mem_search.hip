@@ -199,6 +199,22 @@ struct SearchArgs {
     uint32_t pad4;
     const struct SliceState* slice_state;  // v3: start states of the slices of long records (k_slice_states), or nullptr
     const uint32_t* item_block;            //     strand block number of every item (with slice_state)
+    // kCarry (slamem_stream_*): K8 without its tail.  A launch that is followed by the next batch's does not wait for the last
+    // strands of its lanes: when the work list is empty every lane writes its state to carry_out and the kernel ends; the next
+    // launch takes those lanes in first (carry_in) and lets them write to the PREVIOUS batch's output side (prev).
+    struct OutCtx {
+        struct RawRow* inline_rows;
+        RawKey* raw_key;
+        slamem_mem* raw_mem;
+        unsigned long long* total;
+        uint64_t capacity;
+        uint32_t* block_counts;
+        uint8_t* item_attempt;
+    } prev;
+    const struct CarryRec* carry_in;       // lanes of the previous launch that were not finished (nullptr: none)
+    const unsigned int* carry_in_count;
+    struct CarryRec* carry_out;            // nullptr: run every strand to its end (a stand-alone launch, or the last of a stream)
+    unsigned int* carry_out_count;
 };
 
 // v3 raw record: the BWT row is resolved to SA[row] by K9, so the search kernel never waits for a locate.
@@ -728,6 +744,35 @@ __device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32
     }
 }
 
+// A lane's state between two trips of K8 (kCarry): 64 bytes
+struct __attribute__((aligned(16))) CarryRec {
+    uint32_t st_flags;  // st | pend << 8 | dmis << 9 | dcool << 10
+    uint32_t g, j, top, bot, k, qlen, dir_r;
+    int32_t depth, pub;
+    uint64_t qp;        // the strand's first word in the packed copy
+    uint32_t prev_top, prev_bot, pad0, pad1;
+};
+static_assert(sizeof(CarryRec) == 64, "carry record is one line");
+
+// emit3_at with the output side chosen per lane: `old` lanes (carried in from the previous launch) write to A.prev
+template <bool kCarry>
+__device__ __forceinline__ void emit3_sel(const SearchArgs& A, bool old, uint32_t g, uint32_t kk, uint32_t tag, uint32_t row,
+                                          uint32_t pos, uint32_t len) {
+    if (!kCarry) { emit3_at(A, g, kk, tag, row, pos, len); return; }
+    if (kk < kInlineMems) {
+        RawRow* ir = old ? A.prev.inline_rows : A.inline_rows;
+        ir[(uint64_t)g * kInlineMems + kk] = RawRow{row, pos, len};
+    } else {
+        unsigned long long* tot = old ? A.prev.total : A.total;
+        if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(tot) + 9, 1u);
+        unsigned long long slot = atomicAdd(tot, 1ull);
+        if (slot < (old ? A.prev.capacity : A.capacity)) {
+            (old ? A.prev.raw_key : A.raw_key)[slot] = RawKey{g, kk | tag};
+            (old ? A.prev.raw_mem : A.raw_mem)[slot] = slamem_mem{row, pos, len};
+        }
+    }
+}
+
 // One enumeration job of ONE strand, executed by the WHOLE wave (every argument is wave-uniform): all rows of
 // [t,b] at depth `msz` (only if `level0`), then of every ancestor interval still >= L deep, the new rows above
 // ascending and the new rows below descending (slamem.c:139-193).  The 64 lanes test 64 rows at a time for
@@ -735,7 +780,8 @@ __device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32
 // strand's emission order is exactly the reference's.  This is what makes repeats (intervals of thousands of
 // rows) cost rows/64 steps instead of rows.  Returns the strand's new MEM count; *first_parent = depth of the
 // parent of [t,b] (the exact value of `pub`).
-__device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t lane, uint32_t g, uint32_t k,
+template <bool kCarry>
+__device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, bool old, uint32_t lane, uint32_t g, uint32_t k,
                                                    uint32_t tag, uint32_t t, uint32_t b, int msz, bool level0, bool walk_up,
                                                    uint32_t pos, uint32_t left, int L, int* first_parent) {
     const IndexView& ix = A.ix;
@@ -747,7 +793,7 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
             uint32_t row = base + lane;
             bool ok = row < pt && bwt_code(ix, row) != left;
             unsigned long long m = __ballot(ok);
-            if (ok) emit3_at(A, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), tag, row, pos, (uint32_t)msz);
+            if (ok) emit3_sel<kCarry>(A, old, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), tag, row, pos, (uint32_t)msz);
             k += (uint32_t)__popcll(m);
         }
         for (uint32_t done = 0; done < b - pb; done += 64u) {  // new rows below, bottom-up (slamem.c:165)
@@ -755,7 +801,7 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, uint32_t
             uint32_t row = b - off;
             bool ok = off < b - pb && bwt_code(ix, row) != left;
             unsigned long long m = __ballot(ok);
-            if (ok) emit3_at(A, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), tag, row, pos, (uint32_t)msz);
+            if (ok) emit3_sel<kCarry>(A, old, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), tag, row, pos, (uint32_t)msz);
             k += (uint32_t)__popcll(m);
         }
         if (!walk_up) break;
@@ -940,8 +986,8 @@ enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, 
 // exact, 27 % fewer lines and 32 % fewer lane trips, but the same time -- the kernel is bound by instruction issue and
 // every trip pays for the union of the states its lanes are in -- so the default kernel is the one without them
 // (SLAMEM_SKIP=1 selects this one).
-template <bool kStats, bool kSkip, bool kSliced, bool kMam>
-__global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
+template <bool kStats, bool kSkip, bool kSliced, bool kMam, bool kCarry>
+__global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
     __shared__ ItemDesc lds_item[4][kFetch];
     __shared__ uint64_t lds_pk[4][kFetch];
     __shared__ uint32_t lds_id[4][kFetch];
@@ -981,6 +1027,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
              n_skp = 0, n_skok = 0;
 
     bool active = false, pend = false, dmis = false, dcool = false;
+    bool old = false;  // kCarry: the lane came in from the previous launch and writes to that batch's output side
     uint32_t st = ST_EXT;
     uint32_t g = 0, j = 0, top = 0, bot = 0, k = 0;
     uint32_t a_pos = 0, b_pos = 0, attempt = 0, qlen = 0;  // emitted slice [a_pos, b_pos) of the strand, warm-up attempt
@@ -994,6 +1041,22 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
     Blk kt;
     kt.a = kt.b = kt.c = kt.d = make_uint4(0, 0, 0, 0);
     uint32_t tag_t = 0xFFFFFFFFu;
+
+    if (kCarry && A.carry_in) {  // the unfinished lanes of the previous launch first (the grid always covers them)
+        const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < *A.carry_in_count) {
+            const uint4* r = reinterpret_cast<const uint4*>(A.carry_in + t);
+            const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+            st = r0.x & 0xFFu; pend = (r0.x >> 8) & 1u; dmis = (r0.x >> 9) & 1u; dcool = (r0.x >> 10) & 1u;
+            g = r0.y; j = r0.z; top = r0.w;
+            bot = r1.x; k = r1.y; qlen = r1.z; dir_r = r1.w;
+            depth = (int)r2.x; pub = (int)r2.y;
+            qc.init(reinterpret_cast<const uint64_t*>(u64_of(r2.z, r2.w)));
+            if (kMam) { prev_top = r3.x; prev_bot = r3.y; }
+            a_pos = 0; b_pos = qlen; attempt = 0;
+            active = true; old = true;
+        }
+    }
 
     for (;;) {
         // ---- hand the next items to idle lanes ----------------------------------------------------------------
@@ -1041,6 +1104,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                 attempt = 0;
                 j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
                 top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; k = 0; dcool = false;
+                if (kCarry) old = false;
                 if (kMam) { prev_top = 0; prev_bot = ix.n; }
                 // the first K letters through the jump table: no position that shallow can emit (K < L), and the scan
                 // must have more than K letters before the slice ends
@@ -1060,6 +1124,26 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
             }
             next += (uint32_t)__popcll(idle);
             // the LDS slots are reused by the next fetch: every lane has copied its descriptor by then (same wave, in order)
+        }
+        if (kCarry && A.carry_out && drained && next >= chunk_end && __ballot(active && old) == 0ull) {
+            // the list is empty and this wave has handed out all it fetched: its lanes do not run their strands to the end
+            // here (K8's tail, ~1 ms of a chip that empties), they go on in the next launch.  Lanes that came in from the
+            // previous launch are never passed on a second time (the wave stays until they are through: a strand's time)
+            const unsigned long long am = __ballot(active);
+            if (am != 0ull) {
+                unsigned int base = 0;
+                if (lane == 0u) base = atomicAdd(A.carry_out_count, (unsigned int)__popcll(am));
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if (active) {
+                    uint4* w = reinterpret_cast<uint4*>(A.carry_out + base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull)));
+                    const uint64_t qp = reinterpret_cast<uint64_t>(qc.p);
+                    w[0] = make_uint4(st | (pend ? 0x100u : 0u) | (dmis ? 0x200u : 0u) | (dcool ? 0x400u : 0u), g, j, top);
+                    w[1] = make_uint4(bot, k, qlen, dir_r);
+                    w[2] = make_uint4((uint32_t)depth, (uint32_t)pub, (uint32_t)qp, (uint32_t)(qp >> 32));
+                    w[3] = make_uint4(prev_top, prev_bot, 0u, 0u);
+                }
+            }
+            break;
         }
         if (__ballot(active) == 0ull) {
             if (drained && next >= chunk_end) break;
@@ -1201,7 +1285,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                 st = ST_EXT;
                 uint32_t t2 = top, b2 = bot;
                 pub = parent_from(rt, rb, t2, b2);
-                if (pub < L && top == bot) { emit3_at(A, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; }
+                if (pub < L && top == bot) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; }
                 else { e_on = true; e_level0 = true; e_up = pub >= L; e_pos = 0u; e_left = 0xFFu; }
                 pend = false;
                 finished = true;
@@ -1255,7 +1339,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                     // certified.  The position in front of the disagreeing letter is left-maximal: its one row (text position
                     // dir_r) is emitted if it is long enough (no ancestor can qualify: its class was checked when the run stopped)
                     const bool in_slice = j >= a_pos && j < b_pos;
-                    if (depth >= L && in_slice) { emit3_at(A, g, k, attempt << 28, dir_r, j, (uint32_t)depth | 0x80000000u); k++; }
+                    if (depth >= L && in_slice) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, dir_r, j, (uint32_t)depth | 0x80000000u); k++; }
                     j -= skw + 1u; dir_r -= skw + 1u; depth = (int)skw;
                     pend = false;
                     st = ST_DIR;
@@ -1342,7 +1426,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                 } else if (dmis && rt.w != 0u && !(pend && pdepth >= L)) {
                     // the letter to the left differs from the text's: what EXT + REC would do -- the pending row is
                     // left-maximal (slamem.c:141), then the interval widens to its parent and the letter is retried
-                    if (pend) { emit3_at(A, g, k, attempt << 28, top, j, (uint32_t)depth); k++; pend = false; }
+                    if (pend) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, top, j, (uint32_t)depth); k++; pend = false; }
                     top = rt.y; bot = rt.z; depth = pdepth; pub = pdepth - 1;
                     dcool = false;
                 }
@@ -1385,7 +1469,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                         anc = pub >= L;
                     }
                     if (!anc && (!lvl0 || size == 1u)) {  // the common case: at most this one row, no ancestors
-                        if (lvl0) { emit3_at(A, g, k, attempt << 28, top, j, (uint32_t)depth); k++; }
+                        if (lvl0) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, top, j, (uint32_t)depth); k++; }
                         pend = false;
                     } else {  // several rows and/or ancestors: the wave does it together, below; this trip only emits
                         e_on = true; e_level0 = lvl0; e_up = anc; e_pos = j; e_left = c;
@@ -1439,7 +1523,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
                 finished = true;
                 if (pend && pub >= L && !pub_exact) { st = ST_FLUSH; finished = false; }  // parent depth needed: next trip
                 else if (pend && pub >= L) { e_on = true; e_level0 = true; e_up = true; e_pos = 0u; e_left = 0xFFu; }
-                else if (pend && top == bot) { emit3_at(A, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; pend = false; }
+                else if (pend && top == bot) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; pend = false; }
                 else if (pend) { e_on = true; e_level0 = true; e_up = false; e_pos = 0u; e_left = 0xFFu; }
             }
         }
@@ -1453,7 +1537,8 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
             uint32_t o_pos = __shfl(e_pos, owner), o_left = __shfl(e_left, owner);
             bool o_l0 = __shfl((int)e_level0, owner) != 0, o_up = __shfl((int)e_up, owner) != 0;
             int fp;
-            uint32_t nk = wave_enumerate(A, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp);
+            const bool o_old = kCarry && __shfl((int)old, owner) != 0;
+            uint32_t nk = wave_enumerate<kCarry>(A, o_old, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp);
             if ((int)lane == owner) {
                 k = nk;
                 if (o_up) pub = fp;
@@ -1462,8 +1547,8 @@ __global__ void __launch_bounds__(256, (kSkip || kMam) ? 4 : SLAMEM_V3_WAVES) k_
         }
 
         if (active && finished) {
-            A.block_counts[g] = k;
-            A.item_attempt[g] = (uint8_t)attempt;
+            (kCarry && old ? A.prev.block_counts : A.block_counts)[g] = k;
+            (kCarry && old ? A.prev.item_attempt : A.item_attempt)[g] = (uint8_t)attempt;
             active = false;
         }
         if (kStats) n_enum += e_on;
@@ -1972,9 +2057,12 @@ namespace {
 inline unsigned grid_for(uint64_t items, unsigned block = 256) { return (unsigned)((items + block - 1) / block); }
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
+constexpr uint64_t kK8Waves = 4096;  // what the chip holds at 4 waves per SIMD: no workgroup waits behind the grid
+constexpr uint64_t kCarryLanes = kK8Waves * 64;
+
 struct WorkspaceLayout {
     uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_alive, off_workids, off_select, select_bytes, off_itemoff, off_rawkey,
-        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, off_mamstate, off_mamrun, off_itemblock, off_slicestate, max_bounds, max_items, bytes;
+        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, off_mamstate, off_mamrun, off_itemblock, off_slicestate, off_carry, max_bounds, max_items, bytes;
 };
 
 // max_items bounds the work items of ANY batch with this many records and characters
@@ -2020,6 +2108,7 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     w.off_mamrun = off;   off = align_up(off + w.max_bounds * 4, 256);
     w.off_itemblock = off; off = align_up(off + w.max_items * 4, 256);
     w.off_slicestate = off; off = align_up(off + w.max_bounds * sizeof(SliceState), 256);  // start states of slices (k_slice_states)
+    w.off_carry = off;    off = align_up(off + kCarryLanes * sizeof(CarryRec), 256);  // lanes handed to the next launch (kCarry)
     w.bytes = off;
     return w;
 }
@@ -2059,8 +2148,17 @@ struct SearchJob {
              uint64_t mems_capacity_, uint64_t* block_offsets_dev_, void* workspace_dev_, uint64_t workspace_bytes_);
     int tables(hipStream_t stream);
     int prep(hipStream_t stream);
-    int search(hipStream_t stream);
+    int search(hipStream_t stream) { int rc = search_k8(stream, nullptr, false); return rc != SLAMEM_OK ? rc : place(stream); }
+    // K8 alone.  carry_from: the job of the previous launch on this stream whose unfinished lanes this launch takes in (it
+    // must have been launched with carry_out); carry_out: end when the work list is empty and pass the unfinished lanes on
+    // (the NEXT launch, or flush(), finishes them -- only then may place() of this job follow)
+    int search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_out);
+    bool can_carry() const;                          // this batch runs on an instantiation that can pass lanes on / take them in
+    bool can_carry_into(const SearchJob& next) const;  // ... and `next` can take them
+    int flush(hipStream_t stream);                   // a launch without new work that finishes the lanes this job passed on
+    int place(hipStream_t stream);                   // K9 + the batch's scalars to the host
     int collect();
+    bool carried_out = false;
 };
 
 // One batch through the search, in steps that a caller may issue apart and on different streams (slamem_stream_* does: the
@@ -2264,34 +2362,86 @@ int SearchJob::prep(hipStream_t stream) {
     return SLAMEM_OK;
 }
 
-int SearchJob::search(hipStream_t stream) {
+bool SearchJob::can_carry() const {
+    return nitems != 0 && (match_type != 1 || mam_v3) && nitems == num_blocks && !A.skip_w && !want_stats;
+}
+bool SearchJob::can_carry_into(const SearchJob& next) const {
+    return can_carry() && next.can_carry() && next.idx == idx && next.min_len == min_len && next.strands == strands &&
+           next.mam_v3 == mam_v3 && next.A.direct_min_depth == A.direct_min_depth && next.A.use_jump == A.use_jump;
+}
+
+static void fill_prev_ctx(SearchArgs& A, const SearchJob& from) {
+    A.prev.inline_rows = from.A.inline_rows; A.prev.raw_key = from.A.raw_key; A.prev.raw_mem = from.A.raw_mem;
+    A.prev.total = from.A.total; A.prev.capacity = from.A.capacity; A.prev.block_counts = from.A.block_counts;
+    A.prev.item_attempt = from.A.item_attempt;
+    char* pws = static_cast<char*>(from.workspace_dev);
+    A.carry_in = reinterpret_cast<const CarryRec*>(pws + from.w.off_carry);
+    A.carry_in_count = reinterpret_cast<const unsigned int*>(reinterpret_cast<unsigned long long*>(pws + from.w.off_total) + 7);
+}
+
+int SearchJob::flush(hipStream_t stream) {
+    if (!carried_out) return SLAMEM_OK;
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    SearchArgs F = A;  // no new work: an empty list, nothing passed on
+    F.work_ids = nullptr; F.work_count = nullptr; F.num_items = 0;
+    F.carry_out = nullptr; F.carry_out_count = nullptr;
+    fill_prev_ctx(F, *this);
+    // (the cursor word of this job's scalar block has run past the end of its list: the empty list is drained at once)
+    const dim3 grid8(grid_for(kK8Waves * 64));
+    if (mam_v3) hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true, true>), grid8, dim3(256), 0, stream, F);
+    else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, true>), grid8, dim3(256), 0, stream, F);
+    STEP(hipGetLastError(), "k_find_mems_v3 (flush)");
+    carried_out = false;
+    return SLAMEM_OK;
+}
+
+int SearchJob::search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_out) {
     SLAMEM_HIP(hipSetDevice(idx->device));
     char* ws = static_cast<char*>(workspace_dev);
     unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
     launched = true;
+    carried_out = false;
+    if (carry_from && !(carry_from->carried_out && carry_from->can_carry_into(*this))) {
+        set_error("internal: K8 asked to take in the lanes of a launch that cannot pass them on");
+        return SLAMEM_ERR_ARG;
+    }
+    if (carry_out && !can_carry()) carry_out = false;
     if (nitems && (match_type != 1 || mam_v3)) {
         // persistent waves: as many as the chip holds (256 CUs x 16 waves), fewer for small batches
         uint64_t waves = (nitems + kFetch - 1) / kFetch;
         static const uint64_t env_waves = [] { const char* v = getenv("SLAMEM_K8_WAVES"); return v ? (uint64_t)atoll(v) : 0ull; }();
-        const uint64_t cap_waves = env_waves ? env_waves : 4096;  // what the chip holds at 4 waves per SIMD: no workgroup waits behind the grid
+        const uint64_t cap_waves = env_waves ? env_waves : kK8Waves;
         if (waves > cap_waves) waves = cap_waves;
+        const bool carry = carry_from != nullptr || carry_out;
+        if (carry) {  // the grid covers every lane that may come in, whatever the size of this batch
+            waves = kK8Waves;
+            A.carry_in = nullptr; A.carry_in_count = nullptr;
+            if (carry_from) fill_prev_ctx(A, *carry_from);
+            A.carry_out = carry_out ? reinterpret_cast<CarryRec*>(ws + w.off_carry) : nullptr;
+            A.carry_out_count = carry_out ? reinterpret_cast<unsigned int*>(d_total + 7) : nullptr;  // a word of the zeroed scalar block
+        }
         A.work_cursor = reinterpret_cast<unsigned int*>(d_total + 5);  // a word of the zeroed scalar block
         (void)hipEventRecord(ev[4], stream);
         timed_k8 = true;
         const dim3 grid8(grid_for(waves * 64));
         const bool sliced = nitems != num_blocks;  // some record is longer than a slice
-        if (A.skip_w) {  // (the skipping variant: one instantiation, with the slice logic)
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, true, false>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, true, true, false>), grid8, dim3(256), 0, stream, A);
+        if (carry) {
+            if (mam_v3) hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true, true>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, true>), grid8, dim3(256), 0, stream, A);
+            carried_out = carry_out;
+            if (carry_from) carry_from->carried_out = false;  // its lanes are taken care of by this launch
+        } else if (A.skip_w) {  // (the skipping variant: one instantiation, with the slice logic)
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, true, false, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, true, true, false, false>), grid8, dim3(256), 0, stream, A);
         } else if (sliced) {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, true, false>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, false, true, false>), grid8, dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, true, false, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, true, false, false>), grid8, dim3(256), 0, stream, A);
         } else if (mam_v3) {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false, true>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true>), grid8, dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false, true, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true, false>), grid8, dim3(256), 0, stream, A);
         } else {
-            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false, false>), grid8, dim3(256), 0, stream, A);
-            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false>), grid8, dim3(256), 0, stream, A);
+            if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, false, false, false, false>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, false>), grid8, dim3(256), 0, stream, A);
         }
         STEP(hipGetLastError(), "k_find_mems_v3");
     } else if (nitems) {  // -mam: K9 of the v3 path places the MAMs and resolves their rows
@@ -2362,6 +2512,14 @@ int SearchJob::search(hipStream_t stream) {
         }
     }
     (void)hipEventRecord(ev[1], stream);
+    return SLAMEM_OK;
+}
+
+int SearchJob::place(hipStream_t stream) {
+    SLAMEM_HIP(hipSetDevice(idx->device));
+    if (carried_out) { set_error("internal: K9 before the batch's last lanes are finished"); return SLAMEM_ERR_ARG; }
+    char* ws = static_cast<char*>(workspace_dev);
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
     // ---- K9, right behind K8: per-item counts -> offsets, strand-block offsets, placement.  Nothing here needs a number from
     // the host: the grids cover the items, the list of overflow records is walked by a fixed grid up to the device-side count,
     // and every store is bounds-checked against the capacity (a batch that does not fit is reported by collect()).
@@ -2489,6 +2647,11 @@ void search_job_slices_hint(SearchJob* j, uint32_t slices) { j->slices_hint = sl
 int search_job_tables(SearchJob* j, hipStream_t stream) { return j->tables(stream); }
 int search_job_prep(SearchJob* j, hipStream_t stream) { return j->prep(stream); }
 int search_job_search(SearchJob* j, hipStream_t stream) { return j->search(stream); }
+int search_job_can_carry_into(const SearchJob* j, const SearchJob* next) { return j->can_carry_into(*next) ? 1 : 0; }
+int search_job_k8(SearchJob* j, hipStream_t stream, SearchJob* carry_from, int carry_out) { return j->search_k8(stream, carry_from, carry_out != 0); }
+int search_job_carried_out(const SearchJob* j) { return j->carried_out ? 1 : 0; }
+int search_job_flush(SearchJob* j, hipStream_t stream) { return j->flush(stream); }
+int search_job_place(SearchJob* j, hipStream_t stream) { return j->place(stream); }
 int search_job_collect(SearchJob* j, uint64_t* total_out) {
     int rc = j->collect();
     if (total_out) *total_out = j->total;

@@ -32,7 +32,8 @@ namespace slamem {
 
 namespace {
 
-enum SlotState { FREE = 0, QUEUED = 1, UPLOADED = 2, PREPARED = 3, LAUNCHED = 4, DONE = 5, RETURNED = 6 };
+enum SlotState { FREE = 0, QUEUED = 1, UPLOADED = 2, PREPARED = 3, LAUNCHED = 4, DONE = 5, RETURNED = 6,
+                 K8_ISSUED = 7 };  // K8 enqueued with its lanes passed on; K9 follows behind the next batch's K8 (then LAUNCHED)
 constexpr int kMaxSlots = 8;
 constexpr int kThreads = 4;  // upload, prepare, search, download
 enum { T_UP = 0, T_PREP = 1, T_SEARCH = 2, T_DOWN = 3 };
@@ -66,7 +67,7 @@ struct Slot {
     // the batch on its way through the search (mem_search.hip), the events the stages hand it over with, and the pinned
     // words K9's stream copies the batch's totals into
     SearchJob* job = nullptr;
-    hipEvent_t ev_prep = nullptr, ev_done = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_done = nullptr, ev_k8 = nullptr;
     unsigned long long* h_scal = nullptr;
 };
 
@@ -87,6 +88,12 @@ struct slamem_stream {
     hipStream_t st_upx[3] = {nullptr, nullptr, nullptr};  // more copy streams of the upload stage (SLAMEM_STREAM_UPLOAD_SPLIT = 2..4)
     int upload_split = 2;
     int nthreads = kThreads;
+    // SLAMEM_STREAM_CARRY=1: K8 without its tail (below).  Off by default: it raises the pipeline's steady rate (868 M against
+    // 714 M MEMs/s with million-read batches) but every result then waits for the NEXT batch's K8, and on the 12 batches of
+    // the headline workload that latency costs more than the tails did (40.0 ms against 38.5; profiles/r03_host_leg.jsonl)
+    bool carry = false;
+    Slot* pending = nullptr;     // search stage only: the batch whose K8 has passed its unfinished lanes on
+    hipStream_t st_place = nullptr;    // K9 of every batch: behind the K8 that finished it, but not in front of the next K8
     hipStream_t st_search2 = nullptr;  // SLAMEM_STREAM_SEARCH_STREAMS=2: odd batches' K8 + K9 on a second stream (their K8 starts in the tail of the even one's)
     int search_streams = 1;
     double mems_per_char = 0;  // the densest batch so far: sizes a slot's first output buffers (written by the download stage)
@@ -186,6 +193,7 @@ int job_setup(slamem_stream* s, Slot& sl) {
     if (!sl.job && !(sl.job = search_job_new())) { set_error("out of host memory"); return SLAMEM_ERR_NOMEM; }
     if (!sl.ev_prep) SLAMEM_HIP(hipEventCreateWithFlags(&sl.ev_prep, hipEventDisableTiming));
     if (!sl.ev_done) SLAMEM_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+    if (!sl.ev_k8) SLAMEM_HIP(hipEventCreateWithFlags(&sl.ev_k8, hipEventDisableTiming));
     if (!sl.h_scal) SLAMEM_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_scal), 16 * sizeof(unsigned long long), hipHostMallocDefault));
     return search_job_init(sl.job, s->idx, device_queries(sl), sl.d_off, sl.nq, qbytes, sl.min_len, s->both, s->match_type, sl.d_mems,
                            sl.cap, sl.d_boff, sl.d_ws, sl.ws_bytes, sl.h_scal);
@@ -200,13 +208,64 @@ int stage_prepare(slamem_stream* s, Slot& sl) {
 }
 
 // stage 2: K8 + K9 behind the preparation, enqueued only: the search stream holds the K8s and K9s of all batches in flight,
-// one behind the other
-int stage_search(slamem_stream* s, Slot& sl) {
+// one behind the other.  K8 WITHOUT ITS TAIL: when another batch has been submitted behind this one, K8 ends as soon as its
+// work list is empty and passes the unfinished lanes on (search_job_k8 carry_out); the next batch's K8 takes them in first,
+// and only then this batch's K9 follows -- the chip never drains between two batches of a stream.  The last batch (nothing
+// submitted behind it) runs to its end as before.  `failed`: the batch comes from an earlier stage with an error and only
+// the batch waiting for it has to be finished.
+void finish_pending(slamem_stream* s, hipStream_t st) {  // K9 of the batch whose lanes are all through now; hand it to the download stage
+    Slot* p = s->pending;
+    s->pending = nullptr;
+    hipStream_t ps = s->st_place ? s->st_place : st;
+    if (ps != st) { (void)hipEventRecord(p->ev_k8, st); (void)hipStreamWaitEvent(ps, p->ev_k8, 0); }
+    int rc = search_job_place(p->job, ps);
+    (void)hipEventRecord(p->ev_done, ps);
+    if (rc != SLAMEM_OK) snprintf(p->err, sizeof(p->err), "%s", slamem_last_error_message());
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (rc != SLAMEM_OK) p->rc = rc;
+        p->state = LAUNCHED;
+    }
+    s->cv.notify_all();
+}
+int stage_search(slamem_stream* s, Slot& sl, bool failed, bool* issued_only) {
     hipStream_t st = (s->search_streams > 1 && (sl.seq & 1u)) ? s->st_search2 : s->st[T_SEARCH];
+    *issued_only = false;
+    if (failed) {
+        if (s->pending) {
+            (void)search_job_flush(s->pending->job, st);
+            finish_pending(s, st);
+        }
+        return SLAMEM_OK;
+    }
+    bool more;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        more = s->carry && s->search_streams == 1 && s->submitted > sl.seq + 1;
+    }
     SLAMEM_HIP(hipStreamWaitEvent(st, sl.ev_prep, 0));
-    int rc = search_job_search(sl.job, st);
+    int rc;
+    if (s->pending && search_job_can_carry_into(s->pending->job, sl.job)) {
+        rc = search_job_k8(sl.job, st, s->pending->job, more);
+        if (rc != SLAMEM_OK) (void)search_job_flush(s->pending->job, st);
+        finish_pending(s, st);
+    } else {
+        if (s->pending) {
+            (void)search_job_flush(s->pending->job, st);
+            finish_pending(s, st);
+        }
+        rc = search_job_k8(sl.job, st, nullptr, more);
+    }
+    if (rc == SLAMEM_OK && search_job_carried_out(sl.job)) {
+        s->pending = &sl;
+        *issued_only = true;  // its K9 and its event follow behind the next batch's K8
+        return SLAMEM_OK;
+    }
+    hipStream_t ps = s->st_place ? s->st_place : st;
+    if (ps != st) { SLAMEM_HIP(hipEventRecord(sl.ev_k8, st)); SLAMEM_HIP(hipStreamWaitEvent(ps, sl.ev_k8, 0)); }
+    if (rc == SLAMEM_OK) rc = search_job_place(sl.job, ps);
     // (recorded even after a failed launch: the download stage waits for whatever did get onto the stream)
-    SLAMEM_HIP(hipEventRecord(sl.ev_done, st));
+    SLAMEM_HIP(hipEventRecord(sl.ev_done, ps));
     return rc;
 }
 
@@ -269,11 +328,14 @@ void worker(slamem_stream* s, int t) {
             if (s->stop) return;
         }
         int rc = sl.rc;  // a batch that failed in an earlier stage passes through untouched
+        bool issued_only = false;
         const auto t_begin = std::chrono::steady_clock::now();
         if (rc == SLAMEM_OK) {
-            rc = t == T_UP ? stage_upload(s, sl) : t == T_PREP ? stage_prepare(s, sl) : t == T_SEARCH ? stage_search(s, sl)
+            rc = t == T_UP ? stage_upload(s, sl) : t == T_PREP ? stage_prepare(s, sl) : t == T_SEARCH ? stage_search(s, sl, false, &issued_only)
                                                                                                     : stage_download(s, sl);
             if (rc != SLAMEM_OK) snprintf(sl.err, sizeof(sl.err), "%s", slamem_last_error_message());  // the text is per thread
+        } else if (t == T_SEARCH) {
+            (void)stage_search(s, sl, true, &issued_only);
         } else if (t == T_DOWN && sl.ev_done) {
             (void)hipEventSynchronize(sl.ev_done);  // nothing of a failed batch may still run when its slot is handed back
         }
@@ -286,7 +348,7 @@ void worker(slamem_stream* s, int t) {
         {
             std::lock_guard<std::mutex> lk(s->mu);
             sl.rc = rc;
-            sl.state = done;
+            sl.state = issued_only ? (int)K8_ISSUED : done;
         }
         s->cv.notify_all();
     }
@@ -303,6 +365,7 @@ void free_slot(Slot& sl) {
     if (sl.h_scal) (void)hipHostFree(sl.h_scal);
     if (sl.ev_prep) (void)hipEventDestroy(sl.ev_prep);
     if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    if (sl.ev_k8) (void)hipEventDestroy(sl.ev_k8);
     if (sl.job) search_job_delete(sl.job);
 }
 
@@ -331,7 +394,7 @@ int slamem_stream_destroy(slamem_stream* s) {
         s->cv.wait(lk, [&] {
             for (int k = 0; k < s->nslots; k++)
                 if (s->slot[k].state == QUEUED || s->slot[k].state == UPLOADED || s->slot[k].state == PREPARED ||
-                    s->slot[k].state == LAUNCHED) return false;
+                    s->slot[k].state == LAUNCHED || s->slot[k].state == K8_ISSUED) return false;
             return true;
         });
         s->stop = true;
@@ -346,6 +409,7 @@ int slamem_stream_destroy(slamem_stream* s) {
     for (int k = 0; k < 3; k++)
         if (s->st_upx[k]) (void)hipStreamDestroy(s->st_upx[k]);
     if (s->st_search2) (void)hipStreamDestroy(s->st_search2);
+    if (s->st_place) (void)hipStreamDestroy(s->st_place);
     delete s;
     return SLAMEM_OK;
 }
@@ -380,6 +444,15 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
                                                  : hipStreamCreateWithFlags(&s->st[k], hipStreamNonBlocking);
             if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
         }
+        // K9 on a stream of its own (SLAMEM_STREAM_PLACE_STREAM=1) was measured and lost: behind a K8 that holds every wave
+        // slot its small kernels wait for the next tail (43-44 ms against 38.5)
+        v = getenv("SLAMEM_STREAM_PLACE_STREAM");
+        if (rc == SLAMEM_OK && v && atoi(v) != 0) {
+            hipError_t e = hipStreamCreateWithFlags(&s->st_place, hipStreamNonBlocking);
+            if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+        }
+        v = getenv("SLAMEM_STREAM_CARRY");
+        if (v) s->carry = atoi(v) != 0;
         v = getenv("SLAMEM_STREAM_SEARCH_STREAMS");
         if (rc == SLAMEM_OK && v && atoi(v) == 2) {
             hipError_t e = hipStreamCreateWithFlags(&s->st_search2, hipStreamNonBlocking);

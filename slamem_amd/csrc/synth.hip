@@ -146,7 +146,7 @@ __global__ void k_plant_n(uint8_t* text, uint64_t at, uint64_t len) {
     if (i < len) text[at + i] = 'N';
 }
 
-extern "C" int slamem_synth_plant_genome_like(void* text_dev, uint64_t n, uint64_t seed, void* stream) {
+extern "C" int slamem_synth_plant_genome_like(void* text_dev, uint64_t n, uint64_t seed, int with_n_block, void* stream) {
     if (n < 10000000ull) return -1;
     const uint64_t copies = n / 2480, stride = n / copies, sat_at = n / 3, n_at = n / 2;
     const uint64_t n_len = n / 8 < 30000000ull ? n / 8 : 30000000ull;
@@ -155,7 +155,7 @@ extern "C" int slamem_synth_plant_genome_like(void* text_dev, uint64_t n, uint64
     uint8_t* t = (uint8_t*)text_dev;
     hipLaunchKernelGGL(k_plant_family, dim3((unsigned)((copies * kFamilyLen + 255) / 256)), dim3(256), 0, st, t, sf, copies, stride);
     hipLaunchKernelGGL(k_plant_satellite, dim3((unsigned)((sat + 255) / 256)), dim3(256), 0, st, t, sf, sat_at, sat);
-    hipLaunchKernelGGL(k_plant_n, dim3((unsigned)((n_len + 255) / 256)), dim3(256), 0, st, t, n_at, n_len);
+    if (with_n_block) hipLaunchKernelGGL(k_plant_n, dim3((unsigned)((n_len + 255) / 256)), dim3(256), 0, st, t, n_at, n_len);
     return (int)hipGetLastError();
 }
 

@@ -478,10 +478,10 @@ def synth_plant_repeats(ref: torch.Tensor, seed: int = 42) -> int:
     return int(planted.value)
 
 
-def synth_plant_genome_like(ref: torch.Tensor, seed: int = 42) -> None:
-    """The genome-like repeat load (interspersed family, satellite array, block of N) applied in place; same values as
-    slamem_amd.synth.plant_genome_like."""
-    rc = capi.synth_lib().slamem_synth_plant_genome_like(_ptr(ref), ref.numel(), seed, _stream_handle(ref.device))
+def synth_plant_genome_like(ref: torch.Tensor, seed: int = 42, n_block: bool = True) -> None:
+    """The genome-like repeat load (interspersed family, satellite array, block of N unless n_block=False) applied in place;
+    same values as slamem_amd.synth.plant_genome_like."""
+    rc = capi.synth_lib().slamem_synth_plant_genome_like(_ptr(ref), ref.numel(), seed, int(bool(n_block)), _stream_handle(ref.device))
     if rc:
         raise RuntimeError(f"synth kernel launch failed: hip error {rc}")
 

@@ -133,8 +133,11 @@ def genome_like_layout(n: int):
     return copies, stride, sat_at, n_at, n_len
 
 
-def plant_genome_like(ref: np.ndarray, seed: int = 42) -> dict:
-    """Apply the genome-like model in place (after plant_repeats, if both are wanted).  Returns its layout."""
+def plant_genome_like(ref: np.ndarray, seed: int = 42, n_block: bool = True) -> dict:
+    """Apply the genome-like model in place (after plant_repeats, if both are wanted).  Returns its layout.
+    n_block=False leaves the block of N out: the REAL reference restores LCP values >= 255 by comparing the text letter by
+    letter (lcparray.c:650-662), which is quadratic in the length of a run of N -- a 30 Mbp block never finishes there (30
+    CPU-minutes in that loop before the round-3 run was stopped), so the reference-pinned case is made without it."""
     n = ref.shape[0]
     if n < 10_000_000:
         raise ValueError("genome-like model needs n >= 10^7")
@@ -159,7 +162,10 @@ def plant_genome_like(ref: np.ndarray, seed: int = 42) -> dict:
     code = unit[(i % np.uint64(SAT_UNIT)).astype(np.int64)]
     sub = (x & np.uint64(0xFFFFFFFF)) < np.uint64(int(0.02 * 4294967296.0))
     ref[sat_at:sat_at + tot] = np.where(sub, _ALT[code, ((x >> np.uint64(32)) % np.uint64(3)).astype(np.int64)], _ACGT[code])
-    ref[n_at:n_at + n_len] = ord("N")
+    if n_block:
+        ref[n_at:n_at + n_len] = ord("N")
+    else:
+        n_len = 0
     return {"family_copies": copies, "family_stride": stride, "satellite_at": sat_at, "satellite_letters": tot,
             "n_block_at": n_at, "n_block_letters": n_len}
 

@@ -345,9 +345,10 @@ def test_genome_like_generator_gpu_equals_numpy(eng):
 
 
 def test_config4_genome_like_repeat_load_known_answer(eng):
-    """A realistic repeat load on the chr1-sized text: 100,000 copies of a 300 bp family at 5-15 % divergence, a 171 bp x 10^4
-    satellite array and a 30 Mbp block of N on top of SURVEY's repeat model; the first 100,000 reads, -b -l 50, against the
-    digest of what the REAL reference printed (known_answers.json: config4_genome_like_first100k; slamem.c:139-193), plus the
+    """A realistic repeat load on the chr1-sized text: 100,000 copies of a 300 bp family at 5-15 % divergence and a 171 bp x
+    10^4 satellite array on top of SURVEY's repeat model (the model's 30 Mbp block of N is left out here: the reference's LCP
+    restoration is quadratic on it and does not finish; tools/repeat_load.py and the generator test keep it); the first
+    100,000 reads, -b -l 50, against the digest of what the REAL reference printed (known_answers.json: config4_genome_like_first100k; slamem.c:139-193), plus the
     definitional verifier on 400 of the reads (at least 100 of them drawn from family copies)."""
     import torch
     from slamem_amd import synth
@@ -359,11 +360,11 @@ def test_config4_genome_like_repeat_load_known_answer(eng):
     dev = "cuda:0"
     ref = eng.synth_reference(n, 42, dev)
     eng.synth_plant_repeats(ref, 42)
-    eng.synth_plant_genome_like(ref, 42)
+    eng.synth_plant_genome_like(ref, 42, n_block=False)
     copies, stride, sat_at, n_at, n_len = synth.genome_like_layout(n)
     idx = eng.Index.build(ref, dev)
-    assert idx.info.num_n_rows == n_len
-    reads = eng.synth_reads(ref, 0, nreads, L, 0.02, 42, 50, avoid=(n_at, n_len))
+    assert idx.info.num_n_rows == 0
+    reads = eng.synth_reads(ref, 0, nreads, L, 0.02, 42, 50)
     offsets = torch.arange(nreads + 1, dtype=torch.int64, device=dev) * L
     m = idx.matcher(nreads, True, 64 * nreads, nreads * L)
     total = m.run(reads, offsets, min_len)
@@ -372,8 +373,6 @@ def test_config4_genome_like_repeat_load_known_answer(eng):
     assert got == {k: known[k] for k in DIGEST_KEYS}, got
     # completeness on reads drawn from family copies (their matches spread over thousands of BWT rows) and random ones
     p = read_starts(n, L, nreads, 42)
-    hit = (p + L > n_at) & (p < n_at + n_len)
-    p = np.where(hit, p + n_len + L, p)
     dst = (np.arange(copies, dtype=np.uint64) * np.uint64(stride)
            + synth.splitmix64_at((42 + synth.GENOME_SALT + 1) & 0xFFFFFFFFFFFFFFFF, np.arange(copies, dtype=np.uint64)) % np.uint64(stride - 300)).astype(np.int64)
     k = np.minimum(p // stride, copies - 1)

@@ -623,3 +623,40 @@ def test_auto_layout_follows_the_free_hbm(eng, monkeypatch):
     m = g.matcher(20_000, True, 200_000, 3_000_000)
     assert m.run(reads, offsets, 20) == t_compact > 20_000
     g.close()
+
+
+@pytest.mark.parametrize("mam", [False, True], ids=["mem", "mam"])
+def test_stream_k8_without_tail_passes_lanes_to_the_next_batch(eng, mam, monkeypatch):
+    """slamem_stream_* with SLAMEM_STREAM_CARRY=1 and five batches in flight: every K8 but the last ends when its work list is empty and passes its
+    unfinished lanes -- mid-strand, in any state of the scan -- to the next batch's K8 (kCarry); their MEMs
+    land in the batch they belong to.  Reads with N, repeats (multi-row intervals: enumeration jobs of carried lanes),
+    min_len 9, both strands; batches of very different sizes, one of them empty: every batch equals the oracle in order
+    (slamem.c:114-199)."""
+    from oracle import pyoracle as po
+    monkeypatch.setenv("SLAMEM_STREAM_CARRY", "1")
+    rng = np.random.default_rng(4242)
+    text = rand_text(rng, 300_000, "ACGT", 120, max_rep=600)
+    qs = make_queries(rng, text, 24_000, "ACGTN", maxlen=260)
+    q, off = pack(qs)
+    idx = eng.Index.build(text)
+    o = po.OracleIndex(bytes(text))
+    buf = eng.PinnedBuffer(len(q) + 64)
+    buf.array[: len(q)] = q
+    bounds = [0, 3000, 3040, 9000, 9000, 15000, 15500, 21000, 23900, 24000]
+    wins = [off[bounds[b]: bounds[b + 1] + 1] for b in range(len(bounds) - 1)]
+    st = eng.Stream(idx, 6, 1 << 20, 6000, True, mam=mam)
+    nb = len(wins)
+    for b in range(min(5, nb)):
+        st.submit(buf.array, wins[b], 9)
+    for b in range(nb):
+        m, boff, _ = st.next()
+        if b + 5 < nb:
+            st.submit(buf.array, wins[b + 5], 9)
+        w = wins[b]
+        om, obc = o.match_batch(q[int(w[0]): int(w[-1])], w - w[0], 9, True, mam=mam)
+        assert np.array_equal(np.diff(boff.astype(np.int64)), obc.astype(np.int64)), b
+        for f in ("ref_pos", "query_pos", "length"):
+            assert np.array_equal(m[f], om[f]), (b, f)
+    st.close()
+    buf.close()
+    idx.close()
