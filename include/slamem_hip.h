@@ -128,6 +128,8 @@ typedef struct {
     uint64_t skip_probe_lines;      /* K8 skipping: words of the k-mer occurrence bitmap read                          */
     uint64_t skip_attempts;         /* K8 skipping: diagonals verified (probes follow)                                 */
     uint64_t skips;                 /* K8 skipping: stretches skipped (min_len positions each)                         */
+    uint64_t enum_row_steps;        /* K8: wave steps of the enumeration jobs (64 rows tested for left-maximality each)  */
+    uint64_t enum_levels;           /* K8: ancestor intervals the enumeration jobs walked up to (one record round trip each) */
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

@@ -83,7 +83,8 @@ class SearchStats(C.Structure):
         "fm_lines_top", "fm_lines_bottom", "rec_lines_fail", "rec_lines_pend", "rec_lines_flush", "query_loads",
         "lane_trips", "wave_trips", "positions", "enum_jobs", "prefilter_probes", "prefilter_query_loads",
         "prefilter_items", "items", "survivors", "mems", "overflow_records", "valid", "dir_sa_lines", "dir_group_loads",
-        "dir_rec_lines", "dir_letters", "jump_lines", "skip_group_loads", "skip_probe_lines", "skip_attempts", "skips")]
+        "dir_rec_lines", "dir_letters", "jump_lines", "skip_group_loads", "skip_probe_lines", "skip_attempts", "skips",
+        "enum_row_steps", "enum_levels")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -213,6 +213,27 @@ __global__ void __launch_bounds__(256) k_rank_samples(const uint4* __restrict__ 
 // k- and (k+2)-mers of the text that contain it.  Windows containing N are not entered (a query window with N is
 // treated as present, so N == N matches are never filtered out).
 // ------------------------------------------------------------------------------------------
+// 16 packed letters (4-bit ids, first on top) -> their 2-bit values (id - 2; first letter in the highest bits of the 32) and a
+// bit per letter that is one of A,C,G,T (first letter = bit 15)
+__device__ __forceinline__ void letters16(uint64_t x, uint32_t& v2, uint32_t& ok16) {
+    const uint64_t k1 = 0x1111111111111111ull;
+    uint64_t okn = ((x >> 1) | (x >> 2) | (x >> 3)) & k1;            // nibble >= 2
+    uint64_t c = (x - 2ull * okn) & (3ull * okn);                     // id - 2 where ok, 0 elsewhere (no borrow: ok nibbles are >= 2)
+    // gather the low 2 bits of every nibble: 64 -> 32 bits
+    c = (c & 0x0303030303030303ull) | ((c & 0x3030303030303030ull) >> 2);
+    c = (c & 0x000F000F000F000Full) | ((c & 0x0F000F000F000F00ull) >> 4);
+    c = (c & 0x000000FF000000FFull) | ((c & 0x00FF000000FF0000ull) >> 8);
+    c = (c & 0xFFFFull) | ((c >> 16) & 0xFFFF0000ull);
+    v2 = (uint32_t)c;
+    // gather bit 0 of every nibble: 64 -> 16 bits
+    uint64_t o = okn;
+    o = (o & 0x0101010101010101ull) | ((o & 0x1010101010101010ull) >> 3);
+    o = (o & 0x0003000300030003ull) | ((o & 0x0300030003000300ull) >> 6);
+    o = (o & 0x0000000F0000000Full) | ((o & 0x000F0000000F0000ull) >> 12);
+    o = (o & 0xFFull) | ((o >> 24) & 0xFF00ull);
+    ok16 = (uint32_t)o;
+}
+
 // The entries of text position p: hash of the (k-2)-mer that starts there (-> the line) and the bits of every entry in the
 // line's eight words.  false: the (k-2)-mer does not lie in the text or holds an N (nothing is entered).
 __device__ __forceinline__ bool kfilter_entries(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k, uint32_t levels,
@@ -221,13 +242,23 @@ __device__ __forceinline__ bool kfilter_entries(const uint64_t* __restrict__ pk,
     if (p + k1 > n) return false;
     // the letters [p-4, p+k1+4) as 2-bit values, first letter in the highest bits; ok: bit per letter, set when the
     // letter exists and is not N
-    const uint32_t wn = k1 + 8u;
+    const uint32_t wn = k1 + 8u;  // <= 32 (k <= 26)
     uint64_t w = 0, ok = 0;
-    for (uint32_t d = 0; d < wn; d++) {
-        const int64_t t = (int64_t)p - 4 + (int64_t)d;
-        uint32_t c = (t >= 0 && t < (int64_t)n) ? nibble_at(pk, (uint64_t)t) : 0u;
-        w = (w << 2) | (uint64_t)(c >= 2u ? c - 2u : 0u);
-        ok = (ok << 1) | (uint64_t)(c >= 2u);
+    if (p >= 4u) {
+        // 32 letters from p-4 on in two packed words (behind the text the packed copy holds zeros: '$' and padding, not ok)
+        uint32_t va, oa, vb, ob;
+        letters16(window16(pk, p - 4u), va, oa);
+        letters16(window16(pk, p + 12u), vb, ob);
+        const uint64_t v64 = ((uint64_t)va << 32) | vb, o32 = ((uint64_t)oa << 16) | ob;
+        w = v64 >> (2u * (32u - wn));
+        ok = o32 >> (32u - wn);
+    } else {
+        for (uint32_t d = 0; d < wn; d++) {
+            const int64_t t = (int64_t)p - 4 + (int64_t)d;
+            uint32_t c = (t >= 0 && t < (int64_t)n) ? nibble_at(pk, (uint64_t)t) : 0u;
+            w = (w << 2) | (uint64_t)(c >= 2u ? c - 2u : 0u);
+            ok = (ok << 1) | (uint64_t)(c >= 2u);
+        }
     }
     auto piece = [&](uint32_t first, uint32_t len, uint64_t& v) {  // letters [first, first+len) of the window
         const uint32_t sh = wn - first - len;
@@ -292,53 +323,63 @@ __global__ void __launch_bounds__(256) k_kfilter_keys(const uint64_t* __restrict
     if (p >= (uint64_t)n) return;
     const uint32_t k1 = k - 2u;
     uint64_t key = 1ull << (log2_words - 3u);  // behind every line
-    if (p + k1 <= n) {
-        uint64_t v = 0;
-        bool ok = true;
-        for (uint32_t d = 0; d < k1; d++) {
-            const uint32_t c = nibble_at(pk, p + d);
-            ok = ok && c >= 2u;
-            v = (v << 2) | (uint64_t)(c >= 2u ? c - 2u : 0u);
-        }
-        if (ok) key = kfilter_line(kfilter_hash(v ^ kFilterShortSalt), log2_words) >> 3;
+    if (p + k1 <= n) {  // (k1 <= 24: two packed words hold the letters)
+        uint32_t va, oa, vb, ob;
+        letters16(window16(pk, p), va, oa);
+        letters16(window16(pk, p + 16u), vb, ob);
+        const uint64_t v64 = ((uint64_t)va << 32) | vb, o32 = ((uint64_t)oa << 16) | ob;
+        const uint64_t v = v64 >> (2u * (32u - k1));
+        const uint64_t all = (1ull << k1) - 1ull;
+        if (((o32 >> (32u - k1)) & all) == all) key = kfilter_line(kfilter_hash(v ^ kFilterShortSalt), log2_words) >> 3;
     }
     keys[p] = key;
     vals[p] = (uint32_t)p;
 }
 
-// (runs longer than kFilterRun -- the same (k-2)-mer thousands of times: satellites, homopolymers -- are not walked by one
-//  lane: positions from the kFilterRun-th of a run on enter their bits themselves with atomics, as the direct form does,
-//  and the owner of such a run uses atomics too)
-constexpr uint32_t kFilterRun = 32;
+// Every lane computes the entries of ITS position (all lanes busy: the hashes are most of the work), the block's lanes put
+// them into LDS, and the first lane of every run of equal keys inside the block ORs its run together and writes the line:
+// with one 64-byte store when the whole run lies inside the block (nearly all: three positions per line on average), with
+// atomics when the run crosses a block boundary (the other part writes the same line).  A satellite array or a homopolymer --
+// one (k-2)-mer thousands of times -- is many block-sized pieces of one run, all but the entries of 256 positions combined
+// before they reach memory.
 __global__ void __launch_bounds__(256) k_kfilter_fill(const uint64_t* __restrict__ pk, uint32_t n, uint32_t k,
                                                       uint32_t log2_words, uint32_t levels,
                                                       const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                       unsigned long long* __restrict__ filter) {
+    __shared__ unsigned long long sh_w[256][9];  // (9: the rows start in different banks)
+    __shared__ uint64_t sh_key[256 + 2];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)n) return;
-    const uint64_t key = keys[i], none = 1ull << (log2_words - 3u);
-    if (key == none) return;  // no (k-2)-mer here
+    const uint32_t t = threadIdx.x;
+    const uint64_t none = 1ull << (log2_words - 3u);
+    const uint64_t key = i < (uint64_t)n ? keys[i] : none;
+    unsigned long long words[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    if (key != none) {
+        uint64_t h0;
+        if (!kfilter_entries(pk, n, k, levels, (uint64_t)vals[i], h0, words)) {
+#pragma unroll
+            for (uint32_t wd = 0; wd < 8u; wd++) words[wd] = 0ull;
+        }
+    }
+#pragma unroll
+    for (uint32_t wd = 0; wd < 8u; wd++) sh_w[t][wd] = words[wd];
+    sh_key[t + 1] = key;
+    if (t == 0) {  // the keys on both sides of the block: does a run go on there?
+        const uint64_t b0 = (uint64_t)blockIdx.x * blockDim.x;
+        sh_key[0] = b0 > 0 ? keys[b0 - 1] : ~0ull;
+        sh_key[257] = b0 + 256 < (uint64_t)n ? keys[b0 + 256] : ~0ull;
+    }
+    __syncthreads();
+    if (key == none || (t != 0 && sh_key[t] == key)) return;  // nothing here / not the first of its run inside the block
+    bool whole = sh_key[t] != key;  // (t == 0: the run may have started in the block before)
+    unsigned long long acc[8] = {words[0], words[1], words[2], words[3], words[4], words[5], words[6], words[7]};
+    uint32_t j = t + 1;
+    for (; j < 256u && sh_key[j + 1] == key; j++) {
+#pragma unroll
+        for (uint32_t wd = 0; wd < 8u; wd++) acc[wd] |= sh_w[j][wd];
+    }
+    if (j == 256u && sh_key[257] == key) whole = false;  // it goes on in the next block
     unsigned long long* line = filter + (key << 3);
-    uint64_t h0;
-    unsigned long long words[8];
-    if (i >= kFilterRun && keys[i - kFilterRun] == key) {  // deep inside a long run: on its own
-        if (kfilter_entries(pk, n, k, levels, (uint64_t)vals[i], h0, words)) {
-#pragma unroll
-            for (uint32_t wd = 0; wd < 8u; wd++)
-                if (words[wd]) atomicOr(&line[wd], words[wd]);
-        }
-        return;
-    }
-    if (i != 0 && keys[i - 1] == key) return;  // not the first of its run
-    unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-    uint64_t j = i;
-    for (; j < (uint64_t)n && j < i + kFilterRun && keys[j] == key; j++) {
-        if (kfilter_entries(pk, n, k, levels, (uint64_t)vals[j], h0, words)) {
-#pragma unroll
-            for (uint32_t wd = 0; wd < 8u; wd++) acc[wd] |= words[wd];
-        }
-    }
-    if (j < (uint64_t)n && keys[j] == key) {  // the run goes on: others write this line too
+    if (!whole) {
 #pragma unroll
         for (uint32_t wd = 0; wd < 8u; wd++)
             if (acc[wd]) atomicOr(&line[wd], acc[wd]);
@@ -1104,6 +1145,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         hipLaunchKernelGGL(k_kjump_bounds, dim3(grid_for(R)), dim3(256), 0, stream, tmp32.as<uint32_t>(), n, d_kj);
         SLAMEM_HIP(hipGetLastError());
     }
+    mark("K1c k-mer jump table");
     if (hdr.off_kbits) {
         unsigned long long* d_bits = reinterpret_cast<unsigned long long*>(base + hdr.off_kbits);
         SLAMEM_HIP(hipMemsetAsync(d_bits, 0, (1ull << (2u * hdr.kbits_k)) >> 3, stream));
@@ -1125,9 +1167,11 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
             hipLaunchKernelGGL(k_kfilter_keys, dim3(grid_for(n)), dim3(256), 0, stream, pk.as<uint64_t>(), n, hdr.kfilter_k,
                                hdr.kfilter_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>());
             SLAMEM_HIP(hipGetLastError());
+            mark("K1b filter keys");
             need = tmp_bytes;
             SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysB.as<uint64_t>(), keysA.as<uint64_t>(), valsB.as<uint32_t>(),
                                           valsA.as<uint32_t>(), n, 0, (int)hdr.kfilter_log2 - 3 + 1, stream));
+            mark("K1b filter sort");
             SLAMEM_HIP(hipMemsetAsync(d_filter, 0, 8ull << hdr.kfilter_log2, stream));
             hipLaunchKernelGGL(k_kfilter_fill, dim3(grid_for(n)), dim3(256), 0, stream, pk.as<uint64_t>(), n, hdr.kfilter_k,
                                hdr.kfilter_log2, hdr.kfilter_levels, (const uint64_t*)keysA.as<uint64_t>(),
@@ -1137,7 +1181,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
 
 
-    mark("K1b k-mer filter");
+    mark("K1b filter fill");
     // ---- K3: BWT planes + rank samples ------------------------------------------------------------
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
     SLAMEM_HIP(hipMemsetAsync(d_fm, 0, (uint64_t)nblocks * sizeof(FMBlock), stream));

@@ -773,6 +773,43 @@ __device__ __forceinline__ void emit3_sel(const SearchArgs& A, bool old, uint32_
     }
 }
 
+// The rows a wave reports in ONE step of an enumeration job: lane `lane` reports (row, pos, len) as MEM number
+// k + (reporting lanes below it) of strand block g when `ok`.  The first kInlineMems of a strand go to its inline slots; all
+// the others of the step take their places in the overflow list with ONE atomic for the wave (the per-lane form,
+// emit3_at, is 64 atomics on one address per step: on a text with a 10^5-copy repeat family that counter was the whole
+// kernel -- 0.43 G MEMs/s, 84 ms per million reads at -l 50; profiles/r03_repeat_load.jsonl).
+template <bool kCarry>
+__device__ __forceinline__ uint32_t wave_emit_step(const SearchArgs& A, bool old, uint32_t lane, uint32_t g, uint32_t k, uint32_t tag,
+                                                   bool ok, uint32_t row, uint32_t pos, uint32_t len) {
+    const unsigned long long m = __ballot(ok);
+    if (m == 0ull) return k;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t kk = k + (uint32_t)__popcll(m & below);
+    const bool inl = ok && kk < kInlineMems;
+    const unsigned long long mo = __ballot(ok && !inl);
+    if (inl) {
+        RawRow* ir = (kCarry && old) ? A.prev.inline_rows : A.inline_rows;
+        ir[(uint64_t)g * kInlineMems + kk] = RawRow{row, pos, len};
+    }
+    if (mo != 0ull) {
+        unsigned long long* tot = (kCarry && old) ? A.prev.total : A.total;
+        const uint64_t cap = (kCarry && old) ? A.prev.capacity : A.capacity;
+        const int leader = __ffsll((long long)mo) - 1;
+        unsigned long long base = 0ull;
+        if ((int)lane == leader) base = atomicAdd(tot, (unsigned long long)__popcll(mo));
+        const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader), bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader);
+        if (ok && !inl) {
+            if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(tot) + 9, 1u);  // the ordinal would run into the tag: reported as an error
+            const unsigned long long slot = u64_of(blo, bhi) + (unsigned long long)__popcll(mo & below);
+            if (slot < cap) {
+                ((kCarry && old) ? A.prev.raw_key : A.raw_key)[slot] = RawKey{g, kk | tag};
+                ((kCarry && old) ? A.prev.raw_mem : A.raw_mem)[slot] = slamem_mem{row, pos, len};  // ref_pos holds the ROW until K9
+            }
+        }
+    }
+    return k + (uint32_t)__popcll(m);
+}
+
 // One enumeration job of ONE strand, executed by the WHOLE wave (every argument is wave-uniform): all rows of
 // [t,b] at depth `msz` (only if `level0`), then of every ancestor interval still >= L deep, the new rows above
 // ascending and the new rows below descending (slamem.c:139-193).  The 64 lanes test 64 rows at a time for
@@ -783,7 +820,8 @@ __device__ __forceinline__ void emit3_sel(const SearchArgs& A, bool old, uint32_
 template <bool kCarry>
 __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, bool old, uint32_t lane, uint32_t g, uint32_t k,
                                                    uint32_t tag, uint32_t t, uint32_t b, int msz, bool level0, bool walk_up,
-                                                   uint32_t pos, uint32_t left, int L, int* first_parent) {
+                                                   uint32_t pos, uint32_t left, int L, int* first_parent,
+                                                   uint32_t* row_steps = nullptr, uint32_t* levels = nullptr) {
     const IndexView& ix = A.ix;
     uint32_t pt = level0 ? b + 1u : t, pb = b;  // rows already reported: [pt, pb]
     bool first = true;
@@ -792,22 +830,21 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, bool old
         for (uint32_t base = t; base < pt; base += 64u) {  // new rows above, ascending (slamem.c:140)
             uint32_t row = base + lane;
             bool ok = row < pt && bwt_code(ix, row) != left;
-            unsigned long long m = __ballot(ok);
-            if (ok) emit3_sel<kCarry>(A, old, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), tag, row, pos, (uint32_t)msz);
-            k += (uint32_t)__popcll(m);
+            k = wave_emit_step<kCarry>(A, old, lane, g, k, tag, ok, row, pos, (uint32_t)msz);
+            if (row_steps) (*row_steps)++;
         }
         for (uint32_t done = 0; done < b - pb; done += 64u) {  // new rows below, bottom-up (slamem.c:165)
             uint32_t off = done + lane;
             uint32_t row = b - off;
             bool ok = off < b - pb && bwt_code(ix, row) != left;
-            unsigned long long m = __ballot(ok);
-            if (ok) emit3_sel<kCarry>(A, old, g, k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), tag, row, pos, (uint32_t)msz);
-            k += (uint32_t)__popcll(m);
+            k = wave_emit_step<kCarry>(A, old, lane, g, k, tag, ok, row, pos, (uint32_t)msz);
+            if (row_steps) (*row_steps)++;
         }
         if (!walk_up) break;
         pt = t;
         pb = b;
         msz = parent(ix, t, b);  // same address in every lane: one line, broadcast (slamem.c:192)
+        if (levels) (*levels)++;
         if (first) { *first_parent = msz; first = false; }
         if (msz < L) break;
     }
@@ -821,7 +858,7 @@ enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
     SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
-    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_COUNT
+    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -1024,7 +1061,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
     if (kStats && (threadIdx.x & 63u) == 0u) atomicMin(A.stats + SC_T_FIRST, t_wave0);
     uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_wtrips = 0, n_pos = 0,
              n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0, n_jump = 0, n_skv = 0, n_skq = 0,
-             n_skp = 0, n_skok = 0;
+             n_skp = 0, n_skok = 0, n_erow = 0, n_elev = 0;
 
     bool active = false, pend = false, dmis = false, dcool = false;
     bool old = false;  // kCarry: the lane came in from the previous launch and writes to that batch's output side
@@ -1538,7 +1575,10 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
             bool o_l0 = __shfl((int)e_level0, owner) != 0, o_up = __shfl((int)e_up, owner) != 0;
             int fp;
             const bool o_old = kCarry && __shfl((int)old, owner) != 0;
-            uint32_t nk = wave_enumerate<kCarry>(A, o_old, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp);
+            uint32_t e_steps = 0, e_levels = 0;
+            uint32_t nk = wave_enumerate<kCarry>(A, o_old, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp,
+                                                 kStats ? &e_steps : nullptr, kStats ? &e_levels : nullptr);
+            if (kStats && lane == 0u) { n_erow += e_steps; n_elev += e_levels; }
             if ((int)lane == owner) {
                 k = nk;
                 if (o_up) pub = fp;
@@ -1562,6 +1602,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
         stat_flush<kStats>(A.stats + SC_DIR_SA, n_dsa); stat_flush<kStats>(A.stats + SC_DIR_GROUPS, n_dgrp);
         stat_flush<kStats>(A.stats + SC_DIR_RECS, n_drec); stat_flush<kStats>(A.stats + SC_DIR_LETTERS, n_dlet);
         stat_flush<kStats>(A.stats + SC_JUMP_LINES, n_jump);
+        stat_flush<kStats>(A.stats + SC_ENUM_ROW_STEPS, n_erow); stat_flush<kStats>(A.stats + SC_ENUM_LEVELS, n_elev);
         stat_flush<kStats>(A.stats + SC_SKIP_GROUPS, n_skv); stat_flush<kStats>(A.stats + SC_SKIP_QLOADS, n_skq);
         stat_flush<kStats>(A.stats + SC_SKIP_PROBES, n_skp); stat_flush<kStats>(A.stats + SC_SKIP_OK, n_skok);
         if ((threadIdx.x & 63u) == 0u) {
@@ -2572,6 +2613,7 @@ int SearchJob::collect() {
         o.dir_letters = c[SC_DIR_LETTERS]; o.jump_lines = c[SC_JUMP_LINES];
         o.skip_group_loads = c[SC_SKIP_GROUPS]; o.skip_probe_lines = c[SC_SKIP_PROBES]; o.skips = c[SC_SKIP_OK];
         o.skip_attempts = c[SC_SKIP_QLOADS];
+        o.enum_row_steps = c[SC_ENUM_ROW_STEPS]; o.enum_levels = c[SC_ENUM_LEVELS];
         // 100 MHz clock -> microseconds
         last_search_clock()[0] = (c[SC_T_DRAIN] - c[SC_T_FIRST]) / 100.0;
         last_search_clock()[1] = (c[SC_T_LAST] - c[SC_T_DRAIN]) / 100.0;

@@ -47,7 +47,8 @@ def run(model, idx, ref, lay, reads_n, min_len):
                       "overflow_share": st["overflow_records"] / max(1, total), "survivors": st["survivors"], "items": st["items"],
                       "lines_per_read": (st["fm_lines_top"] + st["fm_lines_bottom"] + st["rec_lines_fail"] + st["rec_lines_pend"]
                                          + st["dir_sa_lines"] + st["dir_group_loads"] + st["dir_rec_lines"] + st["jump_lines"]) / reads_n,
-                      "enum_jobs": st["enum_jobs"], "max_lcp": int(idx.info.max_lcp)}), flush=True)
+                      "enum_jobs": st["enum_jobs"], "enum_row_steps": st["enum_row_steps"], "enum_levels": st["enum_levels"],
+                      "wave_trips": st["wave_trips"], "lane_trips": st["lane_trips"], "max_lcp": int(idx.info.max_lcp)}), flush=True)
     del m
 
 
