@@ -48,7 +48,8 @@ def run(model, idx, ref, lay, reads_n, min_len):
                       "lines_per_read": (st["fm_lines_top"] + st["fm_lines_bottom"] + st["rec_lines_fail"] + st["rec_lines_pend"]
                                          + st["dir_sa_lines"] + st["dir_group_loads"] + st["dir_rec_lines"] + st["jump_lines"]) / reads_n,
                       "enum_jobs": st["enum_jobs"], "enum_row_steps": st["enum_row_steps"], "enum_levels": st["enum_levels"],
-                      "wave_trips": st["wave_trips"], "lane_trips": st["lane_trips"], "max_lcp": int(idx.info.max_lcp)}), flush=True)
+                      "wave_trips": st["wave_trips"], "lane_trips": st["lane_trips"],
+                      "k8_us_until_list_empty": st["k8_us_until_list_empty"], "k8_us_tail": st["k8_us_tail"], "k8_wave_us_sum": st["k8_wave_us_sum"], "max_lcp": int(idx.info.max_lcp)}), flush=True)
     del m
 
 
