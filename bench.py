@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FIXED_BYTES_PER_BASE = 155.0  # SURVEY.md 8(d) figure for these reads
 # the oracle port against the real reference on the same reads, measured in the build container by
-# tools/calibrate_port_vs_reference.py (its output is committed: profiles/r03_port_vs_reference.json); the port is the
+# tests/tools/calibrate_port_vs_reference.py (its output is committed: profiles/r03_port_vs_reference.json); the port is the
 # faster of the two, i.e. a conservative CPU baseline.  1.22 = round 1's measurement (30.0 k vs 24.5 k MEMs/s, one Xeon core).
 def _port_vs_reference_ratio() -> float:
     try:

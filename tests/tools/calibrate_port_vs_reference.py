@@ -7,9 +7,9 @@ compiled by oracle/Makefile from /root/reference).  Same reference text, same re
                      (load + index build), stdout to a file (keep stdout off pipes when timing)
 
 Writes profiles/r03_port_vs_reference.json; bench.py reads the ratio from there.
-    tools/calibrate_port_vs_reference.py [ref_len=100000000] [reads=200000]"""
+    tests/tools/calibrate_port_vs_reference.py [ref_len=100000000] [reads=200000]"""
 import json, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from slamem_amd import synth
