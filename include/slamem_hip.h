@@ -130,6 +130,7 @@ typedef struct {
     uint64_t skips;                 /* K8 skipping: stretches skipped (min_len positions each)                         */
     uint64_t enum_row_steps;        /* K8: wave steps of the enumeration jobs (64 rows tested for left-maximality each)  */
     uint64_t enum_levels;           /* K8: ancestor intervals the enumeration jobs walked up to (one record round trip each) */
+    uint64_t enum_wave_us;          /* K8: microseconds the waves spent inside enumeration jobs, summed over waves (compare k8 wave sum) */
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

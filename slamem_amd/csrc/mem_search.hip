@@ -858,7 +858,7 @@ enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
     SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
-    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_COUNT
+    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_T_ENUM_SUM, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -1062,6 +1062,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
     uint32_t n_kt = 0, n_kb = 0, n_rec_fail = 0, n_rec_pend = 0, n_rec_flush = 0, n_trips = 0, n_wtrips = 0, n_pos = 0,
              n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0, n_jump = 0, n_skv = 0, n_skq = 0,
              n_skp = 0, n_skok = 0, n_erow = 0, n_elev = 0;
+    unsigned long long t_enum = 0ull;  // diagnostic instantiation: wall clock this wave spent in enumeration jobs
 
     bool active = false, pend = false, dmis = false, dcool = false;
     bool old = false;  // kCarry: the lane came in from the previous launch and writes to that batch's output side
@@ -1566,6 +1567,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
         }
 
         // ---- enumeration jobs, one strand at a time, all 64 lanes on its rows (every lane reaches this point) ----
+        const unsigned long long t_en0 = (kStats && __ballot(e_on) != 0ull) ? wall_clock64() : 0ull;
         for (unsigned long long em = __ballot(e_on); em != 0ull; em &= em - 1ull) {
             int owner = __ffsll((long long)em) - 1;
             uint32_t o_g = __shfl(g, owner), o_k = __shfl(k, owner), o_t = __shfl(top, owner), o_b = __shfl(bot, owner);
@@ -1585,6 +1587,8 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
                 pend = false;  // the next trip extends from the same interval with the same letter
             }
         }
+
+        if (kStats && t_en0 != 0ull && lane == 0u) t_enum += wall_clock64() - t_en0;
 
         if (active && finished) {
             (kCarry && old ? A.prev.block_counts : A.block_counts)[g] = k;
@@ -1609,6 +1613,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
             const unsigned long long t1 = wall_clock64();
             atomicMax(A.stats + SC_T_LAST, t1);
             atomicAdd(A.stats + SC_T_WAVE_SUM, t1 - t_wave0);
+            atomicAdd(A.stats + SC_T_ENUM_SUM, t_enum);
         }
     }
 }
@@ -2618,6 +2623,7 @@ int SearchJob::collect() {
         last_search_clock()[0] = (c[SC_T_DRAIN] - c[SC_T_FIRST]) / 100.0;
         last_search_clock()[1] = (c[SC_T_LAST] - c[SC_T_DRAIN]) / 100.0;
         last_search_clock()[2] = c[SC_T_WAVE_SUM] / 100.0;
+        o.enum_wave_us = c[SC_T_ENUM_SUM] / 100;
         o.prefilter_probes = c[SC_PF_PROBES]; o.prefilter_query_loads = c[SC_PF_QUERY_LOADS]; o.prefilter_items = c[SC_PF_ITEMS];
         o.items = nitems;
         o.survivors = prefiltered ? nwork : nitems;

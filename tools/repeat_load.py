@@ -49,7 +49,7 @@ def run(model, idx, ref, lay, reads_n, min_len):
                                          + st["dir_sa_lines"] + st["dir_group_loads"] + st["dir_rec_lines"] + st["jump_lines"]) / reads_n,
                       "enum_jobs": st["enum_jobs"], "enum_row_steps": st["enum_row_steps"], "enum_levels": st["enum_levels"],
                       "wave_trips": st["wave_trips"], "lane_trips": st["lane_trips"],
-                      "k8_us_until_list_empty": st["k8_us_until_list_empty"], "k8_us_tail": st["k8_us_tail"], "k8_wave_us_sum": st["k8_wave_us_sum"], "max_lcp": int(idx.info.max_lcp)}), flush=True)
+                      "k8_us_until_list_empty": st["k8_us_until_list_empty"], "k8_us_tail": st["k8_us_tail"], "k8_wave_us_sum": st["k8_wave_us_sum"], "enum_wave_us_sum": st["enum_wave_us"], "max_lcp": int(idx.info.max_lcp)}), flush=True)
     del m
 
 
