@@ -254,7 +254,8 @@ def test_config4_chr1_sized_known_answer(eng):
 def test_config5_grch38_sized_full_size_properties(eng):
     """configs[4] (GRCh38 stand-in, > 2^31 BWT rows): 3.1 Gbp text with the repeat model, one GPU's share of the
     100 M reads (12.5 M x 150 bp), -b -l 20 (-n strips non-ACGT letters on the host, sequence.c:61-81: a no-op on this
-    ACGT text, exercised on small inputs by the golden `normalise_*` cases).  No CPU oracle fits this size, so:
+    ACGT text, exercised on small inputs by the golden `normalise_*` cases).  The first 100,000 reads are pinned by the REAL
+    reference (round 3); for the rest no CPU run fits, so:
     the suffix array is a permutation (sum and sum of squares over ALL rows, on the device), neighbouring sampled rows
     are in suffix order, every sampled MEM is real and two-sided maximal, and the digest of the engine's deterministic
     output is pinned (config5_share_engine) so that regressions show."""
@@ -288,6 +289,15 @@ def test_config5_grch38_sized_full_size_properties(eng):
     bad, checked = check_sampled_mems(rows, ref_h, reads_h, L, min_len, 30_000)
     assert bad == 0 and checked == 30_000
     assert int(rows[:, 1].max()) > (1 << 31)  # matches beyond text position 2^31 are found
+    # the REAL reference on this text (6,842 s and ~30 GB in the build container; known_answers.json: config5_first100k): the
+    # first 100,000 reads, both strands -- 298,187 MEMs, 91,832 of them beyond text position 2^31, every line checked against
+    # the texts when it was recorded
+    from mems_digest import digest_rows
+    ref100k = KNOWN["config5_first100k"]
+    assert ref100k["reference_completed"] and ref100k["reference_valid"]
+    first = rows[rows[:, 0] < 200_000]
+    assert digest_rows(first) == {k: ref100k[k] for k in DIGEST_KEYS}
+    assert int((first[:, 1].astype(np.int64) > (1 << 31)).sum()) == ref100k["rows_beyond_2p31"]
     # completeness beyond 2^31 rows: the definitional MEM set (every maximal match >= l, from the text and the reads alone,
     # no index) of 2,600 sampled reads -- 1,500 random, 600 drawn from beyond position 2^31, 500 from planted repeats --
     # equals the engine's output for those reads as a set
