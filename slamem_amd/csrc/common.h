@@ -97,8 +97,10 @@ struct ArenaHeader {
     uint32_t kfilter_levels;  // 3 (or 0): (k-2)-, k- and (k+2)-mers; 2: no (k+2)-mers (texts above 2^31 letters)
     uint64_t off_kbits;   // uint64[4^kbits_k / 64]  one bit per k-mer over A,C,G,T: does it occur in the text?
     uint32_t layout;      // 1 = full, 2 = compact (no text-ordered sections, half-size presence filter); 0 in arenas of older builds = full
-    uint32_t reserved[10];
+    uint32_t lcp_ge[10];  // rows whose LCP is >= kLcpGe[i]: how repeat-rich the text is at a given minimum length (all 0 in arenas of older builds: unknown)
 };
+// thresholds of ArenaHeader::lcp_ge
+__host__ __device__ constexpr uint32_t kLcpGe[10] = {18, 20, 25, 30, 40, 50, 75, 100, 150, 255};
 static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 
 // What the kernels see (passed by value).

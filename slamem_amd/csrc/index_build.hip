@@ -629,17 +629,30 @@ __global__ void __launch_bounds__(256) k_text_groups(const uint64_t* __restrict_
 }
 
 // the 16-byte row records: record i describes the boundaries of row i: {LCP[i]+1, PSV[i], LCP[i+1]+1, NSV[i+1]}
+// (and, beside the records: how many rows have an LCP of at least kLcpGe[i] -- what tells a launch of the search how repeat-rich
+//  the text is at its minimum length, IndexView::lcp_ge / ArenaHeader::lcp_ge)
 __global__ void __launch_bounds__(256) k_pack_records(const uint32_t* __restrict__ l32, const uint32_t* __restrict__ psv,
                                                       const uint32_t* __restrict__ nsv, uint32_t rows,
-                                                      RowRec* __restrict__ rec) {
+                                                      RowRec* __restrict__ rec, uint32_t* __restrict__ lcp_ge) {
+    __shared__ uint32_t sh[10];
+    if (threadIdx.x < 10) sh[threadIdx.x] = 0;
+    __syncthreads();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > rows) return;
-    RowRec r;
-    r.lcp1 = l32[i];
-    r.psv = psv[i];
-    r.lcp1n = i < rows ? l32[i + 1] : 0u;
-    r.nsvn = i < rows ? nsv[i + 1] : rows;
-    rec[i] = r;
+    if (i <= rows) {
+        RowRec r;
+        r.lcp1 = l32[i];
+        r.psv = psv[i];
+        r.lcp1n = i < rows ? l32[i + 1] : 0u;
+        r.nsvn = i < rows ? nsv[i + 1] : rows;
+        rec[i] = r;
+        if (r.lcp1 > kLcpGe[0]) {  // LCP >= 18: rare on a text without repeats (chance matches end near log4 n)
+#pragma unroll
+            for (int b = 0; b < 10; b++)
+                if (r.lcp1 > kLcpGe[b]) atomicAdd(&sh[b], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 10 && sh[threadIdx.x]) atomicAdd(&lcp_ge[threadIdx.x], sh[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1279,7 +1292,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         hipLaunchKernelGGL(k_links, dim3(grid_for(n)), dim3(256), 0, stream, L, rows, d_psv, d_nsv);
         SLAMEM_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_pack_records, dim3(grid_for(R + 1)), dim3(256), 0, stream, d_l32, d_psv, d_nsv, rows, d_rec);
+    hipLaunchKernelGGL(k_pack_records, dim3(grid_for(R + 1)), dim3(256), 0, stream, d_l32, d_psv, d_nsv, rows, d_rec, d_scal + 16);
     SLAMEM_HIP(hipGetLastError());
     if (hdr.off_tgrp) {  // text-ordered sections, last: their regions were lent to the sort, the records are complete now
         uint8_t* d_cls = flagB.as<uint8_t>();  // one byte per text position (scratch of the sort rounds, dead since K2)
@@ -1295,6 +1308,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     SLAMEM_HIP(hipEventElapsedTime(&tm.t.build_links_ms, ev.a, ev.b));
     hdr.dollar_row = h_scal[8];
     hdr.max_lcp = h_scal[9];
+    for (int b = 0; b < 10; b++) hdr.lcp_ge[b] = h_scal[16 + b];
     mark("K5 LCP + K7 links + records");
 
     SLAMEM_HIP(hipMemcpyAsync(base, &hdr, sizeof(hdr), hipMemcpyHostToDevice, stream));

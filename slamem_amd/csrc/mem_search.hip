@@ -775,12 +775,19 @@ __device__ __forceinline__ void emit3_sel(const SearchArgs& A, bool old, uint32_
 
 // The rows a wave reports in ONE step of an enumeration job: lane `lane` reports (row, pos, len) as MEM number
 // k + (reporting lanes below it) of strand block g when `ok`.  The first kInlineMems of a strand go to its inline slots; all
-// the others of the step take their places in the overflow list with ONE atomic for the wave (the per-lane form,
-// emit3_at, is 64 atomics on one address per step: on a text with a 10^5-copy repeat family that counter was the whole
-// kernel -- 0.43 G MEMs/s, 84 ms per million reads at -l 50; profiles/r03_repeat_load.jsonl).
-template <bool kCarry>
+// the others of the step take their places in the overflow list with ONE atomic for the wave.
+// kChunk: the instantiation for repeat-rich texts.  The list's counter is ONE word that 4096 waves hit; an atomic per
+// emitting step runs at ~150 M/s there and WAS the kernel on such texts (a 10^5-copy family at -l 50: 12.6 M steps, 83 ms per
+// million reads; -l 20: 479 ms per 100,000 reads; profiles/r03_repeat_load.jsonl).  Here a wave reserves kOvfChunk places at
+// a time and hands them out by itself (ovf_base / ovf_left, wave-uniform, kept in LDS between jobs); places that stay unused
+// keep the mark the whole list is filled with before the launch (block 0xFFFFFFFF), K9 skips them.  It is a separate
+// instantiation because the headline kernel's register allocation does not survive the extra code (+2.4 ms of 20.9).
+constexpr uint32_t kOvfChunk = 128;
+constexpr uint32_t kOvfHole = 0xFFFFFFFFu;
+template <bool kCarry, bool kChunk>
 __device__ __forceinline__ uint32_t wave_emit_step(const SearchArgs& A, bool old, uint32_t lane, uint32_t g, uint32_t k, uint32_t tag,
-                                                   bool ok, uint32_t row, uint32_t pos, uint32_t len) {
+                                                   bool ok, uint32_t row, uint32_t pos, uint32_t len,
+                                                   unsigned long long& ovf_base, uint32_t& ovf_left) {
     const unsigned long long m = __ballot(ok);
     if (m == 0ull) return k;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -795,12 +802,29 @@ __device__ __forceinline__ uint32_t wave_emit_step(const SearchArgs& A, bool old
         unsigned long long* tot = (kCarry && old) ? A.prev.total : A.total;
         const uint64_t cap = (kCarry && old) ? A.prev.capacity : A.capacity;
         const int leader = __ffsll((long long)mo) - 1;
-        unsigned long long base = 0ull;
-        if ((int)lane == leader) base = atomicAdd(tot, (unsigned long long)__popcll(mo));
-        const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader), bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader);
+        unsigned long long first;  // place of the step's first record
+        if (kChunk && !(kCarry && old)) {
+            const uint32_t need = (uint32_t)__popcll(mo);
+            if (ovf_left < need) {  // (wave-uniform) a new chunk; what is left of the old one stays marked as unused
+                const uint32_t chunk = need > kOvfChunk ? need : kOvfChunk;
+                unsigned long long base = 0ull;
+                if ((int)lane == leader) base = atomicAdd(tot, (unsigned long long)chunk);
+                // (readlane, not a shuffle: the result is wave-uniform and the compiler knows it)
+                ovf_base = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader),
+                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader));
+                ovf_left = chunk;
+            }
+            first = ovf_base;
+            ovf_base += need;
+            ovf_left -= need;
+        } else {
+            unsigned long long base = 0ull;
+            if ((int)lane == leader) base = atomicAdd(tot, (unsigned long long)__popcll(mo));
+            first = u64_of((uint32_t)__shfl((int)(uint32_t)base, leader), (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader));
+        }
         if (ok && !inl) {
             if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(tot) + 9, 1u);  // the ordinal would run into the tag: reported as an error
-            const unsigned long long slot = u64_of(blo, bhi) + (unsigned long long)__popcll(mo & below);
+            const unsigned long long slot = first + (unsigned long long)__popcll(mo & below);
             if (slot < cap) {
                 ((kCarry && old) ? A.prev.raw_key : A.raw_key)[slot] = RawKey{g, kk | tag};
                 ((kCarry && old) ? A.prev.raw_mem : A.raw_mem)[slot] = slamem_mem{row, pos, len};  // ref_pos holds the ROW until K9
@@ -817,10 +841,11 @@ __device__ __forceinline__ uint32_t wave_emit_step(const SearchArgs& A, bool old
 // strand's emission order is exactly the reference's.  This is what makes repeats (intervals of thousands of
 // rows) cost rows/64 steps instead of rows.  Returns the strand's new MEM count; *first_parent = depth of the
 // parent of [t,b] (the exact value of `pub`).
-template <bool kCarry>
+template <bool kCarry, bool kChunk>
 __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, bool old, uint32_t lane, uint32_t g, uint32_t k,
                                                    uint32_t tag, uint32_t t, uint32_t b, int msz, bool level0, bool walk_up,
                                                    uint32_t pos, uint32_t left, int L, int* first_parent,
+                                                   unsigned long long& ovf_base, uint32_t& ovf_left,
                                                    uint32_t* row_steps = nullptr, uint32_t* levels = nullptr) {
     const IndexView& ix = A.ix;
     uint32_t pt = level0 ? b + 1u : t, pb = b;  // rows already reported: [pt, pb]
@@ -830,14 +855,14 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, bool old
         for (uint32_t base = t; base < pt; base += 64u) {  // new rows above, ascending (slamem.c:140)
             uint32_t row = base + lane;
             bool ok = row < pt && bwt_code(ix, row) != left;
-            k = wave_emit_step<kCarry>(A, old, lane, g, k, tag, ok, row, pos, (uint32_t)msz);
+            k = wave_emit_step<kCarry, kChunk>(A, old, lane, g, k, tag, ok, row, pos, (uint32_t)msz, ovf_base, ovf_left);
             if (row_steps) (*row_steps)++;
         }
         for (uint32_t done = 0; done < b - pb; done += 64u) {  // new rows below, bottom-up (slamem.c:165)
             uint32_t off = done + lane;
             uint32_t row = b - off;
             bool ok = off < b - pb && bwt_code(ix, row) != left;
-            k = wave_emit_step<kCarry>(A, old, lane, g, k, tag, ok, row, pos, (uint32_t)msz);
+            k = wave_emit_step<kCarry, kChunk>(A, old, lane, g, k, tag, ok, row, pos, (uint32_t)msz, ovf_base, ovf_left);
             if (row_steps) (*row_steps)++;
         }
         if (!walk_up) break;
@@ -1023,8 +1048,8 @@ enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, 
 // exact, 27 % fewer lines and 32 % fewer lane trips, but the same time -- the kernel is bound by instruction issue and
 // every trip pays for the union of the states its lanes are in -- so the default kernel is the one without them
 // (SLAMEM_SKIP=1 selects this one).
-template <bool kStats, bool kSkip, bool kSliced, bool kMam, bool kCarry>
-__global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
+template <bool kStats, bool kSkip, bool kSliced, bool kMam, bool kCarry, bool kChunk = false>
+__global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
     __shared__ ItemDesc lds_item[4][kFetch];
     __shared__ uint64_t lds_pk[4][kFetch];
     __shared__ uint32_t lds_id[4][kFetch];
@@ -1079,6 +1104,12 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
     Blk kt;
     kt.a = kt.b = kt.c = kt.d = make_uint4(0, 0, 0, 0);
     uint32_t tag_t = 0xFFFFFFFFu;
+    // kChunk: the chunk of the overflow list this wave hands out (wave_emit_step), in LDS between the enumeration jobs.  Every
+    // lane stores the same wave-uniform value: a store by lane 0 alone would be invisible to the compiler's per-thread view of
+    // the other lanes, which could keep a stale copy
+    __shared__ unsigned long long lds_ovf_base[kChunk ? 4 : 1];
+    __shared__ uint32_t lds_ovf_left[kChunk ? 4 : 1];
+    if (kChunk) { lds_ovf_base[wv] = 0ull; lds_ovf_left[wv] = 0u; }
 
     if (kCarry && A.carry_in) {  // the unfinished lanes of the previous launch first (the grid always covers them)
         const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1570,16 +1601,23 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry) ? 4 : SLAMEM_V3
         const unsigned long long t_en0 = (kStats && __ballot(e_on) != 0ull) ? wall_clock64() : 0ull;
         for (unsigned long long em = __ballot(e_on); em != 0ull; em &= em - 1ull) {
             int owner = __ffsll((long long)em) - 1;
-            uint32_t o_g = __shfl(g, owner), o_k = __shfl(k, owner), o_t = __shfl(top, owner), o_b = __shfl(bot, owner);
-            uint32_t o_tag = __shfl(attempt, owner) << 28;
-            int o_depth = __shfl(depth, owner);
-            uint32_t o_pos = __shfl(e_pos, owner), o_left = __shfl(e_left, owner);
-            bool o_l0 = __shfl((int)e_level0, owner) != 0, o_up = __shfl((int)e_up, owner) != 0;
+            // (kChunk: readlane instead of a shuffle -- the job's parameters are wave-uniform and the compiler knows it, so the loops
+            //  of wave_enumerate and the chunk state stay in scalar registers)
+#define SLAMEM_OWN(x) (kChunk ? (uint32_t)__builtin_amdgcn_readlane((int)(x), owner) : (uint32_t)__shfl((int)(x), owner))
+            uint32_t o_g = SLAMEM_OWN(g), o_k = SLAMEM_OWN(k), o_t = SLAMEM_OWN(top), o_b = SLAMEM_OWN(bot);
+            uint32_t o_tag = SLAMEM_OWN(attempt) << 28;
+            int o_depth = (int)SLAMEM_OWN(depth);
+            uint32_t o_pos = SLAMEM_OWN(e_pos), o_left = SLAMEM_OWN(e_left);
+            bool o_l0 = SLAMEM_OWN(e_level0 ? 1 : 0) != 0u, o_up = SLAMEM_OWN(e_up ? 1 : 0) != 0u;
             int fp;
-            const bool o_old = kCarry && __shfl((int)old, owner) != 0;
+            const bool o_old = kCarry && SLAMEM_OWN(old ? 1 : 0) != 0u;
+#undef SLAMEM_OWN
             uint32_t e_steps = 0, e_levels = 0;
-            uint32_t nk = wave_enumerate<kCarry>(A, o_old, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp,
-                                                 kStats ? &e_steps : nullptr, kStats ? &e_levels : nullptr);
+            unsigned long long ovf_base = kChunk ? lds_ovf_base[wv] : 0ull;
+            uint32_t ovf_left = kChunk ? lds_ovf_left[wv] : 0u;
+            uint32_t nk = wave_enumerate<kCarry, kChunk>(A, o_old, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp,
+                                                         ovf_base, ovf_left, kStats ? &e_steps : nullptr, kStats ? &e_levels : nullptr);
+            if (kChunk) { lds_ovf_base[wv] = ovf_base; lds_ovf_left[wv] = ovf_left; }
             if (kStats && lane == 0u) { n_erow += e_steps; n_elev += e_levels; }
             if ((int)lane == owner) {
                 k = nk;
@@ -1991,6 +2029,7 @@ __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         RawKey kk = key[i];
+        if (kk.block == 0xFFFFFFFFu) continue;                  // a place some wave reserved and did not use (kChunk)
         if ((kk.k >> 28) != item_attempt[kk.block]) continue;  // written by an attempt that was abandoned
         slamem_mem m = raw[i];
         uint64_t pos = item_off[kk.block] + (kk.k & 0x0FFFFFFFu);
@@ -2199,12 +2238,14 @@ struct SearchJob {
     // must have been launched with carry_out); carry_out: end when the work list is empty and pass the unfinished lanes on
     // (the NEXT launch, or flush(), finishes them -- only then may place() of this job follow)
     int search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_out);
+    bool enum_chunks() const;                        // the text is repeat-rich at this minimum length: K8's kChunk instantiation
     bool can_carry() const;                          // this batch runs on an instantiation that can pass lanes on / take them in
     bool can_carry_into(const SearchJob& next) const;  // ... and `next` can take them
     int flush(hipStream_t stream);                   // a launch without new work that finishes the lanes this job passed on
     int place(hipStream_t stream);                   // K9 + the batch's scalars to the host
     int collect();
     bool carried_out = false;
+    bool chunked = false;  // this launch ran the kChunk instantiation (its overflow list has unused places)
 };
 
 // One batch through the search, in steps that a caller may issue apart and on different streams (slamem_stream_* does: the
@@ -2408,6 +2449,17 @@ int SearchJob::prep(hipStream_t stream) {
     return SLAMEM_OK;
 }
 
+// More than 1/32 of the BWT rows share at least min_len letters with a neighbour in suffix order (ArenaHeader::lcp_ge, counted
+// at build time): intervals of several rows >= min_len deep -- enumeration jobs -- are then a large part of the work.  SURVEY's
+// repeat model (0.5 % of the text in copies) stays below (1 %), a 10^5-copy family lies above (10 %).  SLAMEM_ENUM_CHUNKS=0/1
+// decides instead.
+bool SearchJob::enum_chunks() const {
+    static const int env = [] { const char* v = getenv("SLAMEM_ENUM_CHUNKS"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
+    if (env >= 0) return env == 1;
+    int b = 0;
+    while (b < 9 && kLcpGe[b + 1] <= min_len) b++;
+    return (uint64_t)idx->hdr.lcp_ge[b] * 32ull > (uint64_t)idx->hdr.n;
+}
 bool SearchJob::can_carry() const {
     return nitems != 0 && (match_type != 1 || mam_v3) && nitems == num_blocks && !A.skip_w && !want_stats;
 }
@@ -2447,6 +2499,7 @@ int SearchJob::search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_o
     unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
     launched = true;
     carried_out = false;
+    chunked = false;
     if (carry_from && !(carry_from->carried_out && carry_from->can_carry_into(*this))) {
         set_error("internal: K8 asked to take in the lanes of a launch that cannot pass them on");
         return SLAMEM_ERR_ARG;
@@ -2476,6 +2529,14 @@ int SearchJob::search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_o
             else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, true>), grid8, dim3(256), 0, stream, A);
             carried_out = carry_out;
             if (carry_from) carry_from->carried_out = false;  // its lanes are taken care of by this launch
+        } else if (!A.skip_w && !want_stats && enum_chunks()) {
+            chunked = true;
+            // a repeat-rich text at this minimum length: the instantiation whose enumeration jobs take their places in the
+            // overflow list chunk-wise (wave_emit_step); every place of the list starts as "unused"
+            if (mems_capacity) STEP(hipMemsetAsync(ws + w.off_rawkey, 0xFF, mems_capacity * sizeof(RawKey), stream), "memset");
+            if (sliced) hipLaunchKernelGGL((k_find_mems_v3<false, false, true, false, false, true>), grid8, dim3(256), 0, stream, A);
+            else if (mam_v3) hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true, false, true>), grid8, dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, false, true>), grid8, dim3(256), 0, stream, A);
         } else if (A.skip_w) {  // (the skipping variant: one instantiation, with the slice logic)
             if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, true, false, false>), grid8, dim3(256), 0, stream, A);
             else hipLaunchKernelGGL((k_find_mems_v3<false, true, true, false, false>), grid8, dim3(256), 0, stream, A);
@@ -2651,6 +2712,9 @@ int SearchJob::collect() {
     if (total > mems_capacity || listed > mems_capacity) {
         // the atomic list also holds the records of abandoned slice attempts: ask for room for those too
         if (listed > total) total = listed;
+        // (kChunk: the waves reserve places in chunks and may leave some unused; WHICH waves do depends on the run, the bound
+        //  covers every run, so that a caller who asks again with this much room succeeds)
+        if (chunked) total += kK8Waves * kOvfChunk;
         set_error("slamem_find_mems_device: %llu MEMs found, output capacity is %llu", (unsigned long long)total,
                   (unsigned long long)mems_capacity);
         return SLAMEM_ERR_CAPACITY;

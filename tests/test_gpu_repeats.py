@@ -1,6 +1,7 @@
 """Repeat-heavy inputs: intervals of thousands of rows at depth >= l (the case the wave-cooperative enumeration
 of k_find_mems_v3 exists for).  Checked in order against the oracle; also exercises the overflow list
 (more than kInlineMems MEMs per strand) and ancestor intervals that still qualify."""
+import os
 import time
 
 import numpy as np
@@ -126,3 +127,59 @@ def test_reference_with_long_diverged_repeats_builds_exactly():
     print("build timings", {k: round(v, 1) for k, v in engine.timings().items() if k.startswith("build_")},
           "rounds", int(g.info.sort_rounds))
     g.close()
+
+
+@pytest.mark.parametrize("chunks", ["0", "1"])
+def test_enumeration_in_chunks_equals_oracle(chunks):
+    """K8's kChunk instantiation (enumeration jobs take their places in the overflow list chunk-wise: chosen by itself on
+    repeat-rich texts, ArenaHeader::lcp_ge; forced here both ways with SLAMEM_ENUM_CHUNKS in a child process) must give the
+    oracle's MEMs in the oracle's order on a text that is mostly one repeat family (thousands of MEMs per strand, nearly all
+    through the overflow list), -mem and -mam, reads and a long record in slices, with the capacity retry on the way."""
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
+    child = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from oracle import pyoracle as po
+from slamem_amd import engine
+rng = np.random.default_rng(99)
+unit = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=300)
+n = 400_000
+text = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+for c in range(700):  # 700 copies of a 300 bp family, 3-12 % diverged, over half of the text
+    cp = unit.copy()
+    mut = rng.random(300) < rng.uniform(0.03, 0.12)
+    cp[mut] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(mut.sum()))
+    at = int(rng.integers(0, n - 300))
+    text[at:at + 300] = cp
+qs = []
+for i in range(1500):
+    L = int(rng.integers(40, 260))
+    a = int(rng.integers(0, n - L))
+    q = text[a:a + L].copy()
+    mut = rng.random(L) < 0.02
+    q[mut] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(mut.sum()))
+    qs.append(q)
+qs.append(text[100_000:112_000].copy())  # a record cut into slices
+off = np.zeros(len(qs) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(x) for x in qs])
+q = np.concatenate(qs)
+o = po.OracleIndex(text.tobytes())
+g = engine.Index.build(text)
+for mam in (False, True):
+    for l in (12, 25):
+        om, obc = o.match_batch(q, off, l, True, mam=mam)
+        gm, goff = g.find_mems(q, off, l, True, mam=mam)
+        assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64)), (mam, l)
+        for f in ("ref_pos", "query_pos", "length"):
+            assert np.array_equal(gm[f], om[f]), (mam, l, f)
+        print(mam, l, len(om), int(obc.max()))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", child, root], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, SLAMEM_ENUM_CHUNKS=chunks), timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = r.stdout.decode().split("\n")
+    assert int(lines[0].split()[2]) > 200_000  # the case is enumeration-heavy
