@@ -489,6 +489,8 @@ def synth_plant_genome_like(ref: torch.Tensor, seed: int = 42, n_block: bool = T
 def synth_reads(ref: torch.Tensor, first: int, count: int, length: int = 150, sub: float = 0.02, seed: int = 42,
                 rc_percent: int = 0, avoid: tuple = (0, 0)) -> torch.Tensor:
     """avoid = (at, len): reads that would touch text[at, at+len) are drawn behind it (slamem_amd.synth.make_reads)."""
+    if count * length >= 1 << 32:
+        raise ValueError("synth_reads: one thread per letter, fewer than 2^32 letters per call (make the reads in pieces)")
     dev = ref.device
     out = torch.zeros(count * length + 16, dtype=torch.uint8, device=dev)
     rc = capi.synth_lib().slamem_synth_reads_avoid(_ptr(ref), ref.numel(), _ptr(out), first, count, length, float(sub), seed,
