@@ -2485,7 +2485,8 @@ int SearchJob::flush(hipStream_t stream) {
     F.carry_out = nullptr; F.carry_out_count = nullptr;
     fill_prev_ctx(F, *this);
     // (the cursor word of this job's scalar block has run past the end of its list: the empty list is drained at once)
-    const dim3 grid8(grid_for(kK8Waves * 64));
+    static const uint64_t env_waves = [] { const char* v = getenv("SLAMEM_K8_WAVES"); return v ? (uint64_t)atoll(v) : 0ull; }();
+    const dim3 grid8(grid_for((env_waves ? env_waves : kK8Waves) * 64));
     if (mam_v3) hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true, true>), grid8, dim3(256), 0, stream, F);
     else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, true>), grid8, dim3(256), 0, stream, F);
     STEP(hipGetLastError(), "k_find_mems_v3 (flush)");
@@ -2512,8 +2513,8 @@ int SearchJob::search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_o
         const uint64_t cap_waves = env_waves ? env_waves : kK8Waves;
         if (waves > cap_waves) waves = cap_waves;
         const bool carry = carry_from != nullptr || carry_out;
-        if (carry) {  // the grid covers every lane that may come in, whatever the size of this batch
-            waves = kK8Waves;
+        if (carry) {  // the grid covers every lane that may come in, whatever the size of this batch (every launch of a stream: the same)
+            waves = cap_waves;
             A.carry_in = nullptr; A.carry_in_count = nullptr;
             if (carry_from) fill_prev_ctx(A, *carry_from);
             A.carry_out = carry_out ? reinterpret_cast<CarryRec*>(ws + w.off_carry) : nullptr;
