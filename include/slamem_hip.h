@@ -131,6 +131,10 @@ typedef struct {
     uint64_t enum_row_steps;        /* K8: wave steps of the enumeration jobs (64 rows tested for left-maximality each)  */
     uint64_t enum_levels;           /* K8: ancestor intervals the enumeration jobs walked up to (one record round trip each) */
     uint64_t enum_wave_us;          /* K8: microseconds the waves spent inside enumeration jobs, summed over waves (compare k8 wave sum) */
+    /* K8: loop trips per state of the lane's state machine (EXT, REC, FLUSH, DSA, DIR, DEND, JQ, JT, SKV, SKQ, SKP): summed
+     * over lanes, and the number of WAVE trips in which at least one lane was in the state (what the wave pays for) */
+    uint64_t state_lane_trips[11];
+    uint64_t state_wave_trips[11];
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

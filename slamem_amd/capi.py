@@ -84,10 +84,11 @@ class SearchStats(C.Structure):
         "lane_trips", "wave_trips", "positions", "enum_jobs", "prefilter_probes", "prefilter_query_loads",
         "prefilter_items", "items", "survivors", "mems", "overflow_records", "valid", "dir_sa_lines", "dir_group_loads",
         "dir_rec_lines", "dir_letters", "jump_lines", "skip_group_loads", "skip_probe_lines", "skip_attempts", "skips",
-        "enum_row_steps", "enum_levels", "enum_wave_us")]
+        "enum_row_steps", "enum_levels", "enum_wave_us")] + [("state_lane_trips", C.c_uint64 * 11),
+                                                               ("state_wave_trips", C.c_uint64 * 11)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k.startswith("state_") else int(getattr(self, k))) for k, _ in self._fields_}
 
 
 _LIB = None

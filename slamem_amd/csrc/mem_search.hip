@@ -883,7 +883,7 @@ enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
     SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
-    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_T_ENUM_SUM, SC_COUNT
+    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_T_ENUM_SUM, SC_STATE_TRIPS /* 11 words: lane trips per state */, SC_STATE_WAVES = SC_STATE_TRIPS + 11 /* 11 words: wave trips in which some lane is in the state */, SC_COUNT = SC_STATE_WAVES + 11
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -1088,6 +1088,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
              n_enum = 0, n_qloads = 0, n_dsa = 0, n_dgrp = 0, n_drec = 0, n_dlet = 0, n_jump = 0, n_skv = 0, n_skq = 0,
              n_skp = 0, n_skok = 0, n_erow = 0, n_elev = 0;
     unsigned long long t_enum = 0ull;  // diagnostic instantiation: wall clock this wave spent in enumeration jobs
+    uint32_t n_state[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, n_wstate[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lane / wave trips per state
 
     bool active = false, pend = false, dmis = false, dcool = false;
     bool old = false;  // kCarry: the lane came in from the previous launch and writes to that batch's output side
@@ -1218,7 +1219,12 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
             if (drained && next >= chunk_end) break;
             continue;
         }
-        if (kStats) n_wtrips += lane == 0u;
+        if (kStats) {
+            n_wtrips += lane == 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < 11u; q++)
+                if (__ballot(active && st == q) != 0ull && lane == 0u) n_wstate[q]++;
+        }
         // enumeration job of this trip (rare): rows that the lane does not emit itself
         bool e_on = false, e_level0 = false, e_up = false;
         uint32_t e_pos = 0, e_left = 0;
@@ -1283,6 +1289,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
             }
             if (kStats) {
                 n_trips++;
+                if (st < 11u) n_state[st]++;
                 if (st == ST_REC) n_rec_fail += 1u + ((top >> 2) != (bot >> 2));
                 if (st == ST_FLUSH) n_rec_flush += 1u + ((top >> 2) != (bot >> 2));
             }
@@ -1645,6 +1652,11 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
         stat_flush<kStats>(A.stats + SC_DIR_RECS, n_drec); stat_flush<kStats>(A.stats + SC_DIR_LETTERS, n_dlet);
         stat_flush<kStats>(A.stats + SC_JUMP_LINES, n_jump);
         stat_flush<kStats>(A.stats + SC_ENUM_ROW_STEPS, n_erow); stat_flush<kStats>(A.stats + SC_ENUM_LEVELS, n_elev);
+#pragma unroll
+        for (uint32_t q = 0; q < 11u; q++) {
+            stat_flush<kStats>(A.stats + SC_STATE_TRIPS + q, n_state[q]);
+            stat_flush<kStats>(A.stats + SC_STATE_WAVES + q, n_wstate[q]);
+        }
         stat_flush<kStats>(A.stats + SC_SKIP_GROUPS, n_skv); stat_flush<kStats>(A.stats + SC_SKIP_QLOADS, n_skq);
         stat_flush<kStats>(A.stats + SC_SKIP_PROBES, n_skp); stat_flush<kStats>(A.stats + SC_SKIP_OK, n_skok);
         if ((threadIdx.x & 63u) == 0u) {
@@ -2686,6 +2698,7 @@ int SearchJob::collect() {
         last_search_clock()[1] = (c[SC_T_LAST] - c[SC_T_DRAIN]) / 100.0;
         last_search_clock()[2] = c[SC_T_WAVE_SUM] / 100.0;
         o.enum_wave_us = c[SC_T_ENUM_SUM] / 100;
+        for (int q = 0; q < 11; q++) { o.state_lane_trips[q] = c[SC_STATE_TRIPS + q]; o.state_wave_trips[q] = c[SC_STATE_WAVES + q]; }
         o.prefilter_probes = c[SC_PF_PROBES]; o.prefilter_query_loads = c[SC_PF_QUERY_LOADS]; o.prefilter_items = c[SC_PF_ITEMS];
         o.items = nitems;
         o.survivors = prefiltered ? nwork : nitems;
