@@ -129,3 +129,27 @@ def test_header_validation_rejects_corrupt_arenas(tmp_path):
     assert L.slamem_index_load(str(p).encode(), 0, C.byref(h)) == ERR_FORMAT and not h.value
     p.write_bytes(good)  # header fine, file far shorter than total_bytes
     assert L.slamem_index_load(str(p).encode(), 0, C.byref(h)) == ERR_FORMAT and not h.value
+
+
+def test_index_build_bytes_is_host_arithmetic():
+    """slamem_index_build_bytes (what a front end compares with slamem_device_mem_info before it builds): no GPU needed; the
+    sizes are the ones measured on the MI355X (profiles/r03_compact_layout.jsonl: 6.03 / 3.26 GB at 100 Mbp, 150.7 / 80.9 GB
+    at 3.1 Gbp), the compact layout is smaller, the peak is above the arena, bad arguments are refused."""
+    from slamem_amd import capi
+    L = capi.lib()
+    a, p = C.c_uint64(), C.c_uint64()
+
+    def sizes(n, layout):
+        assert L.slamem_index_build_bytes(n, layout, C.byref(a), C.byref(p)) == capi.SLAMEM_OK
+        return a.value, p.value
+    f100, pf100 = sizes(100_000_000, capi.LAYOUT_FULL)
+    c100, pc100 = sizes(100_000_000, capi.LAYOUT_COMPACT)
+    f3g, pf3g = sizes(3_100_000_000, capi.LAYOUT_FULL)
+    c3g, pc3g = sizes(3_100_000_000, capi.LAYOUT_COMPACT)
+    assert abs(f100 - 6.0317e9) < 2e7 and abs(c100 - 3.2580e9) < 2e7
+    assert abs(f3g - 150.744e9) < 1e8 and abs(c3g - 80.864e9) < 1e8
+    for arena, peak in ((f100, pf100), (c100, pc100), (f3g, pf3g), (c3g, pc3g)):
+        assert arena < peak < arena + 40 * 3_100_000_001
+    assert pc100 < pf100 and pc3g < pf3g < 288 * 2**30  # the full layout of a 3.1 Gbp text fits an MI355X while it is built
+    assert L.slamem_index_build_bytes(0, capi.LAYOUT_FULL, C.byref(a), C.byref(p)) == capi.SLAMEM_ERR_ARG
+    assert L.slamem_index_build_bytes(1000, capi.LAYOUT_AUTO, C.byref(a), C.byref(p)) == capi.SLAMEM_ERR_ARG
