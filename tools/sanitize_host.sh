@@ -15,7 +15,7 @@ for d in "$ROOT"/tests/golden/*/; do
    SLAMEM_THREADS=4 ASAN_OPTIONS=detect_leaks=0 "$EXE" -b -l 10 -o o.txt "$d/ref.fa" "$d/q.fa" > m.out 2> m.err
    # the same with the query file parsed in pieces by the loader thread, in one process and through the forked worker
    SLAMEM_OVERLAP_MB=0 SLAMEM_FOREGROUND=1 SLAMEM_THREADS=4 ASAN_OPTIONS=detect_leaks=0 "$EXE" -b -l 10 -o o.txt "$d/ref.fa" "$d/q.fa" > m2.out 2>> m.err
-   SLAMEM_OVERLAP_MB=0 SLAMEM_THREADS=4 ASAN_OPTIONS=detect_leaks=0 "$EXE" -b -l 10 -o o.txt "$d/ref.fa" "$d/q.fa" > m3.out 2>> m.err)
+   SLAMEM_OVERLAP_MB=0 SLAMEM_DETACH_TEARDOWN=1 SLAMEM_THREADS=4 ASAN_OPTIONS=detect_leaks=0 "$EXE" -b -l 10 -o o.txt "$d/ref.fa" "$d/q.fa" > m3.out 2>> m.err)
   if [ -s "$T/s.err" ] || [ -s "$T/c.err" ] || grep -q "AddressSanitizer\|runtime error" "$T/m.err"; then
     echo "== $d"; head -5 "$T/s.err" "$T/c.err"; grep -m3 "AddressSanitizer\|runtime error" "$T/m.err"; bad=$((bad + 1))
   fi
