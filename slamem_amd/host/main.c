@@ -522,6 +522,41 @@ static void leave_now(void) { /* results complete: tell the front, then end with
     _exit(0);
 }
 
+/* "-v <mems_file>" (slamem.c:630-655): the sequences are loaded for their names and sizes only, then the picture is drawn */
+static int image_tool(int argc, char **argv, slh_options *o, long log_limit) {
+    slh_seqset ref, *sets;
+    slh_record *seqs;
+    int f, k, numbering = 1, loaded = 0, queries = 0, at = 0, status;
+    (void)argc;
+    memset(&ref, 0, sizeof(ref));
+    sets = (slh_seqset *)calloc((size_t)o->num_files + 1, sizeof(slh_seqset));
+    if (!sets) exit_message("Out of memory");
+    for (f = 0; f < o->num_files; f++) {
+        const char *path = argv[o->file_args[f]];
+        int n = slh_load_file(path, loaded == 0, o->no_ns, (uint32_t)o->min_seq_len, loaded == 0 ? o->ref_name : NULL, numbering,
+                              log_limit, loaded == 0 ? &ref : &sets[loaded], stdout);
+        if (n != 0) { loaded++; numbering += n; if (loaded > 1) queries += n; }
+        if (loaded == 0) exit_message("No valid sequences found in reference file");
+    }
+    if (loaded == 1) exit_message("No query files provided");
+    if (queries == 0) exit_message("No valid query sequences found");
+    printf("> %d reference%s and %d quer%s successfully loaded\n", ref.num, ref.num == 1 ? "" : "s", queries, queries == 1 ? "y" : "ies");
+    seqs = (slh_record *)calloc((size_t)queries + 1, sizeof(slh_record));
+    if (!seqs) exit_message("Out of memory");
+    seqs[at].name = ref.recs[0].name;
+    seqs[at++].size = (uint32_t)ref.total; /* one record: its size; several: refused by the tool */
+    for (f = 1; f < loaded; f++)
+        for (k = 0; k < sets[f].num; k++) seqs[at++] = sets[f].recs[k];
+    status = slh_mem_map_image(argv[o->image_arg], seqs, at, ref.num, stdout);
+    fflush(stdout);
+    free(seqs);
+    for (f = 1; f < loaded; f++) slh_free_seqset(&sets[f]);
+    free(sets);
+    slh_free_seqset(&ref);
+    slh_free_options(o);
+    return status;
+}
+
 static void usage(const char *prog) { /* slamem.c:533-553 */
     printf("Usage:\n");
     printf("\t%s (<options>) <reference_file> <query_file(s)>\n", prog);
@@ -534,8 +569,11 @@ static void usage(const char *prog) { /* slamem.c:533-553 */
     printf("\t-n\tdiscard 'N' characters in the sequences\n");
     printf("\t-m\tminimum sequence size (e.g. to ignore small scaffolds)\n");
     printf("\t-r\tload only the reference(s) whose name(s) contain(s) this string\n");
+    printf("Extra:\n");
+    printf("\t-v\tgenerate MEMs map image from this MEMs file\n");
     printf("Example:\n");
     printf("\t%s -b -l 10 ./ref.fna ./query.fna\n", prog);
+    printf("\t%s -v ./ref-mems.txt ./ref.fna ./query.fna\n", prog);
 }
 
 int main(int argc, char **argv) {
@@ -572,9 +610,9 @@ int main(int argc, char **argv) {
     }
     if (o.num_files < 2) exit_message("Not enough input sequence files provided");
     if (o.ref_name_given && o.ref_name_empty) exit_message("No reference name string provided");
-    if (o.image_arg != -1) exit_message("The -v image tool is not part of this front end (use the reference's on the *-mems.txt output)");
     if ((env = getenv("SLAMEM_DEVICE")) != NULL) device = atoi(env);
     if ((env = getenv("SLAMEM_VERBOSE")) != NULL && atoi(env) != 0) log_limit = 0;
+    if (o.image_arg != -1) return image_tool(argc, argv, &o, log_limit); /* slamem.c:652-655; host only, before any GPU call */
     if ((env = getenv("SLAMEM_BATCH_MB")) != NULL && atoll(env) > 0) batch_bytes = (uint64_t)atoll(env) << 20;
 
     if (getenv("SLAMEM_FULL_TEARDOWN") == NULL) split_off_worker();

@@ -61,9 +61,9 @@ int slh_seq_id_from_merged_pos(const uint32_t *starts, int num, uint32_t *pos);
 /* Options as the reference parses them (slamem.c:571-663; tools.c:31-62). */
 typedef struct {
     int usage;          /* argc < 3                                          */
-    int hidden_sort;    /* -s given (not supported by this front end)        */
-    int hidden_clean;   /* -c given (not supported by this front end)        */
-    int image_arg;      /* index of the -v value, or -1                      */
+    int hidden_sort;    /* -s given: slh_sort_mems_file                      */
+    int hidden_clean;   /* -c given: slh_clean_fasta                         */
+    int image_arg;      /* index of the -v value, or -1: slh_mem_map_image   */
     int no_ns;          /* -n                                                */
     int min_seq_len;    /* -m, 0 if absent                                   */
     char *ref_name;     /* -r string (malloc'ed) or NULL                     */
@@ -101,6 +101,11 @@ int slh_buffer_reserve(slh_buffer *b, size_t bytes);
  * "-c <fasta_file>" (CleanFasta, slamem.c:455-523).  Messages go to log; the return value is the process status. */
 int slh_sort_mems_file(const char *path, FILE *log);
 int slh_clean_fasta(const char *path, FILE *log);
+
+/* "-v <mems_file>" (CreateMemMapImage, slamem.c:354-452; graphics.c, bitmap.c): the picture of the MEMs of every query against
+ * the one reference, written as <mems_file without extension>.bmp, the same bytes as the reference's.  seqs: the reference
+ * record first, then every query record in loading order.  Returns the process status (0, or -1 after an error message). */
+int slh_mem_map_image(const char *mems_path, const slh_record *seqs, int num_seqs, int num_refs, FILE *log);
 
 /* number of progress dots the reference prints for a strand of this length (slamem.c:94,116-120) */
 int slh_progress_dots(uint32_t textsize);

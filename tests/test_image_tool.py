@@ -1,0 +1,121 @@
+"""The "-v <mems_file>" image tool of the command line (slamem.c:354-452, graphics.c, bitmap.c -> slamem_amd/host/mem_image.c):
+host C only, so these run without a GPU.  The picture file and stdout are compared BYTE FOR BYTE with what the real reference
+wrote for the same inputs (tests/golden/image/, made by tests/golden/make_image_golden.py)."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+import image_cases
+from golden_cases import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "slamem_amd", "host", "slaMEM-hip")
+MANIFEST = image_cases.manifest()
+
+
+def run_tool(where, opts=()):
+    r = subprocess.run([EXE, *opts, "-v", "mems.txt", "ref.fa", "q.fa"], cwd=where, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=120)
+    return r.returncode, r.stdout
+
+
+def decode_bmp(data):
+    """8-bit BMP, plain or BI_RLE8 -> (width, height, palette bytes, rows bottom-up); an independent decoder, not the tool's"""
+    assert data[:2] == b"BM"
+    size, _, _, offset = struct.unpack_from("<IHHI", data, 2)
+    hdr, w, h, planes, bpp, comp, datasize, _, _, ncol, _ = struct.unpack_from("<IIIHHIIIIII", data, 14)
+    assert (hdr, planes, bpp) == (40, 1, 8) and size == len(data) == offset + datasize and offset == 54 + 4 * ncol
+    d = data[offset:]
+    if comp == 0:
+        return w, h, data[54:offset], [d[r * w:(r + 1) * w] for r in range(h)]
+    assert comp == 1
+    rows, cur, i = [], bytearray(), 0
+    while True:
+        c, v = d[i], d[i + 1]
+        i += 2
+        if c:
+            cur += bytes([v]) * c
+        elif v == 0:
+            rows.append(bytes(cur))
+            cur = bytearray()
+        elif v == 1:
+            break
+        else:
+            assert v >= 3
+            cur += d[i:i + v]
+            i += v + (v & 1)
+    assert not cur and all(x == 0 for x in d[i:]) and len(d) - i < 4
+    return w, h, data[54:offset], rows
+
+
+@pytest.mark.parametrize("case", sorted(MANIFEST))
+def test_image_tool_equals_the_reference_byte_for_byte(case, tmp_path):
+    entry = MANIFEST[case]
+    image_cases.write_inputs(case, entry, str(tmp_path))
+    rc, out = run_tool(str(tmp_path), entry["opts"])
+    assert rc == entry["rc"], out.decode(errors="replace")[-400:]
+    assert out == open(os.path.join(image_cases.IMAGE_GOLDEN, case, "expected-stdout.txt"), "rb").read()
+    bmp = tmp_path / "mems.bmp"
+    assert bmp.exists() == entry["image"]
+    if entry["image"]:
+        mine, ref = bmp.read_bytes(), open(os.path.join(image_cases.IMAGE_GOLDEN, case, "expected.bmp"), "rb").read()
+        assert mine == ref
+        w, h, palette, rows = decode_bmp(mine)
+        n = 1 + len(entry["queries"])
+        assert (w, h) == (1024, 24 + 16 + 30 * n + 12 * (n - 1)) and len(rows) == h and all(len(r) == w for r in rows)
+        assert palette[:12] == bytes([255, 255, 255, 0, 0, 0, 0, 0, 222, 222, 222, 0]) and len(palette) == 4 * 255
+
+
+def test_picture_content_follows_the_mems(tmp_path):
+    """What the bytes MEAN, through an independent decoder: a grey track where no MEM lies, the reference bar's colour of the
+    matching columns where one does (forward MEMs from the bar's upper half, reverse ones from its lower half, mirrored on the
+    query), the longer MEM on top."""
+    entry = {"reference": [["ref", 98700]], "queries": [["q0", 98700]]}  # 100 letters per column (987 columns for 5 digits)
+    image_cases.write_fasta(str(tmp_path / "ref.fa"), [tuple(entry["reference"][0])])
+    image_cases.write_fasta(str(tmp_path / "q.fa"), [tuple(entry["queries"][0])])
+    (tmp_path / "mems.txt").write_text(">q0\n50001\t10001\t5000\n50001\t12001\t1000\n>q0 Reverse\n20001\t1\t3000\n")
+    rc, out = run_tool(str(tmp_path))
+    assert rc == 0 and b"(2 MEMs)" in out and b"(1 MEMs)" in out
+    w, h, palette, rows = decode_bmp((tmp_path / "mems.bmp").read_bytes())
+    rows = rows[::-1]                     # top row first
+    bar_fwd, bar_rev, track = rows[28 + 5], rows[28 + 16 + 5], rows[28 + 42 + 10]
+    grey = 2
+    assert track[10 + 50] == grey and track[10 + 99] == grey and track[10 + 150] == grey
+    for col in range(100, 150):            # query 10,000..14,999 <-> reference 50,000..54,999, forward
+        assert track[10 + col] == bar_fwd[10 + 500 + (col - 100)]
+    # the 1,000-letter MEM at query 12,000 (reference 50,000 as well) lies under the longer one: nothing of it shows
+    assert track[10 + 120] == bar_fwd[10 + 520]
+    for col in range(957, 987):            # reverse strand: query positions count from the other end
+        assert track[10 + col] == bar_rev[10 + 200 + (col - 957)]
+    assert track[10 + 956] == grey and track[10 + 987] == 1  # the track's black frame
+
+
+def test_long_stretches_without_equal_neighbours(tmp_path):
+    """983 neighbouring columns, no two alike: the reference's run-length coder wraps its 8-bit counter at 255, skips a byte of
+    the picture each time and reads behind its pixel buffer at the end (two runs of the reference differ there), so there is no
+    fixture; the tool follows the reference's decisions up to that point (checked in the build container against the reference:
+    the files are equal up to the last row's tail) and must still write a well-formed file that decodes to 1024-wide rows."""
+    image_cases.write_fasta(str(tmp_path / "ref.fa"), [("ref", 983000)])
+    image_cases.write_fasta(str(tmp_path / "q.fa"), [("q0", 983000)])
+    with open(tmp_path / "mems.txt", "w") as f:
+        f.write(">q0\n")
+        for j in range(983):
+            f.write("%d\t%d\t1000\n" % (1 if j % 2 == 0 else 500001, 1 + 1000 * j))
+    rc, out = run_tool(str(tmp_path))
+    assert rc == 0 and out.endswith(b"> Saving image to <mems.bmp> ... OK\n> Done!\n")
+    w, h, palette, rows = decode_bmp((tmp_path / "mems.bmp").read_bytes())
+    assert (w, h) == (1024, 112) and len(rows) == h and all(len(r) == w for r in rows)
+
+
+def test_image_of_a_golden_case_of_the_search(tmp_path):
+    """the search's own output format goes in unchanged: the reference's MEMs file of a golden case of the main path"""
+    src = os.path.join(GOLDEN, "acgt_l20_both")
+    for name, to in (("ref.fa", "ref.fa"), ("q.fa", "q.fa"), ("expected-mems.txt", "mems.txt")):
+        (tmp_path / to).write_bytes(open(os.path.join(src, name), "rb").read())
+    rc, out = run_tool(str(tmp_path))
+    assert rc == 0 and out.count(b" MEMs)\n") == 12
+    import hashlib
+    assert hashlib.sha256((tmp_path / "mems.bmp").read_bytes()).hexdigest() == \
+        "cc08bfe75f081c60ba0ce6f6c64993079116c5c0006aa51b3a361a7123da305f"  # the reference's picture of these files (build container)
