@@ -245,11 +245,22 @@ def case_config1_dups_pair(tmp):
     return _pair_dups(tmp, False)
 
 
+def case_config1_dups_pair_image(tmp):
+    """the reference's -v picture (slamem.c:354-452) of its own MEMs file for the pair with exact repeats"""
+    import hashlib
+    d = _pair_dups(tmp, False)
+    rc, secs = run_reference(["-v", "out.txt", "ref.fa", "qry.fa"], tmp)
+    img = open(os.path.join(tmp, "out.bmp"), "rb").read()
+    os.remove(os.path.join(tmp, "out.bmp"))
+    return {"mems_file_sha256": d["file_sha256"], "image_bytes": len(img), "image_sha256": hashlib.sha256(img).hexdigest(),
+            "reference_rc": rc, "reference_seconds": round(secs, 1), "workload": d["workload"] + "; then -v out.txt ref.fa qry.fa"}
+
+
 def case_config1_dups_pair_mam(tmp):
     return _pair_dups(tmp, True)
 
 
-CASES = {"config4_genome_like_first100k": case_config4_genome_like_first100k, "config1_dups_pair": case_config1_dups_pair, "config1_dups_pair_mam": case_config1_dups_pair_mam,
+CASES = {"config1_dups_pair_image": case_config1_dups_pair_image, "config4_genome_like_first100k": case_config4_genome_like_first100k, "config1_dups_pair": case_config1_dups_pair, "config1_dups_pair_mam": case_config1_dups_pair_mam,
          "config5_first100k": case_config5_first100k, "config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
          "config2_mam_first200k": case_config2_mam_first200k, "config1_pair_mam": case_config1_pair_mam}
 

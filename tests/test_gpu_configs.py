@@ -332,6 +332,13 @@ def test_genome_pair_with_exact_repeats_mem_and_mam_cli(eng, tmp_path, mam):
     data = (tmp_path / "out.txt").read_bytes()
     assert len(data) == known["file_bytes"]
     assert hashlib.sha256(data).hexdigest() == known["file_sha256"]
+    if not mam:  # search -> picture: the -v tool on this output writes the picture the reference drew of ITS output (slamem.c:354-452)
+        img = KNOWN["config1_dups_pair_image"]
+        assert img["mems_file_sha256"] == known["file_sha256"]
+        r = subprocess.run([exe, "-v", "out.txt", "ref.fa", "qry.fa"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 0 and r.stdout.endswith(b"> Saving image to <out.bmp> ... OK\n> Done!\n")
+        bmp = (tmp_path / "out.bmp").read_bytes()
+        assert len(bmp) == img["image_bytes"] and hashlib.sha256(bmp).hexdigest() == img["image_sha256"]
 
 
 def test_genome_like_generator_gpu_equals_numpy(eng):
