@@ -119,3 +119,56 @@ def test_image_of_a_golden_case_of_the_search(tmp_path):
     import hashlib
     assert hashlib.sha256((tmp_path / "mems.bmp").read_bytes()).hexdigest() == \
         "cc08bfe75f081c60ba0ce6f6c64993079116c5c0006aa51b3a361a7123da305f"  # the reference's picture of these files (build container)
+
+
+def test_random_inputs_against_the_reference_binary_when_it_is_here(tmp_path):
+    """Where oracle/_ref/slaMEM exists (the build container, and boxes the built tree travels to), twelve seeded random inputs --
+    1 to 20 queries shorter and longer than the reference, odd names, few / diagonal / scattered / per-column MEMs, names the
+    tool must refuse -- go through both programs: same exit status, same stdout, same picture bytes.  Without the binary the
+    committed fixtures above are the check (the test then only exercises the tool)."""
+    import random
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "slaMEM")
+    have_ref = os.path.exists(ref_bin)
+    for seed in range(12):
+        rng = random.Random(1000 + seed)
+        d = tmp_path / ("c%d" % seed)
+        d.mkdir()
+        rn = rng.choice([300, 5000, 123456, 400000, 2500])
+        queries = []
+        for k in range(rng.choice([1, 2, 3, 5, 9, 20])):
+            ql = rng.choice([50, 400, rn // 2, rn, rn * 2 if rn < 200000 else rn // 3, 1234])
+            name = rng.choice(["q%d" % k, "read_%d some description here that is long" % k, "x" * rng.randint(1, 300) + str(k),
+                               "Reverse%d" % k, "we|rd~{}[]%d" % k, "tab\tname%d" % k])
+            queries.append((name, ql))
+        image_cases.write_fasta(str(d / "ref.fa"), [(rng.choice(["ref", "gi|123|some reference, complete genome", "R" * 200]), rn)])
+        image_cases.write_fasta(str(d / "q.fa"), queries)
+        mode = rng.choice(["scatter", "diag", "few", "noise"])
+        with open(d / "mems.txt", "w") as f:
+            for name, ql in queries:
+                for strand in (0, 1):
+                    f.write(">%s%s\n" % (name, " Reverse" if strand else ""))
+                    if mode == "noise":
+                        step = max(1, ql // 1000)
+                        for qp in range(1, ql + 1, step):
+                            ln = max(1, min(rng.randint(1, step), ql - qp + 1, rn))
+                            f.write("%d\t%d\t%d\n" % (rng.randint(1, rn - ln + 1), qp, ln))
+                        continue
+                    for _ in range(rng.randint(0, 5) if mode == "few" else rng.randint(0, 400)):
+                        ln = max(1, min(rng.randint(1, max(1, min(ql, rn) // rng.choice([1, 3, 10, 100]))), ql, rn))
+                        qp = rng.randint(1, ql - ln + 1)
+                        rp = min(max(1, qp + rng.randint(-5, 5)), rn - ln + 1) if mode == "diag" else rng.randint(1, rn - ln + 1)
+                        f.write("%d\t%d\t%d\n" % (rp, qp, ln))
+        rc, out = run_tool(str(d))
+        assert rc in (0, 255), out[-300:]
+        mine = (d / "mems.bmp").read_bytes() if (d / "mems.bmp").exists() else None
+        assert (mine is not None) == (rc == 0)
+        if mine is not None:
+            w, h, _, rows = decode_bmp(mine)
+            assert w == 1024 and len(rows) == h and all(len(r) == w for r in rows)
+            (d / "mems.bmp").unlink()
+        if have_ref:
+            r = subprocess.run([ref_bin, "-v", "mems.txt", "ref.fa", "q.fa"], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=120)
+            assert (r.returncode, r.stdout) == (rc, out), seed
+            theirs = (d / "mems.bmp").read_bytes() if (d / "mems.bmp").exists() else None
+            assert theirs == mine, seed
