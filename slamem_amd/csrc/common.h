@@ -205,6 +205,8 @@ int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_d
 // (between init and tables) the number of slices of the batch when the caller knows it -- no record longer than a slice: one
 // per record -- which saves tables() its host round trip
 void search_job_slices_hint(SearchJob* j, uint32_t slices);
+// (between init and the search) at most this many waves for the batch's K8 (0: the whole chip)
+void search_job_k8_wave_cap(SearchJob* j, uint32_t waves);
 constexpr uint32_t kSearchSliceLen = 4096;
 int search_job_tables(SearchJob* j, hipStream_t stream);
 int search_job_prep(SearchJob* j, hipStream_t stream);

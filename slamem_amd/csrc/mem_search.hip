@@ -2237,6 +2237,7 @@ struct SearchJob {
     bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
     bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
     unsigned long long scal_own[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t k8_wave_cap = 0;  // waves of this batch's K8 (0: as many as the chip holds); a pipeline that keeps two K8 launches in flight gives each a part of the chip
     uint32_t slices_hint = 0xFFFFFFFFu;  // a caller that has the offsets on the host and knows the slice count (no record longer than a slice: one per record) saves tables() its round trip
     unsigned long long* h_scal = scal_own;  // where search() has the scalars copied: [0..7] the scalar block, [8] all MEMs; pinned memory if the caller has some
     ~SearchJob();
@@ -2522,7 +2523,7 @@ int SearchJob::search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_o
         // persistent waves: as many as the chip holds (256 CUs x 16 waves), fewer for small batches
         uint64_t waves = (nitems + kFetch - 1) / kFetch;
         static const uint64_t env_waves = [] { const char* v = getenv("SLAMEM_K8_WAVES"); return v ? (uint64_t)atoll(v) : 0ull; }();
-        const uint64_t cap_waves = env_waves ? env_waves : kK8Waves;
+        const uint64_t cap_waves = k8_wave_cap ? k8_wave_cap : env_waves ? env_waves : kK8Waves;
         if (waves > cap_waves) waves = cap_waves;
         const bool carry = carry_from != nullptr || carry_out;
         if (carry) {  // the grid covers every lane that may come in, whatever the size of this batch (every launch of a stream: the same)
@@ -2766,10 +2767,12 @@ int search_job_init(SearchJob* j, const slamem_index* idx, const void* queries_d
                     unsigned long long* host_scalars) {
     j->h_scal = host_scalars ? host_scalars : j->scal_own;
     j->slices_hint = 0xFFFFFFFFu;
+    j->k8_wave_cap = 0;
     return j->init(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev,
                    mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes);
 }
 void search_job_slices_hint(SearchJob* j, uint32_t slices) { j->slices_hint = slices; }
+void search_job_k8_wave_cap(SearchJob* j, uint32_t waves) { j->k8_wave_cap = waves; }
 int search_job_tables(SearchJob* j, hipStream_t stream) { return j->tables(stream); }
 int search_job_prep(SearchJob* j, hipStream_t stream) { return j->prep(stream); }
 int search_job_search(SearchJob* j, hipStream_t stream) { return j->search(stream); }

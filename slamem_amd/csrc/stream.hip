@@ -96,6 +96,7 @@ struct slamem_stream {
     hipStream_t st_place = nullptr;    // K9 of every batch: behind the K8 that finished it, but not in front of the next K8
     hipStream_t st_search2 = nullptr;  // SLAMEM_STREAM_SEARCH_STREAMS=2: odd batches' K8 + K9 on a second stream (their K8 starts in the tail of the even one's)
     int search_streams = 1;
+    uint32_t k8_waves = 2560;  // two search streams: waves of a K8 that has another batch behind it (SLAMEM_STREAM_K8_WAVES; the chip holds 4096)
     double mems_per_char = 0;  // the densest batch so far: sizes a slot's first output buffers (written by the download stage)
     std::mutex mu;
     std::condition_variable cv;
@@ -238,11 +239,15 @@ int stage_search(slamem_stream* s, Slot& sl, bool failed, bool* issued_only) {
         }
         return SLAMEM_OK;
     }
-    bool more;
+    bool more, follows;
     {
         std::lock_guard<std::mutex> lk(s->mu);
-        more = s->carry && s->search_streams == 1 && s->submitted > sl.seq + 1;
+        follows = s->submitted > sl.seq + 1;
+        more = s->carry && s->search_streams == 1 && follows;
     }
+    // two search streams: a batch that has another one behind it takes only part of the chip for its K8, so that the next
+    // batch's preparation and then its K8 start beside it instead of in its tail; the last batch of a stream takes all of it
+    search_job_k8_wave_cap(sl.job, (s->search_streams > 1 && follows) ? s->k8_waves : 0u);
     SLAMEM_HIP(hipStreamWaitEvent(st, sl.ev_prep, 0));
     int rc;
     if (s->pending && search_job_can_carry_into(s->pending->job, sl.job)) {
@@ -436,8 +441,12 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
     {
         int lo = 0, hi = 0;  // (numerically lower = higher priority)
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char* v = getenv("SLAMEM_STREAM_PREP_PRIORITY");
-        const bool prio = v && atoi(v) != 0;
+        const char* v = getenv("SLAMEM_STREAM_CARRY");
+        if (v) s->carry = atoi(v) != 0;
+        v = getenv("SLAMEM_STREAM_SEARCH_STREAMS");
+        const bool two = v && atoi(v) == 2 && !s->carry;
+        v = getenv("SLAMEM_STREAM_PREP_PRIORITY");
+        const bool prio = v ? atoi(v) != 0 : two;
         for (int k = 0; k < s->nthreads; k++) {
             // the preparation's workgroups go first where K8's waves retire (it is what the next K8 waits for)
             hipError_t e = (prio && k == T_PREP) ? hipStreamCreateWithPriority(&s->st[k], hipStreamNonBlocking, hi)
@@ -451,10 +460,14 @@ int slamem_stream_create(const slamem_index* idx, int slots, uint64_t max_batch_
             hipError_t e = hipStreamCreateWithFlags(&s->st_place, hipStreamNonBlocking);
             if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
         }
-        v = getenv("SLAMEM_STREAM_CARRY");
-        if (v) s->carry = atoi(v) != 0;
-        v = getenv("SLAMEM_STREAM_SEARCH_STREAMS");
-        if (rc == SLAMEM_OK && v && atoi(v) == 2) {
+        v = getenv("SLAMEM_STREAM_K8_WAVES");
+        if (v && atoi(v) > 0) s->k8_waves = (uint32_t)atoi(v);
+        // SLAMEM_STREAM_SEARCH_STREAMS=2 (measured at the end of round 3, not the default): even / odd batches on two search
+        // streams, each K8 on 2560 of the chip's 4096 wave slots while another batch follows, the preparation on a high-priority
+        // stream -- K8 (b+1) fills in as K8 (b) drains and the preparation of b+2 finds slots beside them.  Million-read batches
+        // gain (headline stream 38.3 -> 37.5 ms, 30 M reads 109.0 -> 102.5 ms), two-million-read batches lose (102.3 -> 103.9 ms),
+        // the command line does not move: profiles/r03_host_leg_two_streams.jsonl.
+        if (rc == SLAMEM_OK && two) {
             hipError_t e = hipStreamCreateWithFlags(&s->st_search2, hipStreamNonBlocking);
             if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
             else s->search_streams = 2;
