@@ -625,15 +625,24 @@ def test_auto_layout_follows_the_free_hbm(eng, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("mode", ["carry", "two_streams"])
 @pytest.mark.parametrize("mam", [False, True], ids=["mem", "mam"])
-def test_stream_k8_without_tail_passes_lanes_to_the_next_batch(eng, mam, monkeypatch):
-    """slamem_stream_* with SLAMEM_STREAM_CARRY=1 and five batches in flight: every K8 but the last ends when its work list is empty and passes its
+def test_stream_k8_without_tail_passes_lanes_to_the_next_batch(eng, mam, mode, monkeypatch):
+    """The two opt-in organisations of the search stage of slamem_stream_*, each against the oracle batch by batch.
+    two_streams: SLAMEM_STREAM_SEARCH_STREAMS=2 -- even and odd batches on two search streams, a K8 that has another batch behind
+    it on a part of the chip only (here 16 waves, so that every launch runs into the cap), the preparation at high priority.
+    carry: SLAMEM_STREAM_CARRY=1 and five batches in flight: every K8 but the last ends when its work list is empty and passes its
     unfinished lanes -- mid-strand, in any state of the scan -- to the next batch's K8 (kCarry); their MEMs
     land in the batch they belong to.  Reads with N, repeats (multi-row intervals: enumeration jobs of carried lanes),
     min_len 9, both strands; batches of very different sizes, one of them empty: every batch equals the oracle in order
     (slamem.c:114-199)."""
     from oracle import pyoracle as po
-    monkeypatch.setenv("SLAMEM_STREAM_CARRY", "1")
+    if mode == "carry":
+        monkeypatch.setenv("SLAMEM_STREAM_CARRY", "1")
+    else:
+        monkeypatch.setenv("SLAMEM_STREAM_SEARCH_STREAMS", "2")
+        monkeypatch.setenv("SLAMEM_STREAM_K8_WAVES", "16")
+        monkeypatch.setenv("SLAMEM_STREAM_PREP_PRIORITY", "1")
     rng = np.random.default_rng(4242)
     text = rand_text(rng, 300_000, "ACGT", 120, max_rep=600)
     qs = make_queries(rng, text, 24_000, "ACGTN", maxlen=260)
