@@ -67,6 +67,24 @@ def test_rccl_companion_library_exports_replicate():
     assert "slamem_index_replicate" in text
 
 
+def test_reference_named_layer_exports_the_reference_names():
+    """libslamem_refapi.so (include/slamem_refapi.h): SURVEY 8(b)(2) over the GPU engine -- every function the header declares is
+    exported under the reference's own name, and the layer is built on the C ABI (it needs libslamem_hip.so, not the oracle)."""
+    so = os.path.join(ROOT, "slamem_amd", "csrc", "libslamem_refapi.so")
+    assert os.path.exists(so), "run __graft_entry__.build()"
+    import subprocess
+    text = open(os.path.join(ROOT, "include", "slamem_refapi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b([A-Za-z_]+)\s*\(", text)) - {"defined"})
+    assert names == ["BuildSampledLCPArray", "FMI_BuildIndex", "FMI_FollowLetter", "FMI_FreeIndex", "FMI_GetBWTSize", "FMI_GetCharAtBWTPos",
+                     "FMI_GetTextSize", "FMI_PositionInText", "FreeSampledSuffixArray", "GetEnclosingLCPInterval"]
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], stdout=subprocess.PIPE).stdout.decode()
+    for n in names:
+        assert " T %s\n" % n in syms, n
+    needed = subprocess.run(["readelf", "-d", so], stdout=subprocess.PIPE).stdout.decode()
+    assert "libslamem_hip.so" in needed and "oracle" not in needed
+
+
 def _arena_header(n=100_000, num_n=3, with_filter=True):
     """A consistent arena header, laid out as slamem_amd/csrc/common.h::ArenaHeader does (host-side mirror for the test)."""
     import struct
