@@ -18,15 +18,15 @@ extern "C" {
 #endif
 
 /* bwtindex.h:7, call slamem.c:73 -- numTexts is 1 there; *lcpOut receives a malloc'ed array of n+1 bytes min(LCP,255) */
-void FMI_BuildIndex(char **inputTexts, unsigned int *inputTextSizes, unsigned int inputNumTexts, unsigned char **lcpArrayPointer, char verbose);
+void FMI_BuildIndex(char **texts, unsigned int *sizes, unsigned int num_texts, unsigned char **lcp_out, char verbose);
 /* lcparray.h:1, call slamem.c:74 -- the parent structure was built with the index; returns the number of LCP samples */
-int BuildSampledLCPArray(char *text, unsigned int textsize, unsigned char *lcparray, int minlcp, int verbose);
+int BuildSampledLCPArray(char *text, unsigned int n, unsigned char *lcp, int min_lcp, int verbose);
 unsigned int FMI_GetBWTSize(void);                                                          /* bwtindex.h:9, slamem.c:111 */
 unsigned int FMI_GetTextSize(void);                                                         /* bwtindex.h:8 */
-unsigned int FMI_FollowLetter(char c, unsigned int *topPointer, unsigned int *bottomPointer); /* bwtindex.h:2, slamem.c:121 */
-int GetEnclosingLCPInterval(unsigned int *topptr, unsigned int *bottomptr);                 /* lcparray.h:4, slamem.c:124,192 */
-char FMI_GetCharAtBWTPos(unsigned int bwtpos);                                              /* bwtindex.h:4, slamem.c:141,166 */
-unsigned int FMI_PositionInText(unsigned int bwtpos);                                       /* bwtindex.h:1, slamem.c:142,167 */
+unsigned int FMI_FollowLetter(char letter, unsigned int *top, unsigned int *bottom); /* bwtindex.h:2, slamem.c:121 */
+int GetEnclosingLCPInterval(unsigned int *top, unsigned int *bottom);                       /* lcparray.h:4, slamem.c:124,192 */
+char FMI_GetCharAtBWTPos(unsigned int row);                                                 /* bwtindex.h:4, slamem.c:141,166 */
+unsigned int FMI_PositionInText(unsigned int row);                                          /* bwtindex.h:1, slamem.c:142,167 */
 void FMI_FreeIndex(void);                                                                   /* bwtindex.h:6, slamem.c:208 */
 void FreeSampledSuffixArray(void);                                                          /* lcparray.h:2, slamem.c:209 */
 
