@@ -349,6 +349,24 @@ static int canvas_save(const canvas *cv, const char *path) {
     return (fclose(f) != EOF) && ok;
 }
 
+/* Test entry (libslamem_host.so): any 8-bit picture through the same writer -- rows top first, palette as in the tool.  Lets the
+   tests reach what the MEM map never produces (a picture that does not compress: the plain fall-back of canvas_save). */
+int slh_write_bmp8(const char *path, int width, int height, const uint8_t *rows_top_first) {
+    canvas cv;
+    int y, ok;
+    if (!path || width <= 0 || height <= 0 || !rows_top_first) return 0;
+    cv.w = width; cv.h = height;
+    cv.px = (uint8_t *)malloc((size_t)width * (size_t)height + 4);
+    if (!cv.px) return 0;
+    memset(cv.px + (size_t)width * (size_t)height, 0, 4);
+    palette_init(&cv);
+    for (y = 0; y < height; y++)
+        memcpy(cv.px + (size_t)(height - 1 - y) * (size_t)width, rows_top_first + (size_t)y * (size_t)width, (size_t)width);
+    ok = canvas_save(&cv, path);
+    free(cv.px);
+    return ok;
+}
+
 /* ---- the MEMs file (slamem.c:387-439) -------------------------------------------------------------------------------------- */
 
 typedef struct { const char *p, *end; } reader;

@@ -107,6 +107,10 @@ int slh_clean_fasta(const char *path, FILE *log);
  * record first, then every query record in loading order.  Returns the process status (0, or -1 after an error message). */
 int slh_mem_map_image(const char *mems_path, const slh_record *seqs, int num_seqs, int num_refs, FILE *log);
 
+/* (tests) an arbitrary 8-bit picture, rows top first, through the tool's file writer (palette of the tool; run-length coded, or
+ * plain when that would not be shorter); 1 on success */
+int slh_write_bmp8(const char *path, int width, int height, const uint8_t *rows_top_first);
+
 /* number of progress dots the reference prints for a strand of this length (slamem.c:94,116-120) */
 int slh_progress_dots(uint32_t textsize);
 

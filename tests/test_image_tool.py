@@ -172,3 +172,40 @@ def test_random_inputs_against_the_reference_binary_when_it_is_here(tmp_path):
             assert (r.returncode, r.stdout) == (rc, out), seed
             theirs = (d / "mems.bmp").read_bytes() if (d / "mems.bmp").exists() else None
             assert theirs == mine, seed
+
+
+def test_file_writer_round_trips_any_picture(tmp_path):
+    """The writer behind the tool (slh_write_bmp8 of libslamem_host.so) on pictures the MEM map never makes, read back with the
+    independent decoder: runs, lone bytes between runs, literal stretches of odd and even length, a row of one colour -- and
+    NOISE, which does not compress: the file is then written plain (compression 0), as the reference does (bitmap.c:617)."""
+    import ctypes as C
+    import numpy as np
+    import hostlib
+    L = C.CDLL(os.path.join(hostlib.HOST_DIR, "libslamem_host.so"))
+    L.slh_write_bmp8.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(12)
+    w, h = 1024, 40
+    pics = {}
+    a = np.zeros((h, w), dtype=np.uint8)
+    a[3, 100:400] = 7; a[4, 0:240:2] = 9; a[5, 10:13] = [1, 2, 3]; a[6, 10:14] = [1, 2, 3, 4]; a[7, :] = 200
+    a[8, 5] = 1; a[8, 6:8] = 2; a[8, 8] = 3; a[8, 9:11] = 4                       # lone bytes between pairs
+    a[9, 0:200] = (np.arange(200) % 7 + 1).astype(np.uint8)                        # 200 neighbours, no two alike
+    a[7, -4:] = 0
+    pics["shapes"] = a
+    pics["runs"] = np.repeat(rng.integers(0, 255, size=(h, w // 8), dtype=np.uint8), 8, axis=1)
+    # (stretches of 255 and more neighbours without two alike are the reference's broken regime -- see the test above; the
+    #  noise here has an equal pair every 100 columns so that it stays out of it)
+    noise = rng.integers(0, 250, size=(h, w), dtype=np.uint8)
+    noise[:, 50::100] = noise[:, 49::100][:, : noise[:, 50::100].shape[1]]
+    noise[:, -4:] = 0   # (a row that ends inside a stretch of unequal neighbours is the other way into that regime)
+    pics["noise"] = noise
+    pics["noise_rows"] = np.where(np.arange(h)[:, None] % 4 == 0, noise, 0).astype(np.uint8)
+    for name, pic in pics.items():
+        path = str(tmp_path / (name + ".bmp"))
+        assert L.slh_write_bmp8(path.encode(), w, h, np.ascontiguousarray(pic).ctypes.data) == 1
+        data = open(path, "rb").read()
+        ww, hh, palette, rows = decode_bmp(data)
+        assert (ww, hh) == (w, h) and len(rows) == h
+        assert np.array_equal(np.frombuffer(b"".join(rows[::-1]), dtype=np.uint8).reshape(h, w), pic), name
+        comp = struct.unpack_from("<I", data, 30)[0]
+        assert comp == (0 if name == "noise" else 1), (name, comp, len(data))
