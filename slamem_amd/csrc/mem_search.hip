@@ -876,6 +876,61 @@ __device__ __forceinline__ uint32_t wave_enumerate(const SearchArgs& A, bool old
     return k;
 }
 
+// wave_enumerate for the kChunk instantiations (repeat-rich texts: enumeration is most of the kernel there, and a job is a chain
+// of levels).  Same order, same results; ONE memory round trip per level instead of three: the first 64 rows above, the first 64
+// rows below and the parent's records are independent of each other (the parent depends on [t,b] only), so their loads go out
+// together, and a row's three plane words are read at once instead of the exception word first.  Levels with more than 64 new
+// rows on a side take further steps as before.
+__device__ __forceinline__ uint32_t bwt_code_all(const IndexView& ix, uint32_t row) {
+    const FMBlock* blk = ix.fm + (row >> kFmRowsLog2);
+    const uint32_t o = row & (kFmRows - 1u), hs = o >> 6, bit = o & 63u;
+    const uint64_t e = blk->ex[hs], p0 = blk->p0[hs], p1 = blk->p1[hs];
+    const uint32_t acgt = 2u + (uint32_t)((p0 >> bit) & 1ull) + 2u * (uint32_t)((p1 >> bit) & 1ull);
+    return ((e >> bit) & 1ull) ? (row == ix.dollar_row ? 0u : 1u) : acgt;
+}
+template <bool kCarry>
+__device__ __forceinline__ uint32_t wave_enumerate_merged(const SearchArgs& A, bool old, uint32_t lane, uint32_t g, uint32_t k,
+                                                          uint32_t tag, uint32_t t, uint32_t b, int msz, bool level0, bool walk_up,
+                                                          uint32_t pos, uint32_t left, int L, int* first_parent,
+                                                          unsigned long long& ovf_base, uint32_t& ovf_left) {
+    const IndexView& ix = A.ix;
+    const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
+    uint32_t pt = level0 ? b + 1u : t, pb = b;  // rows already reported: [pt, pb]
+    bool first = true;
+    *first_parent = -2;
+    for (;;) {
+        // ---- one memory phase: rows t+lane (above), b-lane (below), the records of [t,b] -----------------------------
+        const uint32_t ra = t + lane, rb = b - lane;
+        const bool wa = ra < pt, wb = lane < b - pb;
+        uint32_t ca = left, cb = left;
+        if (wa) ca = bwt_code_all(ix, ra);
+        if (wb) cb = bwt_code_all(ix, rb);
+        uint4 rt = make_uint4(0, 0, 0, 0), rbm = rt;
+        if (walk_up) { rt = R[t]; rbm = R[b]; }  // (same address in every lane: one line each, broadcast)
+        // ---- new rows above, ascending (slamem.c:140) ------------------------------------------------------------------
+        if (t < pt) k = wave_emit_step<kCarry, true>(A, old, lane, g, k, tag, wa && ca != left, ra, pos, (uint32_t)msz, ovf_base, ovf_left);
+        for (uint32_t base = t + 64u; base < pt && base > t; base += 64u) {
+            const uint32_t row = base + lane;
+            const bool ok = row < pt && bwt_code(ix, row) != left;
+            k = wave_emit_step<kCarry, true>(A, old, lane, g, k, tag, ok, row, pos, (uint32_t)msz, ovf_base, ovf_left);
+        }
+        // ---- new rows below, bottom-up (slamem.c:165) ------------------------------------------------------------------
+        if (b != pb) k = wave_emit_step<kCarry, true>(A, old, lane, g, k, tag, wb && cb != left, rb, pos, (uint32_t)msz, ovf_base, ovf_left);
+        for (uint32_t done = 64u; done < b - pb; done += 64u) {
+            const uint32_t off = done + lane;
+            const uint32_t row = b - off;
+            const bool ok = off < b - pb && bwt_code(ix, row) != left;
+            k = wave_emit_step<kCarry, true>(A, old, lane, g, k, tag, ok, row, pos, (uint32_t)msz, ovf_base, ovf_left);
+        }
+        if (!walk_up) break;
+        pt = t;
+        pb = b;
+        msz = parent_from(rt, rbm, t, b);  // (slamem.c:192)
+        if (first) { *first_parent = msz; first = false; }
+        if (msz < L) break;
+    }
+    return k;
+}
 
 // Counters of a diagnostic launch (template parameter kStats; the timed kernels are the kStats = false instantiations,
 // which carry none of this): how many loads of each kind the lanes issue.  One 64-bit word each, at SearchArgs::stats.
@@ -1622,8 +1677,11 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
             uint32_t e_steps = 0, e_levels = 0;
             unsigned long long ovf_base = kChunk ? lds_ovf_base[wv] : 0ull;
             uint32_t ovf_left = kChunk ? lds_ovf_left[wv] : 0u;
-            uint32_t nk = wave_enumerate<kCarry, kChunk>(A, o_old, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp,
-                                                         ovf_base, ovf_left, kStats ? &e_steps : nullptr, kStats ? &e_levels : nullptr);
+            uint32_t nk = (kChunk && !kStats)
+                              ? wave_enumerate_merged<kCarry>(A, o_old, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp,
+                                                              ovf_base, ovf_left)
+                              : wave_enumerate<kCarry, kChunk>(A, o_old, lane, o_g, o_k, o_tag, o_t, o_b, o_depth, o_l0, o_up, o_pos, o_left, L, &fp,
+                                                               ovf_base, ovf_left, kStats ? &e_steps : nullptr, kStats ? &e_levels : nullptr);
             if (kChunk) { lds_ovf_base[wv] = ovf_base; lds_ovf_left[wv] = ovf_left; }
             if (kStats && lane == 0u) { n_erow += e_steps; n_elev += e_levels; }
             if ((int)lane == owner) {
