@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SLAMEM_ABI_VERSION 3
+#define SLAMEM_ABI_VERSION 4
 
 enum {
     SLAMEM_OK = 0,
@@ -94,6 +94,9 @@ typedef struct {
     float k8_ms;              /* K8 k_find_mems_v3 alone, part of search_kernel_ms */
     double prefilter_ms_sum;
     double k8_ms_sum;
+    float seed_ms;            /* K8s k_seed_mems (seed-and-compare for reads; runs in K8a's place), part of search_kernel_ms (ABI 4) */
+    float reserved0;
+    double seed_ms_sum;
 } slamem_timings;
 
 /* Load counters of ONE diagnostic search launch (slamem_search_stats_enable): how many loads of each kind the lanes of
@@ -135,6 +138,14 @@ typedef struct {
      * over lanes, and the number of WAVE trips in which at least one lane was in the state (what the wave pays for) */
     uint64_t state_lane_trips[11];
     uint64_t state_wave_trips[11];
+    /* K8s (ABI 4): seed-and-compare for reads */
+    uint64_t seed_windows;          /* K8s: seed-table lines fetched (one 64-byte line per window, both strands of a read share it)   */
+    uint64_t seed_compares;         /* K8s: diagonals compared with the text (four 16-byte units of the text bit-planes each)         */
+    uint64_t seed_letter_masks;     /* K8s: compares that also read the text's "not A,C,G,T" masks (four 8-byte words)                */
+    uint64_t seed_mems;             /* K8s: MEMs it reported                                                                          */
+    uint64_t seed_strands_left;     /* K8s: strands left to the index walk (K8)                                                       */
+    uint64_t seed_reads;            /* K8s: reads screened                                                                            */
+    uint64_t seed_query_bytes;      /* K8s: bytes of the reads it packed                                                              */
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

@@ -72,7 +72,7 @@ class Timings(C.Structure):
                 ("search_kernel_ms", C.c_float), ("search_total_ms", C.c_float),
                 ("search_launches", C.c_uint64), ("search_kernel_ms_sum", C.c_double),
                 ("prefilter_ms", C.c_float), ("k8_ms", C.c_float), ("prefilter_ms_sum", C.c_double),
-                ("k8_ms_sum", C.c_double)]
+                ("k8_ms_sum", C.c_double), ("seed_ms", C.c_float), ("reserved0", C.c_float), ("seed_ms_sum", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -85,7 +85,9 @@ class SearchStats(C.Structure):
         "prefilter_items", "items", "survivors", "mems", "overflow_records", "valid", "dir_sa_lines", "dir_group_loads",
         "dir_rec_lines", "dir_letters", "jump_lines", "skip_group_loads", "skip_probe_lines", "skip_attempts", "skips",
         "enum_row_steps", "enum_levels", "enum_wave_us")] + [("state_lane_trips", C.c_uint64 * 11),
-                                                               ("state_wave_trips", C.c_uint64 * 11)]
+                                                               ("state_wave_trips", C.c_uint64 * 11)] + [
+        (k, C.c_uint64) for k in ("seed_windows", "seed_compares", "seed_letter_masks", "seed_mems", "seed_strands_left",
+                                  "seed_reads", "seed_query_bytes")]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k.startswith("state_") else int(getattr(self, k))) for k, _ in self._fields_}
@@ -169,7 +171,7 @@ def lib():
         _load_torch_runtime_first()
         L = C.CDLL(LIB_PATH)
         _declare(L)
-        if L.slamem_abi_version() != 3:
+        if L.slamem_abi_version() != 4:
             raise ImportError("libslamem_hip.so ABI version mismatch")
         _LIB = L
     return _LIB

@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 11;  // 11: presence filter in lines keyed by the (k-2)-mer; 10: k-mer occurrence bitmap; 9: K-mer jump table; 8: text-ordered groups + parent records
+constexpr uint32_t kArenaVersion = 12;  // 12: seed table + text bit-planes (the seed-and-compare path of the search); 11: presence filter in lines keyed by the (k-2)-mer; 10: k-mer occurrence bitmap; 9: K-mer jump table; 8: text-ordered groups + parent records
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -98,10 +98,61 @@ struct ArenaHeader {
     uint64_t off_kbits;   // uint64[4^kbits_k / 64]  one bit per k-mer over A,C,G,T: does it occur in the text?
     uint32_t layout;      // 1 = full, 2 = compact (no text-ordered sections, half-size presence filter); 0 in arenas of older builds = full
     uint32_t lcp_ge[10];  // rows whose LCP is >= kLcpGe[i]: how repeat-rich the text is at a given minimum length (all 0 in arenas of older builds: unknown)
+    // seed-and-compare sections (version 12; all 0: the index has none)
+    uint32_t seed_k;      // letters of a seed (<= 16)
+    uint32_t seed_log2;   // log2 of the number of buckets of the seed table
+    uint64_t off_seed;    // SeedBucket[1 << seed_log2]   every k-mer of the text over A,C,G,T by its canonical form
+    uint64_t off_tpl;     // TextPlanes[text_units(n)]    the text as two bit-planes, 64 letters per 16 bytes
+    uint64_t off_tnm;     // uint64[text_units(n)]        bit per letter: not one of A,C,G,T
+    uint64_t off_tnb;     // uint64[text_units(n)/64 + 1] bit per 64-letter unit: it holds such a letter
 };
 // thresholds of ArenaHeader::lcp_ge
 __host__ __device__ constexpr uint32_t kLcpGe[10] = {18, 20, 25, 30, 40, 50, 75, 100, 150, 255};
 static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
+
+// ---- seed-and-compare sections (no reference counterpart) ---------------------------------------------------------
+// What they replace for reads: the reference finds a MEM by walking the query letter by letter through the index
+// (slamem.c:114-199).  A MEM of at least L letters contains a k-letter window that starts at a multiple of s = L - k + 1 of
+// the strand; the seed table gives every text position of that window, and the MEM is then the run of agreeing letters
+// around it on that diagonal -- found by comparing the strand with the text itself, 64 letters per XOR.
+//   TextPlanes u : letters 64u .. 64u+63 of the text as two bit-planes (A,C,G,T = 0..3; bit i of p0 / p1 = low / high bit of
+//                  letter 64u+i; letters that are not A,C,G,T and positions behind the text are 0 and marked in tnm / tnb)
+//   SeedBucket   : one 64-byte line: up to 12 text positions whose k-mer hashes here (ascending), a tag byte each (the low
+//                  bits of the hash -- the hash is a bijection of the canonical k-mer, so bucket + tag identify it exactly --
+//                  and bit 7: the text holds the reverse complement of the canonical form), and the number of k-mers that
+//                  hash here (13 = more than fit: a strand that meets the bucket is left to the index walk)
+struct __attribute__((aligned(16))) TextPlanes { uint64_t p0, p1; };
+constexpr uint32_t kSeedSlots = 12;
+struct __attribute__((aligned(64))) SeedBucket {
+    uint32_t pos[kSeedSlots];
+    uint8_t tag[kSeedSlots];
+    uint32_t count;
+};
+static_assert(sizeof(SeedBucket) == 64 && sizeof(TextPlanes) == 16, "seed bucket = one line, text unit = 16 bytes");
+__host__ __device__ inline uint64_t text_units(uint64_t n) { return (n + 63) / 64 + 4; }  // (a compare reads four units from the one its diagonal starts in)
+// k letters as two k-bit plane fields (bit i = letter i) -> the 2k-bit key
+__host__ __device__ inline uint32_t seed_key(uint32_t p0, uint32_t p1, uint32_t k) { return p0 | (p1 << k); }
+// the key of the reverse complement: letter i of it is the complement (3 - code: both bits flipped) of letter k-1-i
+__host__ __device__ inline uint32_t seed_rev_field(uint32_t f, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__brev(f) >> (32u - k)) ^ ((1u << k) - 1u);
+#else
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < k; i++) r |= ((f >> i) & 1u) << (k - 1u - i);
+    return r ^ ((1u << k) - 1u);
+#endif
+}
+// a bijection of the 2k-bit keys (odd multipliers and right shifts): the high bits choose the bucket, the low ones are the tag
+__host__ __device__ inline uint32_t seed_mix(uint32_t key, uint32_t bits) {
+    const uint32_t mask = bits >= 32u ? 0xFFFFFFFFu : (1u << bits) - 1u;
+    uint32_t x = key;
+    x = (x * 0x9E3779B1u) & mask;
+    x ^= x >> (bits >> 1);
+    x = (x * 0x85EBCA6Bu) & mask;
+    x ^= x >> ((bits >> 1) + 1u);
+    x = (x * 0xC2B2AE35u) & mask;
+    return x;
+}
 
 // What the kernels see (passed by value).
 struct IndexView {
@@ -123,6 +174,12 @@ struct IndexView {
     uint32_t kfilter_log2;
     uint32_t kfilter_k;
     uint32_t kfilter_levels;  // 2 or 3
+    const SeedBucket* seed;   // nullptr when the index has no seed sections
+    const TextPlanes* tpl;
+    const uint64_t* tnm;
+    const uint64_t* tnb;
+    uint32_t seed_k;
+    uint32_t seed_log2;
 };
 
 // Presence filter: a blocked Bloom filter in 64-byte lines of eight words.  The line is chosen by a (k-2)-mer of the

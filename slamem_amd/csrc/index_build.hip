@@ -393,6 +393,91 @@ __global__ void __launch_bounds__(256) k_kfilter_fill(const uint64_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// K1d: text bit-planes and the seed table (the seed-and-compare path of the search, mem_search.hip k_seed_mems)
+// ------------------------------------------------------------------------------------------
+// even bits of x (bit 2j -> bit j)
+__device__ __forceinline__ uint32_t even_bits16(uint32_t x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+// one lane per unit of 64 letters; a wave covers 64 consecutive units and writes their word of the coarse bitmap
+__global__ void __launch_bounds__(256) k_text_planes(const uint64_t* __restrict__ pk, uint32_t n, uint64_t units,
+                                                     TextPlanes* __restrict__ tpl, uint64_t* __restrict__ tnm,
+                                                     uint64_t* __restrict__ tnb) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t p0 = 0, p1 = 0, nm = 0;
+    if (u < units && u * 64 < (uint64_t)n) {
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; w++) {
+            uint32_t v2, ok16;
+            letters16(pk[u * 4 + w], v2, ok16);  // first letter in the highest bits / bit 15
+            const uint32_t r = __brev(v2);       // letter j at bits 2j (its high bit) and 2j+1 (its low bit)
+            p1 |= (uint64_t)even_bits16(r) << (16u * w);
+            p0 |= (uint64_t)even_bits16(r >> 1) << (16u * w);
+            nm |= (uint64_t)((__brev(ok16) >> 16) ^ 0xFFFFu) << (16u * w);
+        }
+        const uint64_t left = (uint64_t)n - u * 64;  // letters of the text in this unit
+        if (left < 64) nm &= (1ull << left) - 1ull;  // positions behind the text are not marked (the compare bounds them)
+    }
+    if (u < units) { tpl[u] = TextPlanes{p0, p1}; tnm[u] = nm; }
+    const unsigned long long any = __ballot(nm != 0ull);
+    if ((threadIdx.x & 63u) == 0u && (u >> 6) < units / 64 + 1) tnb[u >> 6] = any;
+}
+
+// k letters of the text from position t as plane fields; false: a letter is not A,C,G,T
+__device__ __forceinline__ bool text_field(const TextPlanes* __restrict__ tpl, const uint64_t* __restrict__ tnm, uint64_t t,
+                                           uint32_t k, uint32_t& f0, uint32_t& f1) {
+    const uint64_t u = t >> 6;
+    const uint32_t sh = (uint32_t)t & 63u;
+    const TextPlanes a = tpl[u], b = tpl[u + 1];
+    const uint64_t na = tnm[u], nb = tnm[u + 1];
+    const uint32_t m = (k >= 32u) ? 0xFFFFFFFFu : (1u << k) - 1u;
+    f0 = (uint32_t)((a.p0 >> sh) | ((b.p0 << 1) << (63u - sh))) & m;
+    f1 = (uint32_t)((a.p1 >> sh) | ((b.p1 << 1) << (63u - sh))) & m;
+    return ((uint32_t)((na >> sh) | ((nb << 1) << (63u - sh))) & m) == 0u;
+}
+// sort key of text position t: its bucket above a tag byte; positions without a k-mer over A,C,G,T sort behind every bucket
+__global__ void __launch_bounds__(256) k_seed_keys(const TextPlanes* __restrict__ tpl, const uint64_t* __restrict__ tnm,
+                                                   uint32_t n, uint32_t k, uint32_t log2b, uint64_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n) return;
+    uint64_t key = 1ull << (log2b + 8u);
+    uint32_t f0, f1;
+    if (t + k <= (uint64_t)n && text_field(tpl, tnm, t, k, f0, f1)) {
+        const uint32_t x = seed_key(f0, f1, k), y = seed_key(seed_rev_field(f0, k), seed_rev_field(f1, k), k);
+        const uint32_t h = seed_mix(x < y ? x : y, 2u * k), tb = 2u * k - log2b;
+        key = ((uint64_t)(h >> tb) << 8) | (uint64_t)((h & ((1u << tb) - 1u)) | (x > y ? 0x80u : 0u));
+    }
+    keys[t] = key;
+    vals[t] = (uint32_t)t;
+}
+// the sorted positions into their buckets: a lane finds its place in its bucket's run by looking back, the first lane of a
+// run also counts it (13 = more than fit)
+__global__ void __launch_bounds__(256) k_seed_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                   uint64_t n, uint32_t log2b, SeedBucket* __restrict__ table) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    if (key >> (log2b + 8u)) return;
+    const uint64_t b = key >> 8;
+    uint32_t r = 0;
+    while (r < kSeedSlots && r < i && (keys[i - r - 1u] >> 8) == b) r++;
+    if (r >= kSeedSlots) return;
+    table[b].pos[r] = vals[i];
+    table[b].tag[r] = (uint8_t)(key & 0xFFu);
+    if (r == 0u) {
+        uint32_t c = 1;
+        while (c <= kSeedSlots && i + c < n && (keys[i + c] >> 8) == b) c++;
+        table[b].count = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K5: exact LCP in text order (Kasai): one thread per chunk of text positions, the match length
 // carried from position i to i+1 never drops by more than one.  Stores LCP+1 (0 = "-1" sentinel).
 // ------------------------------------------------------------------------------------------
@@ -828,6 +913,12 @@ void make_view(slamem_index* idx) {
     idx->view.kfilter_log2 = h.kfilter_log2;
     idx->view.kfilter_k = h.kfilter_k;
     idx->view.kfilter_levels = h.kfilter_levels == 2u ? 2u : 3u;
+    idx->view.seed = h.off_seed ? reinterpret_cast<const SeedBucket*>(base + h.off_seed) : nullptr;
+    idx->view.tpl = h.off_seed ? reinterpret_cast<const TextPlanes*>(base + h.off_tpl) : nullptr;
+    idx->view.tnm = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tnm) : nullptr;
+    idx->view.tnb = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tnb) : nullptr;
+    idx->view.seed_k = h.off_seed ? h.seed_k : 0u;
+    idx->view.seed_log2 = h.off_seed ? h.seed_log2 : 0u;
     idx->view.n = h.n;
     idx->view.nblocks = h.nblocks;
     idx->view.dollar_row = h.dollar_row;
@@ -914,6 +1005,24 @@ static void plan_arena(uint32_t n, uint32_t num_n, int layout, ArenaHeader& hdr)
         if (want_kbits && n >= k && (uint64_t)n * 10ull <= (1ull << (2u * k))) {
             hdr.kbits_k = k;
             hdr.off_kbits = off; off = align_up(off + ((1ull << (2u * k)) >> 3), 256);
+        }
+    }
+    {   // seed table + text bit-planes (the seed-and-compare path for reads): full layout, texts below 2^28 letters (a seed
+        // is at most 16 letters: beyond, chance occurrences swamp the table); SLAMEM_SEED=0 builds without.  Two to four
+        // k-mers per 12-slot bucket (more than 12 in one bucket: 3e-4 of the buckets at four); k so that the tag fits 7 bits
+        const char* se = getenv("SLAMEM_SEED");
+        if (!compact && !(se && atoi(se) == 0) && n >= 64u && n < (1u << 28)) {
+            uint32_t lg = 10;
+            while ((4ull << lg) < (uint64_t)n) lg++;
+            uint32_t k = (lg + 7u) / 2u;
+            if (k > 16u) k = 16u;
+            hdr.seed_k = k;
+            hdr.seed_log2 = lg;
+            const uint64_t units = text_units(n);
+            hdr.off_seed = off; off = align_up(off + (sizeof(SeedBucket) << lg), 256);
+            hdr.off_tpl = off;  off = align_up(off + units * sizeof(TextPlanes), 256);
+            hdr.off_tnm = off;  off = align_up(off + units * 8, 256);
+            hdr.off_tnb = off;  off = align_up(off + (units / 64 + 1) * 8, 256);
         }
     }
     hdr.total_bytes = off;
@@ -1195,6 +1304,26 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
 
 
     mark("K1b filter fill");
+    if (hdr.off_seed) {  // text bit-planes, then the seed table by sorting the positions by bucket (the sort's buffers are free)
+        const uint64_t units = text_units(n);
+        TextPlanes* d_tpl = reinterpret_cast<TextPlanes*>(base + hdr.off_tpl);
+        uint64_t* d_tnm = reinterpret_cast<uint64_t*>(base + hdr.off_tnm);
+        uint64_t* d_tnb = reinterpret_cast<uint64_t*>(base + hdr.off_tnb);
+        SeedBucket* d_seed = reinterpret_cast<SeedBucket*>(base + hdr.off_seed);
+        SLAMEM_HIP(hipMemsetAsync(d_tnb, 0, (units / 64 + 1) * 8, stream));
+        hipLaunchKernelGGL(k_text_planes, dim3(grid_for(units + 63)), dim3(256), 0, stream, pk.as<uint64_t>(), n, units, d_tpl, d_tnm, d_tnb);
+        hipLaunchKernelGGL(k_seed_keys, dim3(grid_for(n)), dim3(256), 0, stream, (const TextPlanes*)d_tpl, (const uint64_t*)d_tnm, n,
+                           hdr.seed_k, hdr.seed_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>());
+        SLAMEM_HIP(hipGetLastError());
+        need = tmp_bytes;
+        SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysB.as<uint64_t>(), keysA.as<uint64_t>(), valsB.as<uint32_t>(),
+                                      valsA.as<uint32_t>(), n, 8, (int)hdr.seed_log2 + 8 + 1, stream));
+        SLAMEM_HIP(hipMemsetAsync(d_seed, 0, sizeof(SeedBucket) << hdr.seed_log2, stream));
+        hipLaunchKernelGGL(k_seed_fill, dim3(grid_for(n)), dim3(256), 0, stream, (const uint64_t*)keysA.as<uint64_t>(),
+                           (const uint32_t*)valsA.as<uint32_t>(), (uint64_t)n, hdr.seed_log2, d_seed);
+        SLAMEM_HIP(hipGetLastError());
+        mark("K1d seed table");
+    }
     // ---- K3: BWT planes + rank samples ------------------------------------------------------------
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
     SLAMEM_HIP(hipMemsetAsync(d_fm, 0, (uint64_t)nblocks * sizeof(FMBlock), stream));

@@ -938,7 +938,8 @@ enum : uint32_t {
     SC_FM_TOP = 0, SC_FM_BOT, SC_REC_FAIL_LINES, SC_REC_PEND_LINES, SC_REC_FLUSH_LINES, SC_QUERY_LOADS, SC_LANE_TRIPS,
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
     SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
-    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_T_ENUM_SUM, SC_STATE_TRIPS /* 11 words: lane trips per state */, SC_STATE_WAVES = SC_STATE_TRIPS + 11 /* 11 words: wave trips in which some lane is in the state */, SC_COUNT = SC_STATE_WAVES + 11
+    SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_T_ENUM_SUM, SC_STATE_TRIPS /* 11 words: lane trips per state */, SC_STATE_WAVES = SC_STATE_TRIPS + 11 /* 11 words: wave trips in which some lane is in the state */,
+    SC_SEED_WINDOWS = SC_STATE_WAVES + 11, SC_SEED_COMPARES, SC_SEED_NMASKS, SC_SEED_MEMS, SC_SEED_LEFT, SC_SEED_READS, SC_SEED_QBYTES, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -2051,6 +2052,362 @@ __global__ void __launch_bounds__(256, SLAMEM_PF_WAVES) k_prefilter(SearchArgs A
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K8s: seed-and-compare -- the search for READS (k_seed_mems)
+// ------------------------------------------------------------------------------------------
+// Replaces, for strands of up to kSeedMaxLen letters, the scan of GetMatches (slamem.c:105-199) AND the prefilter: the
+// output of the scan is the set of all maximal matches of at least L letters, and every such match contains a
+// k-letter window that starts at a multiple of s = L - k + 1 of its strand.  So, per read:
+//   1. every window of the forward strand at a multiple of s is looked up in the seed table by its canonical form: ONE
+//      64-byte line gives every text position of the window AND of its reverse complement -- the window of the reverse
+//      strand that covers the same letters (strand offset len - k - o; those offsets form a residue class mod s too, so the
+//      reverse strand's MEMs all hold one).  One lane per window, every lookup of a read in flight at once: two dependent
+//      memory phases per read instead of the scan's chain of ~100;
+//   2. a hit (strand, text position p, strand offset o) is a diagonal d = p - o; the MEM around the window is the run of
+//      agreeing letters on that diagonal: the strand (bit-planes in LDS) XOR the text (bit-planes, four 16-byte units = the
+//      192 letters from d on), one lane per compare.  A MEM is reported by its window with the smallest forward offset (a
+//      hit whose neighbour window hit the same diagonal is dropped before the compare when s <= k);
+//   3. the MEMs of a strand are ranked in the reference's emission order -- start descending, then length descending
+//      (slamem.c:114,139-193: the scan runs right to left, a position reports its deepest interval first) -- with wave-wide
+//      comparisons and go to the strand's inline slots / the overflow list with their text position (K9 skips the
+//      suffix-array read for them).
+// Whatever this cannot decide exactly goes to the index walk (K8), strand by strand (alive[] = 1): a letter that is not
+// A,C,G,T in the read, a read longer than kSeedMaxLen (or with more than 64 windows), a bucket with more k-mers than it
+// holds (a repeat: its rows need the suffix order), a palindromic window that hits,
+// two MEMs of a strand with the same start and length (their order is the order of their BWT rows).  Nothing here is
+// approximate: a strand is either reported completely by this kernel or completely by K8.
+constexpr uint32_t kSeedReads = 16;     // reads of a wave
+constexpr uint32_t kSeedMaxLen = 192;   // letters of a strand the planes hold (three words)
+constexpr uint32_t kSeedJobs = 256;     // compares of one trip
+constexpr uint32_t kSeedMems = 128;     // MEMs of one trip
+
+struct SeedWave {
+    uint64_t pl[kSeedReads][2][2][4];   // [read][strand][plane][word]; word 3 stays 0 (a window's second word)
+    uint32_t len[kSeedReads];           // letters (0: the read takes no part)
+    uint32_t nwin[kSeedReads];          // windows
+    uint32_t job_p[kSeedJobs], job_x[kSeedJobs];
+    uint32_t mem_key[kSeedMems], mem_ref[kSeedMems], mem_g[kSeedMems];
+    uint32_t flags;                     // bit 2 * read + strand: the strand is left to K8
+    uint32_t pad[3];
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// bits [sh, sh + 64) of the 128-bit value hi:lo (sh in 0..63)
+__device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t sh) { return (lo >> sh) | ((hi << 1) << (63u - sh)); }
+// the bits [lo, hi) of a word (any integers; clamped to 0..64)
+__device__ __forceinline__ uint64_t bits_range(int lo, int hi) {
+    lo = lo < 0 ? 0 : lo > 64 ? 64 : lo;
+    hi = hi < 0 ? 0 : hi > 64 ? 64 : hi;
+    const uint64_t a = hi >= 64 ? ~0ull : (1ull << hi) - 1ull, b = lo >= 64 ? ~0ull : (1ull << lo) - 1ull;
+    return a & ~b;
+}
+__device__ __forceinline__ uint32_t sel4(const uint4& v, uint32_t a) {
+    const uint32_t lo = (a & 1u) ? v.y : v.x, hi = (a & 1u) ? v.w : v.z;
+    return (a & 2u) ? hi : lo;
+}
+__device__ __forceinline__ uint32_t sel12(const uint4& b0, const uint4& b1, const uint4& b2, uint32_t e) {
+    const uint32_t a = e & 3u, x0 = sel4(b0, a), x1 = sel4(b1, a), x2 = sel4(b2, a);
+    return e < 4u ? x0 : e < 8u ? x1 : x2;
+}
+// bit 7 of every byte of m -> four bits
+__device__ __forceinline__ uint32_t byte_tops(uint32_t m) {
+    const uint32_t y = m >> 7;
+    return (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xFu;
+}
+
+template <bool kStats>
+__global__ void __launch_bounds__(256) k_seed_mems(SearchArgs A, uint8_t* __restrict__ alive) {
+    __shared__ SeedWave lds[4];
+    __shared__ uint8_t lut[256];  // ASCII -> 2-bit code | 4 (one of A,C,G,T), or 8
+    {
+        const uint32_t u = threadIdx.x & 0xDFu, x = (u >> 1) & 3u;
+        lut[threadIdx.x] = (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? (uint8_t)((x ^ (x >> 1)) | 4u) : (uint8_t)8u;
+    }
+    __syncthreads();
+    const IndexView& ix = A.ix;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    SeedWave& S = lds[wv];
+    const uint32_t strands = A.strands, k = ix.seed_k, L = A.min_len, s = L - k + 1u;
+    const uint32_t kmask = (1u << k) - 1u, tb = 2u * k - ix.seed_log2, tagmask = (1u << tb) - 1u;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wv) * kSeedReads;
+    if (r0 >= (uint64_t)A.num_queries) return;
+    const uint32_t nr = (uint64_t)A.num_queries - r0 < kSeedReads ? (uint32_t)((uint64_t)A.num_queries - r0) : kSeedReads;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int64_t ulast = (int64_t)text_units(ix.n) - 1;
+    uint32_t n_win = 0, n_cmp = 0, n_nm = 0, n_mem = 0;
+
+    // ---- the wave's reads: lengths, windows, bit-planes of both strands -------------------------------------------------
+    const uint64_t off = lane <= nr ? A.offsets[r0 + lane] : 0ull;
+    const uint64_t offn = __shfl_down(off, 1);
+    uint32_t len = 0, nwin = 0;
+    bool left = false;  // both strands of the read are left to K8
+    if (lane < nr) {
+        const uint64_t l64 = offn - off;
+        if (l64 > kSeedMaxLen) left = l64 >= L; else len = (uint32_t)l64;
+        if (len >= L) nwin = (len - k) / s + 1u;
+        if (nwin > 64u) { left = true; nwin = 0; }
+    }
+    uint32_t wflags = 0;  // wave-uniform part of the flags
+    {
+        uint32_t m = (uint32_t)__ballot(left) & 0xFFFFu;
+        m = (m | (m << 8)) & 0x00FF00FFu; m = (m | (m << 4)) & 0x0F0F0F0Fu; m = (m | (m << 2)) & 0x33333333u; m = (m | (m << 1)) & 0x55555555u;
+        wflags = m | (m << 1);
+    }
+    if (lane == 0u) S.flags = 0u;
+    const uint32_t plen = nwin ? len : 0u;
+    const uint8_t* qbytes = reinterpret_cast<const uint8_t*>(A.qwords);
+    for (uint32_t i = 0; i < nr; i++) {
+        const uint32_t Li = (uint32_t)__builtin_amdgcn_readlane((int)plen, (int)i);
+        uint32_t keep_len = Li, keep_win = (uint32_t)__builtin_amdgcn_readlane((int)nwin, (int)i);
+        if (Li) {
+            const uint64_t base = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)i),
+                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)i));
+            uint64_t f0[3], f1[3];
+            unsigned long long other = 0ull;
+#pragma unroll
+            for (uint32_t j = 0; j < 3u; j++) {
+                const uint32_t x = 64u * j + lane;
+                uint32_t v = 0;
+                if (x < Li) v = lut[qbytes[base + x]];
+                f0[j] = __ballot((v & 1u) != 0u);
+                f1[j] = __ballot((v & 2u) != 0u);
+                other |= __ballot((v & 8u) != 0u);
+            }
+            if (other) {  // a letter that is not A,C,G,T (N equals N in the reference, A.1): the index walk knows how
+                wflags |= 3u << (2u * i);
+                keep_len = 0; keep_win = 0;
+            } else {
+                // reverse strand: letter x of it is the complement (both plane bits flipped) of letter Li-1-x
+                const uint32_t sh = 192u - Li, q = sh >> 6, r = sh & 63u;
+                uint64_t g0[3], g1[3];
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const uint64_t* f = pl ? f1 : f0;
+                    const uint64_t t0 = __brevll(f[2]), t1 = __brevll(f[1]), t2 = __brevll(f[0]);
+                    const uint64_t a0 = q == 0u ? t0 : q == 1u ? t1 : t2, a1 = q == 0u ? t1 : q == 1u ? t2 : 0ull, a2 = q == 0u ? t2 : 0ull;
+                    uint64_t* g = pl ? g1 : g0;
+                    g[0] = ~funnel64(a0, a1, r) & bits_range(0, (int)Li);
+                    g[1] = ~funnel64(a1, a2, r) & bits_range(0, (int)Li - 64);
+                    g[2] = ~funnel64(a2, 0ull, r) & bits_range(0, (int)Li - 128);
+                }
+                if (lane == 0u) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 3u; j++) {
+                        S.pl[i][0][0][j] = f0[j]; S.pl[i][0][1][j] = f1[j];
+                        S.pl[i][1][0][j] = g0[j]; S.pl[i][1][1][j] = g1[j];
+                    }
+                    S.pl[i][0][0][3] = 0ull; S.pl[i][0][1][3] = 0ull; S.pl[i][1][0][3] = 0ull; S.pl[i][1][1][3] = 0ull;
+                }
+            }
+        }
+        if (lane == 0u) { S.len[i] = keep_len; S.nwin[i] = keep_win; }
+        if (keep_win == 0u && lane == i) nwin = 0;
+    }
+    if (lane == 0u)
+        for (uint32_t i = nr; i < kSeedReads; i++) { S.len[i] = 0u; S.nwin[i] = 0u; }
+    wave_sync();
+    // slots per read: the power of two that holds the most windows of a read of this wave
+    uint32_t slots = 0, lg_slots = 0;
+    if (__ballot(nwin > 0u)) { slots = 1; }
+#pragma unroll
+    for (uint32_t t = 1, lg = 1; t <= 32u; t <<= 1, lg++)
+        if (__ballot(nwin > t)) { slots = 2u * t; lg_slots = lg; }
+    const uint32_t rpt = slots ? 64u / slots : kSeedReads;  // reads per trip
+
+    if (slots)
+    for (uint32_t t0 = 0; t0 < nr; t0 += rpt) {
+        // ---- phase 1: one lane per window: the seed table line of its canonical form -----------------------------------
+        const uint32_t rs = t0 + (lane >> lg_slots), wi = lane & (slots - 1u);
+        const uint32_t nw = rs < kSeedReads ? S.nwin[rs] : 0u, Lr = rs < kSeedReads ? S.len[rs] : 0u;
+        const bool act = wi < nw;
+        if (__ballot(act) == 0ull) continue;
+        const uint32_t o = wi * s;
+        uint32_t want = 0, pal = 0;
+        uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0, b3 = b0;
+        if (act) {
+            const uint32_t q = o >> 6, sh = o & 63u;
+            const uint64_t* P0 = S.pl[rs][0][0];
+            const uint64_t* P1 = S.pl[rs][0][1];
+            const uint32_t f0 = (uint32_t)funnel64(P0[q], P0[q + 1u], sh) & kmask, f1 = (uint32_t)funnel64(P1[q], P1[q + 1u], sh) & kmask;
+            const uint32_t x = seed_key(f0, f1, k), y = seed_key(seed_rev_field(f0, k), seed_rev_field(f1, k), k);
+            const uint32_t h = seed_mix(x < y ? x : y, 2u * k);
+            want = (h & tagmask) | (x > y ? 0x80u : 0u);
+            pal = x == y ? 1u : 0u;
+            const uint4* B = reinterpret_cast<const uint4*>(ix.seed + (h >> tb));
+            b0 = B[0]; b1 = B[1]; b2 = B[2]; b3 = B[3];
+        }
+        if (kStats) n_win += (uint32_t)__popcll(__ballot(act));
+        // tags that agree (bit 7 aside) -> hits; bit 7 differs: the text holds the window's reverse complement
+        const uint32_t wbytes = want * 0x01010101u;
+        const uint32_t x0 = b3.x ^ wbytes, x1 = b3.y ^ wbytes, x2 = b3.z ^ wbytes;
+        const uint32_t m0 = ~((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) & 0x80808080u, m1 = ~((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) & 0x80808080u,
+                       m2 = ~((x2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) & 0x80808080u;
+        const uint32_t count = b3.w;
+        uint32_t hits = byte_tops(m0) | (byte_tops(m1) << 4) | (byte_tops(m2) << 8);
+        const uint32_t rev = byte_tops(x0 & 0x80808080u) | (byte_tops(x1 & 0x80808080u) << 4) | (byte_tops(x2 & 0x80808080u) << 8);
+        hits &= count >= kSeedSlots ? 0xFFFu : (1u << count) - 1u;
+        if (strands == 1u) hits &= ~rev;
+        if (!act) hits = 0;
+        if (act && (count > kSeedSlots || (pal && hits && strands == 2u))) {
+            atomicOr(&S.flags, 3u << (2u * rs));
+            hits = 0;
+        }
+        // Every hit is a compare -- except one whose neighbour window (the one s letters earlier in the forward strand) hit the
+        // same diagonal: the two windows overlap or touch, so they lie in the same match and that window, or one before it,
+        // reports the MEM.  (The neighbour's first two hits are looked at; a hit this misses is sorted out by its compare.)
+        const uint32_t nm = (uint32_t)__popc(hits);
+        const uint32_t e1 = nm ? (uint32_t)__ffs((int)hits) - 1u : 0u, h2 = hits & (hits - 1u), e2 = nm > 1u ? (uint32_t)__ffs((int)h2) - 1u : 0u;
+        const uint32_t p1 = sel12(b0, b1, b2, e1), p2 = sel12(b0, b1, b2, e2);
+        const uint32_t st1 = (rev >> e1) & 1u, st2 = (rev >> e2) & 1u;
+        uint32_t pn = 0, pp1 = 0, pp2 = 0, ps1 = 0, ps2 = 0;
+        if (s <= k) {
+            pn = __shfl_up(nm, 1); pp1 = __shfl_up(p1, 1); pp2 = __shfl_up(p2, 1); ps1 = __shfl_up(st1, 1); ps2 = __shfl_up(st2, 1);
+            if (wi == 0u) pn = 0;
+        }
+        uint32_t njobs = 0, rem = hits;
+        for (uint32_t it = 0; __ballot(rem != 0u) != 0ull; it++) {
+            const bool hv = rem != 0u;
+            const uint32_t e = it == 0u ? e1 : it == 1u ? e2 : hv ? (uint32_t)__ffs((int)rem) - 1u : 0u;
+            rem &= rem - 1u;
+            const uint32_t p = it == 0u ? p1 : it == 1u ? p2 : sel12(b0, b1, b2, e);
+            const uint32_t st = (rev >> e) & 1u;
+            const uint32_t w = st ? p + s : p - s;
+            const bool job = hv && !((pn >= 1u && ps1 == st && pp1 == w) || (pn >= 2u && ps2 == st && pp2 == w));
+            const unsigned long long qb = __ballot(job);
+            const uint32_t at = njobs + (uint32_t)__popcll(qb & below);
+            if (job && at < kSeedJobs) {
+                S.job_p[at] = p;
+                S.job_x[at] = (st ? Lr - k - o : o) | (st << 15) | (rs << 16);
+            }
+            njobs += (uint32_t)__popcll(qb);
+        }
+        if (njobs > kSeedJobs) {  // (many repeated windows in one trip) every read of the trip is left to K8
+            for (uint32_t i = t0; i < t0 + rpt && i < kSeedReads; i++) wflags |= 3u << (2u * i);
+            njobs = 0;
+        }
+        wave_sync();
+
+        // ---- phase 2: one lane per compare: the strand against the text on the hit's diagonal --------------------------
+        uint32_t nmems = 0;
+        for (uint32_t jb = 0; jb < njobs; jb += 64u) {
+            const bool has = jb + lane < njobs;
+            const uint32_t p = has ? S.job_p[jb + lane] : 0u, xx = has ? S.job_x[jb + lane] : 0u;
+            const uint32_t os = xx & 0x7FFFu, st = (xx >> 15) & 1u, jr = xx >> 16;
+            const uint32_t Lj = S.len[jr];
+            const int64_t d = (int64_t)p - (int64_t)os;   // text position of the strand's first letter
+            const int64_t u0 = d >> 6;
+            const uint32_t sh = (uint32_t)(d & 63);
+            bool is_mem = false;
+            uint32_t key = 0, ref = 0, g = 0;
+            if (has) {
+                int64_t ui[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const int64_t u = u0 + i; ui[i] = u < 0 ? 0 : u > ulast ? ulast : u; }
+                const uint4* T = reinterpret_cast<const uint4*>(ix.tpl);
+                const uint4 t0 = T[ui[0]], t1 = T[ui[1]], t2 = T[ui[2]], t3 = T[ui[3]];
+                const uint64_t c0 = ix.tnb[ui[0] >> 6], c3 = ix.tnb[ui[3] >> 6];
+                uint32_t anyn = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) anyn |= (uint32_t)((((ui[i] >> 6) == (ui[0] >> 6) ? c0 : c3) >> (ui[i] & 63)) & 1ull);
+                uint64_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+                if (anyn) {  // (rare) some unit holds a letter that is not A,C,G,T: it disagrees with every letter of a strand that has none
+                    n0 = ix.tnm[ui[0]]; n1 = ix.tnm[ui[1]]; n2 = ix.tnm[ui[2]]; n3 = ix.tnm[ui[3]];
+                    if (kStats) n_nm++;
+                }
+                const uint64_t* R0 = S.pl[jr][st][0];
+                const uint64_t* R1 = S.pl[jr][st][1];
+                uint64_t mm[3];
+                mm[0] = (funnel64(u64_of(t0.x, t0.y), u64_of(t1.x, t1.y), sh) ^ R0[0]) | (funnel64(u64_of(t0.z, t0.w), u64_of(t1.z, t1.w), sh) ^ R1[0]) | funnel64(n0, n1, sh);
+                mm[1] = (funnel64(u64_of(t1.x, t1.y), u64_of(t2.x, t2.y), sh) ^ R0[1]) | (funnel64(u64_of(t1.z, t1.w), u64_of(t2.z, t2.w), sh) ^ R1[1]) | funnel64(n1, n2, sh);
+                mm[2] = (funnel64(u64_of(t2.x, t2.y), u64_of(t3.x, t3.y), sh) ^ R0[2]) | (funnel64(u64_of(t2.z, t2.w), u64_of(t3.z, t3.w), sh) ^ R1[2]) | funnel64(n2, n3, sh);
+                // letters that face no text letter, or lie behind the strand, disagree
+                const int lo = d < 0 ? (int)(-d) : 0;
+                const int64_t room = (int64_t)ix.n - d;
+                const int hi = room < (int64_t)Lj ? (int)room : (int)Lj;
+#pragma unroll
+                for (int w = 0; w < 3; w++) mm[w] |= ~bits_range(lo - 64 * w, hi - 64 * w);
+                // the run of agreeing letters around the window [os, os + k): [a, b)
+                uint32_t a = 0, b = 192u;
+                bool broken = false;
+#pragma unroll
+                for (int w = 0; w < 3; w++) {
+                    const uint64_t lw = mm[w] & bits_range(0, (int)os - 64 * w);
+                    if (lw) a = 64u * w + 64u - (uint32_t)__clzll((long long)lw);
+                    if (mm[w] & bits_range((int)os - 64 * w, (int)(os + k) - 64 * w)) broken = true;
+                }
+#pragma unroll
+                for (int w = 2; w >= 0; w--) {
+                    const uint64_t hw = mm[w] & ~bits_range(0, (int)(os + k) - 64 * w);
+                    if (hw) b = 64u * w + (uint32_t)__ffsll((unsigned long long)hw) - 1u;
+                }
+                // reported by the window with the smallest forward offset inside the match
+                const bool owner = st ? !(os + s + k <= b) : !(os >= s && os - s >= a);
+                g = (uint32_t)((r0 + jr) * strands + st);
+                if (broken) atomicOr(&S.flags, 1u << (2u * jr + st));  // (cannot happen: the table is exact) -- leave the strand to K8
+                else if (owner && b - a >= L) { is_mem = true; key = (a << 16) | (b - a); ref = (uint32_t)(d + (int64_t)a); }
+            }
+            if (kStats) n_cmp += (uint32_t)__popcll(__ballot(has));
+            const unsigned long long mb = __ballot(is_mem);
+            if (is_mem) {
+                const uint32_t at = nmems + (uint32_t)__popcll(mb & below);
+                if (at < kSeedMems) { S.mem_key[at] = key; S.mem_ref[at] = ref; S.mem_g[at] = g; }
+                else atomicOr(&S.flags, 1u << (2u * jr + st));
+            }
+            nmems += (uint32_t)__popcll(mb);
+        }
+        if (nmems > kSeedMems) nmems = kSeedMems;
+        wave_sync();
+
+        // ---- phase 3: the strand's MEMs in the reference's emission order --------------------------------------------------
+        const uint32_t g0 = (uint32_t)(r0 * strands);
+        for (uint32_t pass = 0; pass < 2u; pass++) {   // 0: MEMs of a strand that tie (same start, same length) leave it to K8;  1: emit
+            const uint32_t fl = pass ? (S.flags | wflags) : 0u;
+            for (uint32_t m0i = 0; m0i < nmems; m0i += 64u) {
+                const uint32_t mi = m0i + lane;
+                const bool has = mi < nmems;
+                const uint32_t key = has ? S.mem_key[mi] : 0u, ref = has ? S.mem_ref[mi] : 0u, g = has ? S.mem_g[mi] : 0xFFFFFFFFu;
+                uint32_t rank = 0, cnt = 0;
+                bool tie = false;
+                for (uint32_t t2 = 0; t2 < nmems; t2++) {
+                    const uint32_t kk = S.mem_key[t2], gg = S.mem_g[t2];
+                    const bool same = gg == g;
+                    cnt += same ? 1u : 0u;
+                    rank += (same && kk > key) ? 1u : 0u;
+                    tie = tie || (same && kk == key && t2 != mi);
+                }
+                const uint32_t bit = strands == 2u ? g - g0 : 2u * (g - g0);
+                if (!pass) { if (has && tie) atomicOr(&S.flags, 1u << bit); }
+                else if (has && !((fl >> bit) & 1u)) {
+                    emit3_at(A, g, rank, 0u, ref, key >> 16, (key & 0xFFFFu) | 0x80000000u);  // bit 31: ref_pos is the text position (K9)
+                    if (rank == 0u) A.block_counts[g] = cnt;
+                    if (kStats) n_mem++;
+                }
+            }
+            wave_sync();
+        }
+    }
+    wave_sync();
+    const uint32_t fl = S.flags | wflags;
+    if (lane < nr * strands) alive[r0 * strands + lane] = (uint8_t)((fl >> (strands == 2u ? lane : 2u * lane)) & 1u);
+    if (kStats) {
+        stat_flush<kStats>(A.stats + SC_SEED_NMASKS, n_nm);
+        stat_flush<kStats>(A.stats + SC_SEED_MEMS, n_mem);
+        if (lane == 0u) {
+            atomicAdd(A.stats + SC_SEED_WINDOWS, (unsigned long long)n_win);
+            atomicAdd(A.stats + SC_SEED_COMPARES, (unsigned long long)n_cmp);
+            atomicAdd(A.stats + SC_SEED_READS, (unsigned long long)nr);
+            atomicAdd(A.stats + SC_SEED_QBYTES, (unsigned long long)(__builtin_amdgcn_readlane((int)(uint32_t)off, (int)nr) - __builtin_amdgcn_readlane((int)(uint32_t)off, 0)));
+            uint32_t lf = 0;
+            for (uint32_t i = 0; i < nr * strands; i++) lf += (fl >> (strands == 2u ? i : 2u * i)) & 1u;
+            atomicAdd(A.stats + SC_SEED_LEFT, (unsigned long long)lf);
+        }
+    }
+}
+
 // K9 for v3: inline slots and overflow records -> grouped output, BWT rows resolved to text positions here
 __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__ inl, const uint32_t* __restrict__ counts,
                                                       const uint64_t* __restrict__ item_off, uint64_t nitems,
@@ -2293,6 +2650,8 @@ struct SearchJob {
     SearchArgs A;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // before K8a, after K8, after K9, after K8a, before K8, after K7q
     bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
+    bool rawkey_marked = false;  // the overflow list already carries its "unused" marks (kChunk)
+    bool seeded = false;  // this batch's MEMs come from K8s (k_seed_mems); K8 scans only the strands it left
     bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
     unsigned long long scal_own[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t k8_wave_cap = 0;  // waves of this batch's K8 (0: as many as the chip holds); a pipeline that keeps two K8 launches in flight gives each a part of the chip
@@ -2467,11 +2826,40 @@ int SearchJob::prep(hipStream_t stream) {
     char* ws = static_cast<char*>(workspace_dev);
     unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ws + w.off_total);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
-    prefiltered = false; timed_k8 = false; launched = true;
+    prefiltered = false; timed_k8 = false; launched = true; seeded = false; rawkey_marked = false;
     (void)hipEventRecord(ev[0], stream);
     if (nitems && (match_type != 1 || mam_v3)) {
         static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
-        if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
+        // reads (no record was cut into slices, none longer on average than the seed kernel's strands), -mem, a minimum length
+        // that leaves at least four letters between two windows: K8s finds the MEMs by seed-and-compare and leaves to K8
+        // only the strands it cannot decide (SLAMEM_SEED_SEARCH=0: the prefilter and the index walk for everything)
+        static const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
+        seeded = use_seed && match_type == 0 && nitems == num_blocks && idx->view.seed && min_len >= idx->view.seed_k + 3u &&
+                 min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLen;
+        if (seeded) {
+            uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
+            // (K8's kChunk instantiation wants every place of the overflow list marked "unused" before the launch: K8s puts
+            //  records there too, so the marks come first)
+            if (mems_capacity && !A.skip_w && !want_stats && enum_chunks()) {
+                STEP(hipMemsetAsync(ws + w.off_rawkey, 0xFF, mems_capacity * sizeof(RawKey), stream), "memset");
+                rawkey_marked = true;
+            }
+            STEP(hipMemsetAsync(d_counts, 0, nitems * 4, stream), "memset");
+            STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
+            const dim3 gs(grid_for((uint64_t)num_queries, 4 * kSeedReads));
+            if (want_stats) hipLaunchKernelGGL(k_seed_mems<true>, gs, dim3(256), 0, stream, A, d_alive);
+            else hipLaunchKernelGGL(k_seed_mems<false>, gs, dim3(256), 0, stream, A, d_alive);
+            STEP(hipGetLastError(), "k_seed_mems");
+            (void)hipEventRecord(ev[3], stream);
+            prefiltered = true;
+            A.item_alive = d_alive;
+            uint32_t* d_ids = reinterpret_cast<uint32_t*>(ws + w.off_workids);
+            uint32_t* d_nwork = reinterpret_cast<uint32_t*>(d_total) + 8;  // a word of the zeroed scalar block
+            size_t need2 = w.select_bytes;
+            STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
+            A.work_ids = d_ids;
+            A.work_count = d_nwork;
+        } else if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
             uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
             if (want_stats) hipLaunchKernelGGL(k_prefilter<true>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
             else hipLaunchKernelGGL(k_prefilter<false>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
@@ -2605,7 +2993,7 @@ int SearchJob::search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_o
             chunked = true;
             // a repeat-rich text at this minimum length: the instantiation whose enumeration jobs take their places in the
             // overflow list chunk-wise (wave_emit_step); every place of the list starts as "unused"
-            if (mems_capacity) STEP(hipMemsetAsync(ws + w.off_rawkey, 0xFF, mems_capacity * sizeof(RawKey), stream), "memset");
+            if (mems_capacity && !rawkey_marked) STEP(hipMemsetAsync(ws + w.off_rawkey, 0xFF, mems_capacity * sizeof(RawKey), stream), "memset");
             if (sliced) hipLaunchKernelGGL((k_find_mems_v3<false, false, true, false, false, true>), grid8, dim3(256), 0, stream, A);
             else if (mam_v3) hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true, false, true>), grid8, dim3(256), 0, stream, A);
             else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, false, true>), grid8, dim3(256), 0, stream, A);
@@ -2759,6 +3147,9 @@ int SearchJob::collect() {
         o.enum_wave_us = c[SC_T_ENUM_SUM] / 100;
         for (int q = 0; q < 11; q++) { o.state_lane_trips[q] = c[SC_STATE_TRIPS + q]; o.state_wave_trips[q] = c[SC_STATE_WAVES + q]; }
         o.prefilter_probes = c[SC_PF_PROBES]; o.prefilter_query_loads = c[SC_PF_QUERY_LOADS]; o.prefilter_items = c[SC_PF_ITEMS];
+        o.seed_windows = c[SC_SEED_WINDOWS]; o.seed_compares = c[SC_SEED_COMPARES]; o.seed_letter_masks = c[SC_SEED_NMASKS];
+        o.seed_mems = c[SC_SEED_MEMS]; o.seed_strands_left = c[SC_SEED_LEFT]; o.seed_reads = c[SC_SEED_READS];
+        o.seed_query_bytes = c[SC_SEED_QBYTES];
         o.items = nitems;
         o.survivors = prefiltered ? nwork : nitems;
         o.mems = total;
@@ -2777,9 +3168,9 @@ int SearchJob::collect() {
     tm.t.search_kernel_ms = ms_prep + ms_k8;
     tm.t.search_kernel_ms_sum += ms_prep + ms_k8;
     tm.t.search_launches++;
-    if (prefiltered && hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) {  // K8a
-        tm.t.prefilter_ms = ms;
-        tm.t.prefilter_ms_sum += ms;
+    if (prefiltered && hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) {  // K8a, or K8s in its place
+        if (seeded) { tm.t.seed_ms = ms; tm.t.seed_ms_sum += ms; tm.t.prefilter_ms = 0; }
+        else { tm.t.prefilter_ms = ms; tm.t.prefilter_ms_sum += ms; tm.t.seed_ms = 0; }
     }
     if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) tm.t.search_total_ms = ms_prep + ms_k8 + ms;
     if (total > mems_capacity || listed > mems_capacity) {

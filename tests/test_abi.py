@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"libslamem_hip.so does not export {n}"
     assert set(names) == set(capi.ABI_SYMBOLS)
-    assert L.slamem_abi_version() == 3
+    assert L.slamem_abi_version() == 4
     assert L.slamem_strerror(0) == b"ok"
 
 
