@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slamem_amd import engine, synth, capi  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402  (checker)
 
