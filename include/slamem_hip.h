@@ -64,6 +64,8 @@ typedef struct {
     int32_t owns_arena;
     uint32_t filter_k;     /* k of the k-mer presence filter (0 = the index has none); no reference counterpart */
     uint32_t layout;       /* SLAMEM_LAYOUT_FULL or SLAMEM_LAYOUT_COMPACT: what the build chose (ABI 2: reserved, 0)   */
+    uint32_t seed_k;       /* letters of a seed of the seed-and-compare sections (0 = the index has none); ABI 4; no reference counterpart */
+    uint32_t reserved1;
 } slamem_index_info;
 
 /* Index layouts (no reference counterpart: the reference has one layout of 3.3 B per letter made for CPU caches,

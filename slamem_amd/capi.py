@@ -57,7 +57,7 @@ class IndexInfo(C.Structure):
     _fields_ = [("text_length", C.c_uint32), ("bwt_size", C.c_uint32), ("num_n_rows", C.c_uint32),
                 ("dollar_row", C.c_uint32), ("max_lcp", C.c_uint32), ("sort_rounds", C.c_uint32),
                 ("arena_bytes", C.c_uint64), ("device", C.c_int32), ("owns_arena", C.c_int32),
-                ("filter_k", C.c_uint32), ("layout", C.c_uint32)]
+                ("filter_k", C.c_uint32), ("layout", C.c_uint32), ("seed_k", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class SslcpStats(C.Structure):

@@ -260,6 +260,8 @@ int slamem_index_get_info(const slamem_index* idx, slamem_index_info* out) {
     out->device = idx->device;
     out->owns_arena = idx->owns_arena;
     out->filter_k = idx->hdr.off_kfilter ? idx->hdr.kfilter_k : 0u;
+    out->seed_k = idx->hdr.off_seed ? idx->hdr.seed_k : 0u;
+    out->reserved1 = 0u;
     out->layout = idx->hdr.layout == 2u ? SLAMEM_LAYOUT_COMPACT : SLAMEM_LAYOUT_FULL;
     return SLAMEM_OK;
 }

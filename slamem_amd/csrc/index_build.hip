@@ -1275,6 +1275,27 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
                            hdr.kbits_k, d_bits);
         SLAMEM_HIP(hipGetLastError());
     }
+    if (hdr.off_seed) {  // text bit-planes, then the seed table by sorting the positions by bucket (the sort's buffers are free).
+                         // BEFORE the presence filter is built: the B buffers may lie in the filter's region
+        const uint64_t units = text_units(n);
+        TextPlanes* d_tpl = reinterpret_cast<TextPlanes*>(base + hdr.off_tpl);
+        uint64_t* d_tnm = reinterpret_cast<uint64_t*>(base + hdr.off_tnm);
+        uint64_t* d_tnb = reinterpret_cast<uint64_t*>(base + hdr.off_tnb);
+        SeedBucket* d_seed = reinterpret_cast<SeedBucket*>(base + hdr.off_seed);
+        SLAMEM_HIP(hipMemsetAsync(d_tnb, 0, (units / 64 + 1) * 8, stream));
+        hipLaunchKernelGGL(k_text_planes, dim3(grid_for(units + 63)), dim3(256), 0, stream, pk.as<uint64_t>(), n, units, d_tpl, d_tnm, d_tnb);
+        hipLaunchKernelGGL(k_seed_keys, dim3(grid_for(n)), dim3(256), 0, stream, (const TextPlanes*)d_tpl, (const uint64_t*)d_tnm, n,
+                           hdr.seed_k, hdr.seed_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>());
+        SLAMEM_HIP(hipGetLastError());
+        need = tmp_bytes;
+        SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysB.as<uint64_t>(), keysA.as<uint64_t>(), valsB.as<uint32_t>(),
+                                      valsA.as<uint32_t>(), n, 8, (int)hdr.seed_log2 + 8 + 1, stream));
+        SLAMEM_HIP(hipMemsetAsync(d_seed, 0, sizeof(SeedBucket) << hdr.seed_log2, stream));
+        hipLaunchKernelGGL(k_seed_fill, dim3(grid_for(n)), dim3(256), 0, stream, (const uint64_t*)keysA.as<uint64_t>(),
+                           (const uint32_t*)valsA.as<uint32_t>(), (uint64_t)n, hdr.seed_log2, d_seed);
+        SLAMEM_HIP(hipGetLastError());
+        mark("K1d seed table");
+    }
     if (hdr.off_kfilter) {
         unsigned long long* d_filter = reinterpret_cast<unsigned long long*>(base + hdr.off_kfilter);
         static const bool env_atomic = [] { const char* v = getenv("SLAMEM_KFILTER_ATOMIC"); return v && atoi(v) != 0; }();
@@ -1304,26 +1325,6 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
 
 
     mark("K1b filter fill");
-    if (hdr.off_seed) {  // text bit-planes, then the seed table by sorting the positions by bucket (the sort's buffers are free)
-        const uint64_t units = text_units(n);
-        TextPlanes* d_tpl = reinterpret_cast<TextPlanes*>(base + hdr.off_tpl);
-        uint64_t* d_tnm = reinterpret_cast<uint64_t*>(base + hdr.off_tnm);
-        uint64_t* d_tnb = reinterpret_cast<uint64_t*>(base + hdr.off_tnb);
-        SeedBucket* d_seed = reinterpret_cast<SeedBucket*>(base + hdr.off_seed);
-        SLAMEM_HIP(hipMemsetAsync(d_tnb, 0, (units / 64 + 1) * 8, stream));
-        hipLaunchKernelGGL(k_text_planes, dim3(grid_for(units + 63)), dim3(256), 0, stream, pk.as<uint64_t>(), n, units, d_tpl, d_tnm, d_tnb);
-        hipLaunchKernelGGL(k_seed_keys, dim3(grid_for(n)), dim3(256), 0, stream, (const TextPlanes*)d_tpl, (const uint64_t*)d_tnm, n,
-                           hdr.seed_k, hdr.seed_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>());
-        SLAMEM_HIP(hipGetLastError());
-        need = tmp_bytes;
-        SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysB.as<uint64_t>(), keysA.as<uint64_t>(), valsB.as<uint32_t>(),
-                                      valsA.as<uint32_t>(), n, 8, (int)hdr.seed_log2 + 8 + 1, stream));
-        SLAMEM_HIP(hipMemsetAsync(d_seed, 0, sizeof(SeedBucket) << hdr.seed_log2, stream));
-        hipLaunchKernelGGL(k_seed_fill, dim3(grid_for(n)), dim3(256), 0, stream, (const uint64_t*)keysA.as<uint64_t>(),
-                           (const uint32_t*)valsA.as<uint32_t>(), (uint64_t)n, hdr.seed_log2, d_seed);
-        SLAMEM_HIP(hipGetLastError());
-        mark("K1d seed table");
-    }
     // ---- K3: BWT planes + rank samples ------------------------------------------------------------
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
     SLAMEM_HIP(hipMemsetAsync(d_fm, 0, (uint64_t)nblocks * sizeof(FMBlock), stream));

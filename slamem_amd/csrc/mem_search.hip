@@ -2833,7 +2833,8 @@ int SearchJob::prep(hipStream_t stream) {
         // reads (no record was cut into slices, none longer on average than the seed kernel's strands), -mem, a minimum length
         // that leaves at least four letters between two windows: K8s finds the MEMs by seed-and-compare and leaves to K8
         // only the strands it cannot decide (SLAMEM_SEED_SEARCH=0: the prefilter and the index walk for everything)
-        static const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
+        // (read per call, not once per process: the tests run both paths in one process)
+        const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
         seeded = use_seed && match_type == 0 && nitems == num_blocks && idx->view.seed && min_len >= idx->view.seed_k + 3u &&
                  min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLen;
         if (seeded) {

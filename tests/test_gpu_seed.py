@@ -1,0 +1,308 @@
+"""K8s (k_seed_mems: seed-and-compare for reads, slamem_amd/csrc/mem_search.hip) against the oracle, in emission order, on the
+inputs that decide whether it is exact: windows that occur several times, ties that need the suffix order, palindromic
+windows, letters that are not A,C,G,T in the reads and in the text, the ends of the text, matches that are barely long
+enough, reads of every length in one batch.  Each case also says -- from the kernel's own counters -- that the seed path
+really ran and how many strands it left to the index walk (K8)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.arange(256, dtype=np.uint8)
+for _u, _v in zip(b"ACGTacgt", b"TGCAtgca"):
+    COMP[_u] = _v
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (there is no CPU path)")
+    from slamem_amd import engine
+    return engine
+
+
+def rc(a):
+    return COMP[a[::-1]]
+
+
+def pack(qs):
+    q = np.concatenate(qs) if qs else np.zeros(0, dtype=np.uint8)
+    off = np.zeros(len(qs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in qs])
+    return q, off
+
+
+def mutate(rng, a, rate):
+    a = a.copy()
+    m = rng.random(len(a)) < rate
+    a[m] = rng.choice(ACGT, size=int(m.sum()))
+    return a
+
+
+def seed_stats(eng, idx, q, off, l, both):
+    import ctypes as C
+    from slamem_amd import capi
+    L = capi.lib()
+    L.slamem_search_stats_enable(1)
+    try:
+        idx.find_mems(q, off, l, both)
+        st = capi.SearchStats()
+        capi.check(L.slamem_get_search_stats(C.byref(st)))
+    finally:
+        L.slamem_search_stats_enable(0)
+    return st.as_dict()
+
+
+def normalised(a):
+    """What the reference's loader hands to GetMatches (sequence.c:61-81): upper case, every other letter N."""
+    u = np.frombuffer(a.tobytes().upper(), dtype=np.uint8).copy()
+    u[~np.isin(u, ACGT)] = ord("N")
+    return u
+
+
+def check(eng, text, qs, l, both, expect_seed=True, max_left_frac=None, min_left=0):
+    """engine == oracle in order (counters instantiation too); returns the counters.  The engine gets the reads as they are
+    (any case, any letter), the oracle the normalised ones."""
+    from oracle import pyoracle as po
+    text = text.tobytes() if isinstance(text, np.ndarray) else text
+    q, off = pack(qs)
+    o = po.OracleIndex(text)
+    om, obc = o.match_batch(pack([normalised(x) for x in qs])[0], off, l, both)
+    g = eng.Index.build(text)
+    try:
+        gm, goff = g.find_mems(q, off, l, both)
+        assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+        for f in ("ref_pos", "query_pos", "length"):
+            assert np.array_equal(gm[f], om[f]), f
+        st = seed_stats(eng, g, q, off, l, both)
+        assert st["mems"] == len(om)
+        if expect_seed:
+            assert g.info.seed_k >= 4 and l >= g.info.seed_k + 3
+            assert st["seed_reads"] == len(qs), "the seed path did not take this batch"
+            assert st["survivors"] == st["seed_strands_left"]
+            if max_left_frac is not None:
+                assert st["seed_strands_left"] <= max_left_frac * st["items"], st
+            assert st["seed_strands_left"] >= min_left, st
+        else:
+            assert st["seed_reads"] == 0
+        st["seed_k"] = int(g.info.seed_k)
+        return st, om
+    finally:
+        g.close()
+
+
+def reads_from(rng, t, count, length, sub, rc_share=0.5):
+    out = []
+    for _ in range(count):
+        x = int(rng.integers(0, len(t) - length + 1))
+        r = mutate(rng, t[x:x + length], sub)
+        out.append(rc(r) if rng.random() < rc_share else r)
+    return out
+
+
+@pytest.mark.parametrize("n,count,length,l,both,sub", [
+    (200_000, 2000, 150, 20, True, 0.02), (200_000, 2000, 150, 20, False, 0.02), (300_000, 3000, 150, 50, True, 0.02),
+    (100_000, 3000, 36, 20, True, 0.02), (100_000, 1000, 192, 25, True, 0.02), (5_000, 500, 80, 20, True, 0.02),
+    (200_000, 3000, 150, 18, True, 0.08), (1_000_000, 20_000, 150, 20, True, 0.02), (70_000, 1000, 101, 33, True, 0.0)])
+def test_reads_on_random_text(eng, n, count, length, l, both, sub):
+    rng = np.random.default_rng(n + count + l)
+    t = rng.choice(ACGT, size=n)
+    st, om = check(eng, t, reads_from(rng, t, count, length, sub, 0.5 if both else 0.0), l, both, max_left_frac=0.02)
+    assert st["seed_windows"] > 0 and st["seed_mems"] >= 0.95 * len(om)
+
+
+def test_reads_longer_than_the_planes_go_to_the_index_walk(eng):
+    """193 letters: one more than the three plane words hold.  A batch of them does not qualify at all (the prefilter and the
+    index walk take it); mixed with shorter reads the seed kernel leaves them, strand by strand."""
+    rng = np.random.default_rng(193)
+    t = rng.choice(ACGT, size=100_000)
+    st, _ = check(eng, t, reads_from(rng, t, 300, 193, 0.02), 25, True, expect_seed=False)
+    qs = reads_from(rng, t, 300, 193, 0.02) + reads_from(rng, t, 900, 100, 0.02) + reads_from(rng, t, 20, 400, 0.02)
+    order = rng.permutation(len(qs))
+    st, _ = check(eng, t, [qs[i] for i in order], 25, True, min_left=2 * 320)
+    assert st["seed_strands_left"] <= 2 * 320 + 40
+
+
+def test_every_read_length_in_one_batch(eng):
+    """Lengths 0 .. 192 (and a few beyond), several reads of each, shuffled: windows per read from none to the most a wave
+    holds, reads shorter than the seed and than the minimum length, empty records."""
+    rng = np.random.default_rng(7)
+    t = rng.choice(ACGT, size=150_000)
+    qs = []
+    for length in list(range(0, 193)) + [193, 200, 255, 256, 300]:
+        for _ in range(3):
+            qs += reads_from(rng, t, 1, length, 0.02) if length else [np.zeros(0, dtype=np.uint8)]
+    order = rng.permutation(len(qs))
+    for l in (14, 20, 31):
+        st, _ = check(eng, t, [qs[i] for i in order], l, True)
+
+
+def test_ends_of_the_text_and_reads_hanging_over_them(eng):
+    """Reads cut from the first / last letters of the text, and reads that run past either end (their diagonals start before
+    position 0 or end behind n): maximality by the text boundary, compares with letters that face no text."""
+    rng = np.random.default_rng(11)
+    n = 50_000
+    t = rng.choice(ACGT, size=n)
+    qs = []
+    for k in range(60):
+        a = int(rng.integers(20, 120))
+        junk = rng.choice(ACGT, size=int(rng.integers(1, 60)))
+        qs += [t[:a].copy(), t[n - a:].copy(), rc(t[:a]), rc(t[n - a:]),
+               np.concatenate([junk, t[:a]]), np.concatenate([t[n - a:], junk]), rc(np.concatenate([junk, t[:a]])),
+               mutate(rng, np.concatenate([t[n - a:], junk]), 0.03)]
+    check(eng, t, qs, 20, True, max_left_frac=0.05)
+
+
+def test_letters_that_are_not_acgt(eng):
+    """N in reads (the strand goes to the index walk: N equals N in the reference, A.1), N runs and single N in the text (a
+    compare whose units hold one reads the letter masks), lower case and IUPAC letters on both sides."""
+    rng = np.random.default_rng(13)
+    n = 80_000
+    t = rng.choice(ACGT, size=n)
+    for _ in range(6):
+        p = int(rng.integers(100, n - 400))
+        t[p:p + int(rng.integers(1, 200))] = ord("N")
+    for _ in range(40):
+        t[int(rng.integers(0, n))] = ord("N")
+    qs = reads_from(rng, t, 1500, 120, 0.02)
+    for i in range(0, len(qs), 9):
+        qs[i] = qs[i].copy()
+        qs[i][int(rng.integers(0, 120))] = ord("NRYKMnrw"[i % 8])
+    for i in range(1, len(qs), 50):
+        qs[i] = np.frombuffer(qs[i].tobytes().lower(), dtype=np.uint8)  # lower case is A,C,G,T all the same
+    st, _ = check(eng, t, qs, 20, True)
+    assert st["seed_letter_masks"] > 0 and st["seed_strands_left"] >= 2 * (len(qs) // 9)
+
+
+def test_windows_that_occur_several_times_and_ties(eng):
+    """Segments of the text in 2, 3, 5, 13 and 40 exact copies and reads from them: every copy is a hit of every window (up to
+    12 per bucket; beyond, the strand is left to the index walk), equal-length MEMs with equal starts tie and need the suffix
+    order (left to the index walk), nested repeats give MEMs with equal starts and different lengths (ranked here)."""
+    rng = np.random.default_rng(17)
+    n = 300_000
+    t = rng.choice(ACGT, size=n)
+    segs = []
+    for copies, length in [(2, 400), (3, 300), (5, 200), (13, 150), (40, 120)]:
+        x = int(rng.integers(0, n - length))
+        seg = t[x:x + length].copy()
+        segs.append(seg)
+        for _ in range(copies - 1):
+            y = int(rng.integers(0, n - length))
+            t[y:y + length] = seg
+    # nested: a copy of the first segment's middle part only
+    y = int(rng.integers(0, n - 100))
+    t[y:y + 100] = segs[0][150:250]
+    qs = reads_from(rng, t, 1500, 150, 0.02)
+    for seg in segs:
+        for _ in range(60):
+            a = int(rng.integers(0, len(seg) - 100))
+            r = mutate(rng, seg[a:a + 100 + int(rng.integers(0, min(50, len(seg) - a - 100) + 1))], 0.01)
+            qs.append(rc(r) if rng.random() < 0.5 else r)
+    st, _ = check(eng, t, qs, 20, True, min_left=100)
+    assert st["seed_mems"] > 1500
+
+
+def test_palindromic_windows(eng):
+    """A window that equals its own reverse complement (even seed length) hits BOTH strands at one text position: the read is
+    left to the index walk.  Planted so that a window of the read starts exactly on the palindrome."""
+    rng = np.random.default_rng(19)
+    n = 300_000  # 2^18 < n <= 2^19: seed_k = 12
+    t = rng.choice(ACGT, size=n)
+    pal = np.frombuffer(b"ACGTACGTACGT", dtype=np.uint8)
+    assert np.array_equal(rc(pal), pal)
+    spots = [int(x) for x in rng.integers(1000, n - 1000, size=30)]
+    for x in spots:
+        t[x:x + 12] = pal
+    l = 21  # s = 10
+    qs = reads_from(rng, t, 500, 150, 0.02)
+    for x in spots:
+        for w in (0, 1, 5):  # the palindrome at a window start (offset 10 * w) of the read
+            r = t[x - 10 * w: x - 10 * w + 150].copy()
+            qs += [r, rc(r)]
+    st, _ = check(eng, t, qs, l, True, min_left=2 * 30)
+    assert st["seed_k"] == 12
+
+
+@pytest.mark.parametrize("l", [13, 14, 15, 16, 17, 18, 19, 20, 21, 25, 40])
+def test_matches_that_are_barely_long_enough(eng, l):
+    """Strands whose ONLY match is l .. l+3 letters long, at the strand's ends, in the middle, on both strands: the windows at
+    multiples of s = l - k + 1 must catch each of them (the counterpart of test_prefilter_never_drops_...)."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(900 + l)
+    n = 50_001
+    t = rng.choice(ACGT, size=n)
+    qs = []
+    for qlen in (150, 64, 192):
+        for d in range(4):
+            for at in [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 30, 31, 32, 33, None]:
+                m = l + d
+                pos = qlen - m if at is None else at
+                if pos + m > qlen:
+                    continue
+                q = rng.choice(ACGT, size=qlen)
+                x = int(rng.integers(1, n - m - 1))
+                q[pos:pos + m] = t[x:x + m]
+                if pos > 0:
+                    q[pos - 1] = ACGT[(int(np.searchsorted(ACGT, t[x - 1])) + 1) % 4]
+                if pos + m < qlen:
+                    q[pos + m] = ACGT[(int(np.searchsorted(ACGT, t[x + m])) + 1) % 4]
+                qs.append(q if (len(qs) % 2 == 0) else rc(q))
+    st, om = check(eng, t, qs, l, True)
+    assert st["seed_k"] == 10 and len(om) >= len(qs)
+
+
+def test_satellite_fills_its_buckets(eng):
+    """A tandem array (one unit 2,000 times) puts thousands of positions into the buckets of its k-mers (count 13 = more than
+    fit): reads from it, and reads that merely share one window with it, are left to the index walk; the others are not."""
+    rng = np.random.default_rng(23)
+    n = 400_000
+    t = rng.choice(ACGT, size=n)
+    unit = rng.choice(ACGT, size=37)
+    t[50_000:50_000 + 37 * 2000] = np.tile(unit, 2000)
+    qs = reads_from(rng, t, 1200, 150, 0.02)
+    chim = []
+    for _ in range(50):  # 20 letters of the array inside an ordinary read
+        x = int(rng.integers(200_000, n - 200))
+        r = t[x:x + 150].copy()
+        a = int(rng.integers(0, 130))
+        r[a:a + 20] = np.tile(unit, 2)[3:23]
+        chim.append(r)
+    st, _ = check(eng, t, qs + chim, 30, True)
+    assert 0 < st["seed_strands_left"] < st["items"]
+
+
+def test_forward_only_ignores_the_other_strand(eng):
+    """Without -b the reverse-complement hits of a window are dropped before any compare."""
+    rng = np.random.default_rng(29)
+    t = rng.choice(ACGT, size=120_000)
+    qs = reads_from(rng, t, 1000, 150, 0.02, rc_share=1.0)  # every read comes from the other strand
+    st, om = check(eng, t, qs, 20, False)
+    assert len(om) < 20 and st["seed_compares"] < 3000  # (chance forward hits only; the true ones are all on the other strand)
+
+
+def test_full_size_headline_both_paths_agree_in_order(eng):
+    """BASELINE.json configs[2] at full size through both paths: the seed path's 24,216,704 MEMs are the index walk's, row for
+    row in the same order (the walk's order is the oracle's on every sample checked; its set is the REAL reference's digest in
+    test_config3_known_answer_full_size), and nearly every strand is answered by K8s itself."""
+    import torch
+    from conftest import search_path
+    n, nreads, L = 100_000_000, 10_000_000, 150
+    ref = eng.synth_reference(n, 42, "cuda:0")
+    reads = eng.synth_reads(ref, 0, nreads, L, 0.02, 42, 50)
+    offsets = torch.arange(nreads + 1, dtype=torch.int64, device="cuda:0") * L
+    idx = eng.Index.build(ref, "cuda:0")
+    m = idx.matcher(nreads, True, 4 * nreads, nreads * L)
+    with search_path("seed"):
+        total = m.run(reads, offsets, 20)
+    assert total == 24_216_704
+    seed_mems = m.mems[:total].clone()
+    seed_off = m.block_offsets.clone()
+    with search_path("walk"):
+        assert m.run(reads, offsets, 20) == total
+    assert torch.equal(seed_off, m.block_offsets) and torch.equal(seed_mems, m.mems[:total])
+    with search_path("seed"):
+        st = eng.search_stats(m, reads, offsets, 20)
+    assert st["seed_reads"] == nreads and st["seed_windows"] == 27 * nreads and st["seed_strands_left"] < 0.01 * 2 * nreads
+    idx.close()

@@ -64,10 +64,13 @@ def test_random_case_matches_oracle_in_order(seed, mam):
     om, obc = o.match_batch(q, off, l, both, mam=mam)
     assert len(om) <= 3_000_000  # all 80 cases run: the largest of these seeds has 590,034 MEMs (checked on the CPU)
     g = engine.Index.build(text)
-    gm, goff = g.find_mems(q, off, l, both, mam=mam)
-    assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64)), (len(text), l, both)
-    for f in ("ref_pos", "query_pos", "length"):
-        assert np.array_equal(gm[f], om[f]), (f, len(text), l, both)
+    from conftest import search_path
+    for path in (("seed", "walk") if not mam else ("seed",)):  # (-mam never takes the seed path)
+        with search_path(path):
+            gm, goff = g.find_mems(q, off, l, both, mam=mam)
+        assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64)), (len(text), l, both, path)
+        for f in ("ref_pos", "query_pos", "length"):
+            assert np.array_equal(gm[f], om[f]), (f, len(text), l, both, path)
     g.close()
 
 
