@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libslamem_hip.so")
+# SLAMEM_HIP_LIB: another build of the same library (tools/variants.sh builds A/B variants of a kernel beside the product's
+# library instead of over it; the product path never sets it)
+LIB_PATH = os.environ.get("SLAMEM_HIP_LIB") or os.path.join(_HERE, "csrc", "libslamem_hip.so")
 SYNTH_PATH = os.path.join(_HERE, "csrc", "libslamem_synth.so")
 
 SLAMEM_OK = 0

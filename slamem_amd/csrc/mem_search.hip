@@ -2076,10 +2076,13 @@ __global__ void __launch_bounds__(256, SLAMEM_PF_WAVES) k_prefilter(SearchArgs A
 // holds (a repeat: its rows need the suffix order), a palindromic window that hits,
 // two MEMs of a strand with the same start and length (their order is the order of their BWT rows).  Nothing here is
 // approximate: a strand is either reported completely by this kernel or completely by K8.
-constexpr uint32_t kSeedReads = 16;     // reads of a wave
+#ifndef SLAMEM_SEED_READS
+#define SLAMEM_SEED_READS 16
+#endif
+constexpr uint32_t kSeedReads = SLAMEM_SEED_READS;     // reads of a wave (at most 16: a flag word holds two bits per read)
 constexpr uint32_t kSeedMaxLen = 192;   // letters of a strand the planes hold (three words)
-constexpr uint32_t kSeedJobs = 256;     // compares of one trip
-constexpr uint32_t kSeedMems = 128;     // MEMs of one trip
+constexpr uint32_t kSeedJobs = 256;     // compares of one wave
+constexpr uint32_t kSeedMems = 192;     // MEMs of one wave
 
 struct SeedWave {
     uint64_t pl[kSeedReads][2][2][4];   // [read][strand][plane][word]; word 3 stays 0 (a window's second word)
@@ -2119,8 +2122,11 @@ __device__ __forceinline__ uint32_t byte_tops(uint32_t m) {
     return (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xFu;
 }
 
+#ifndef SLAMEM_SEED_WAVES
+#define SLAMEM_SEED_WAVES 1
+#endif
 template <bool kStats>
-__global__ void __launch_bounds__(256) k_seed_mems(SearchArgs A, uint8_t* __restrict__ alive) {
+__global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs A, uint8_t* __restrict__ alive) {
     __shared__ SeedWave lds[4];
     __shared__ uint8_t lut[256];  // ASCII -> 2-bit code | 4 (one of A,C,G,T), or 8
     {
@@ -2218,6 +2224,9 @@ __global__ void __launch_bounds__(256) k_seed_mems(SearchArgs A, uint8_t* __rest
         if (__ballot(nwin > t)) { slots = 2u * t; lg_slots = lg; }
     const uint32_t rpt = slots ? 64u / slots : kSeedReads;  // reads per trip
 
+    // Phase 1 for every trip first (the trips are independent: their table lines are in flight together), then ONE pass of
+    // compares over the wave's jobs and one ranking of its MEMs -- those run with most lanes busy instead of a few per trip.
+    uint32_t njobs = 0;
     if (slots)
     for (uint32_t t0 = 0; t0 < nr; t0 += rpt) {
         // ---- phase 1: one lane per window: the seed table line of its canonical form -----------------------------------
@@ -2268,7 +2277,8 @@ __global__ void __launch_bounds__(256) k_seed_mems(SearchArgs A, uint8_t* __rest
             pn = __shfl_up(nm, 1); pp1 = __shfl_up(p1, 1); pp2 = __shfl_up(p2, 1); ps1 = __shfl_up(st1, 1); ps2 = __shfl_up(st2, 1);
             if (wi == 0u) pn = 0;
         }
-        uint32_t njobs = 0, rem = hits;
+        const uint32_t njobs0 = njobs;
+        uint32_t rem = hits;
         for (uint32_t it = 0; __ballot(rem != 0u) != 0ull; it++) {
             const bool hv = rem != 0u;
             const uint32_t e = it == 0u ? e1 : it == 1u ? e2 : hv ? (uint32_t)__ffs((int)rem) - 1u : 0u;
@@ -2285,12 +2295,16 @@ __global__ void __launch_bounds__(256) k_seed_mems(SearchArgs A, uint8_t* __rest
             }
             njobs += (uint32_t)__popcll(qb);
         }
-        if (njobs > kSeedJobs) {  // (many repeated windows in one trip) every read of the trip is left to K8
+        if (njobs > kSeedJobs) {  // (many repeated windows) every read of this trip is left to K8
             for (uint32_t i = t0; i < t0 + rpt && i < kSeedReads; i++) wflags |= 3u << (2u * i);
-            njobs = 0;
+            njobs = njobs0;
         }
-        wave_sync();
-
+    }
+    wave_sync();
+#ifdef SLAMEM_SEED_DIAG_NO_COMPARE   // (timing experiments only: wrong results)
+    njobs = 0;
+#endif
+    {
         // ---- phase 2: one lane per compare: the strand against the text on the hit's diagonal --------------------------
         uint32_t nmems = 0;
         for (uint32_t jb = 0; jb < njobs; jb += 64u) {
@@ -2362,32 +2376,51 @@ __global__ void __launch_bounds__(256) k_seed_mems(SearchArgs A, uint8_t* __rest
         if (nmems > kSeedMems) nmems = kSeedMems;
         wave_sync();
 
-        // ---- phase 3: the strand's MEMs in the reference's emission order --------------------------------------------------
+        // ---- phase 3: the strands' MEMs in the reference's emission order ------------------------------------------------
+        // rank of a MEM = MEMs of its strand that come before it (greater start, or equal start and greater length); MEMs of a
+        // strand that tie (same start, same length) leave the strand to K8
         const uint32_t g0 = (uint32_t)(r0 * strands);
-        for (uint32_t pass = 0; pass < 2u; pass++) {   // 0: MEMs of a strand that tie (same start, same length) leave it to K8;  1: emit
-            const uint32_t fl = pass ? (S.flags | wflags) : 0u;
-            for (uint32_t m0i = 0; m0i < nmems; m0i += 64u) {
-                const uint32_t mi = m0i + lane;
-                const bool has = mi < nmems;
-                const uint32_t key = has ? S.mem_key[mi] : 0u, ref = has ? S.mem_ref[mi] : 0u, g = has ? S.mem_g[mi] : 0xFFFFFFFFu;
-                uint32_t rank = 0, cnt = 0;
-                bool tie = false;
-                for (uint32_t t2 = 0; t2 < nmems; t2++) {
-                    const uint32_t kk = S.mem_key[t2], gg = S.mem_g[t2];
-                    const bool same = gg == g;
-                    cnt += same ? 1u : 0u;
-                    rank += (same && kk > key) ? 1u : 0u;
-                    tie = tie || (same && kk == key && t2 != mi);
-                }
-                const uint32_t bit = strands == 2u ? g - g0 : 2u * (g - g0);
-                if (!pass) { if (has && tie) atomicOr(&S.flags, 1u << bit); }
-                else if (has && !((fl >> bit) & 1u)) {
-                    emit3_at(A, g, rank, 0u, ref, key >> 16, (key & 0xFFFFu) | 0x80000000u);  // bit 31: ref_pos is the text position (K9)
-                    if (rank == 0u) A.block_counts[g] = cnt;
-                    if (kStats) n_mem++;
-                }
+        auto rank_of = [&](uint32_t mi, uint32_t key, uint32_t g, uint32_t& rank, uint32_t& cnt, bool& tie) {
+            rank = 0; cnt = 0; tie = false;
+            for (uint32_t t2 = 0; t2 < nmems; t2++) {
+                const uint32_t kk = S.mem_key[t2], gg = S.mem_g[t2];
+                const bool same = gg == g;
+                cnt += same ? 1u : 0u;
+                rank += (same && kk > key) ? 1u : 0u;
+                tie = tie || (same && kk == key && t2 != mi);
             }
+        };
+        auto emit_mem = [&](uint32_t fl, uint32_t key, uint32_t ref, uint32_t g, uint32_t rank, uint32_t cnt) {
+            const uint32_t bit = strands == 2u ? g - g0 : 2u * (g - g0);
+            if ((fl >> bit) & 1u) return;
+            emit3_at(A, g, rank, 0u, ref, key >> 16, (key & 0xFFFFu) | 0x80000000u);  // bit 31: ref_pos is the text position (K9)
+            if (rank == 0u) A.block_counts[g] = cnt;
+            if (kStats) n_mem++;
+        };
+        if (nmems <= 64u) {  // the usual case: one MEM per lane, one loop
+            const bool has = lane < nmems;
+            const uint32_t key = has ? S.mem_key[lane] : 0u, ref = has ? S.mem_ref[lane] : 0u, g = has ? S.mem_g[lane] : 0xFFFFFFFFu;
+            uint32_t rank, cnt;
+            bool tie;
+            rank_of(lane, key, g, rank, cnt, tie);
+            if (has && tie) atomicOr(&S.flags, 1u << (strands == 2u ? g - g0 : 2u * (g - g0)));
             wave_sync();
+            if (has) emit_mem(S.flags | wflags, key, ref, g, rank, cnt);
+        } else {
+            for (uint32_t pass = 0; pass < 2u; pass++) {
+                const uint32_t fl = pass ? (S.flags | wflags) : 0u;
+                for (uint32_t m0i = 0; m0i < nmems; m0i += 64u) {
+                    const uint32_t mi = m0i + lane;
+                    const bool has = mi < nmems;
+                    const uint32_t key = has ? S.mem_key[mi] : 0u, ref = has ? S.mem_ref[mi] : 0u, g = has ? S.mem_g[mi] : 0xFFFFFFFFu;
+                    uint32_t rank, cnt;
+                    bool tie;
+                    rank_of(mi, key, g, rank, cnt, tie);
+                    if (!pass) { if (has && tie) atomicOr(&S.flags, 1u << (strands == 2u ? g - g0 : 2u * (g - g0))); }
+                    else if (has) emit_mem(fl, key, ref, g, rank, cnt);
+                }
+                wave_sync();
+            }
         }
     }
     wave_sync();
