@@ -148,6 +148,11 @@ typedef struct {
     uint64_t seed_strands_left;     /* K8s: strands left to the index walk (K8)                                                       */
     uint64_t seed_reads;            /* K8s: reads screened                                                                            */
     uint64_t seed_query_bytes;      /* K8s: bytes of the reads it packed                                                              */
+    /* K8s: events that left a read / strand to K8: [0] reads left before any lookup (longer than the kernel's strands, a letter
+     * that is not A,C,G,T; also the reads of a wave whose compares did not fit), [1] windows whose bucket holds more k-mers than
+     * it has slots, [2] palindromic windows that hit, [3] waves whose compares did not fit, [4] inconsistent hits (never),
+     * [5] MEMs beyond the wave's list, [6] MEMs that tie with another of their strand (same start, same length)               */
+    uint64_t seed_left_why[7];
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

@@ -939,7 +939,7 @@ enum : uint32_t {
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
     SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
     SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_T_ENUM_SUM, SC_STATE_TRIPS /* 11 words: lane trips per state */, SC_STATE_WAVES = SC_STATE_TRIPS + 11 /* 11 words: wave trips in which some lane is in the state */,
-    SC_SEED_WINDOWS = SC_STATE_WAVES + 11, SC_SEED_COMPARES, SC_SEED_NMASKS, SC_SEED_MEMS, SC_SEED_LEFT, SC_SEED_READS, SC_SEED_QBYTES, SC_COUNT
+    SC_SEED_WINDOWS = SC_STATE_WAVES + 11, SC_SEED_COMPARES, SC_SEED_NMASKS, SC_SEED_MEMS, SC_SEED_LEFT, SC_SEED_READS, SC_SEED_QBYTES, SC_SEED_WHY /* 7 words: why a read / strand was left */, SC_COUNT = SC_SEED_WHY + 7
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -2088,8 +2088,15 @@ struct SeedWave {
     uint64_t pl[kSeedReads][2][2][4];   // [read][strand][plane][word]; word 3 stays 0 (a window's second word)
     uint32_t len[kSeedReads];           // letters (0: the read takes no part)
     uint32_t nwin[kSeedReads];          // windows
-    uint32_t job_p[kSeedJobs], job_x[kSeedJobs];
-    uint32_t mem_key[kSeedMems], mem_ref[kSeedMems], mem_g[kSeedMems];
+    union {
+        // first the wave's reads as they are (their bytes, 16-byte chunks of the query buffer), while the planes are made ...
+        uint4 raw[kSeedReads * kSeedMaxLen / 16 + 1];
+        // ... then the compares and the MEMs
+        struct {
+            uint32_t job_p[kSeedJobs], job_x[kSeedJobs];
+            uint32_t mem_key[kSeedMems], mem_ref[kSeedMems], mem_g[kSeedMems];
+        };
+    };
     uint32_t flags;                     // bit 2 * read + strand: the strand is left to K8
     uint32_t pad[3];
 };
@@ -2166,6 +2173,21 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     if (lane == 0u) S.flags = 0u;
     const uint32_t plen = nwin ? len : 0u;
     const uint8_t* qbytes = reinterpret_cast<const uint8_t*>(A.qwords);
+    // The wave's reads lie next to each other in the query buffer: all their 16-byte chunks are fetched at once into LDS (a few
+    // wide loads in flight together) and the letters are taken from there.  (Letter by letter from global memory, each round
+    // of 64 letters waited for its own 64-byte load: the kernel spent half its time there.)  A wave whose reads span more than
+    // the buffer holds (a long record among them) reads them from global memory.
+    const uint64_t span0 = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, 0), (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), 0));
+    const uint64_t span1 = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)nr), (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)nr));
+    const uint64_t chunk0 = span0 >> 4;
+    const uint32_t nchunks = span1 > span0 ? (uint32_t)(((span1 - 1u) >> 4) - chunk0 + 1u) : 0u;
+    const bool staged = nchunks <= kSeedReads * kSeedMaxLen / 16u + 1u;
+    if (staged) {
+        const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + chunk0;
+        for (uint32_t c = lane; c < nchunks; c += 64u) S.raw[c] = src[c];
+    }
+    wave_sync();
+    const uint8_t* rawbytes = reinterpret_cast<const uint8_t*>(S.raw);
     for (uint32_t i = 0; i < nr; i++) {
         const uint32_t Li = (uint32_t)__builtin_amdgcn_readlane((int)plen, (int)i);
         uint32_t keep_len = Li, keep_win = (uint32_t)__builtin_amdgcn_readlane((int)nwin, (int)i);
@@ -2178,7 +2200,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             for (uint32_t j = 0; j < 3u; j++) {
                 const uint32_t x = 64u * j + lane;
                 uint32_t v = 0;
-                if (x < Li) v = lut[qbytes[base + x]];
+                if (x < Li) v = lut[staged ? rawbytes[(uint32_t)(base - (chunk0 << 4)) + x] : qbytes[base + x]];
                 f0[j] = __ballot((v & 1u) != 0u);
                 f1[j] = __ballot((v & 2u) != 0u);
                 other |= __ballot((v & 8u) != 0u);
@@ -2222,6 +2244,9 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
 #pragma unroll
     for (uint32_t t = 1, lg = 1; t <= 32u; t <<= 1, lg++)
         if (__ballot(nwin > t)) { slots = 2u * t; lg_slots = lg; }
+#ifdef SLAMEM_SEED_DIAG_PACK_ONLY   // (timing experiments only: wrong results)
+    slots = 0;
+#endif
     const uint32_t rpt = slots ? 64u / slots : kSeedReads;  // reads per trip
 
     // Phase 1 for every trip first (the trips are independent: their table lines are in flight together), then ONE pass of
@@ -2263,6 +2288,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         if (!act) hits = 0;
         if (act && (count > kSeedSlots || (pal && hits && strands == 2u))) {
             atomicOr(&S.flags, 3u << (2u * rs));
+            if (kStats) atomicAdd(A.stats + SC_SEED_WHY + (count > kSeedSlots ? 1u : 2u), 1ull);
             hits = 0;
         }
         // Every hit is a compare -- except one whose neighbour window (the one s letters earlier in the forward strand) hit the
@@ -2297,6 +2323,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         }
         if (njobs > kSeedJobs) {  // (many repeated windows) every read of this trip is left to K8
             for (uint32_t i = t0; i < t0 + rpt && i < kSeedReads; i++) wflags |= 3u << (2u * i);
+            if (kStats && lane == 0u) atomicAdd(A.stats + SC_SEED_WHY + 3u, 1ull);
             njobs = njobs0;
         }
     }
@@ -2361,7 +2388,10 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 // reported by the window with the smallest forward offset inside the match
                 const bool owner = st ? !(os + s + k <= b) : !(os >= s && os - s >= a);
                 g = (uint32_t)((r0 + jr) * strands + st);
-                if (broken) atomicOr(&S.flags, 1u << (2u * jr + st));  // (cannot happen: the table is exact) -- leave the strand to K8
+                if (broken) {  // (cannot happen: the table is exact) -- leave the strand to K8
+                    atomicOr(&S.flags, 1u << (2u * jr + st));
+                    if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 4u, 1ull);
+                }
                 else if (owner && b - a >= L) { is_mem = true; key = (a << 16) | (b - a); ref = (uint32_t)(d + (int64_t)a); }
             }
             if (kStats) n_cmp += (uint32_t)__popcll(__ballot(has));
@@ -2369,7 +2399,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             if (is_mem) {
                 const uint32_t at = nmems + (uint32_t)__popcll(mb & below);
                 if (at < kSeedMems) { S.mem_key[at] = key; S.mem_ref[at] = ref; S.mem_g[at] = g; }
-                else atomicOr(&S.flags, 1u << (2u * jr + st));
+                else { atomicOr(&S.flags, 1u << (2u * jr + st)); if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 5u, 1ull); }
             }
             nmems += (uint32_t)__popcll(mb);
         }
@@ -2403,7 +2433,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             uint32_t rank, cnt;
             bool tie;
             rank_of(lane, key, g, rank, cnt, tie);
-            if (has && tie) atomicOr(&S.flags, 1u << (strands == 2u ? g - g0 : 2u * (g - g0)));
+            if (has && tie) { atomicOr(&S.flags, 1u << (strands == 2u ? g - g0 : 2u * (g - g0))); if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 6u, 1ull); }
             wave_sync();
             if (has) emit_mem(S.flags | wflags, key, ref, g, rank, cnt);
         } else {
@@ -2437,6 +2467,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             uint32_t lf = 0;
             for (uint32_t i = 0; i < nr * strands; i++) lf += (fl >> (strands == 2u ? i : 2u * i)) & 1u;
             atomicAdd(A.stats + SC_SEED_LEFT, (unsigned long long)lf);
+            atomicAdd(A.stats + SC_SEED_WHY + 0u, (unsigned long long)__popc(wflags & 0x55555555u));  // reads left before any lookup: too long, or a letter that is not A,C,G,T (and trips whose compares did not fit)
         }
     }
 }
@@ -3184,6 +3215,7 @@ int SearchJob::collect() {
         o.seed_windows = c[SC_SEED_WINDOWS]; o.seed_compares = c[SC_SEED_COMPARES]; o.seed_letter_masks = c[SC_SEED_NMASKS];
         o.seed_mems = c[SC_SEED_MEMS]; o.seed_strands_left = c[SC_SEED_LEFT]; o.seed_reads = c[SC_SEED_READS];
         o.seed_query_bytes = c[SC_SEED_QBYTES];
+        for (int q = 0; q < 7; q++) o.seed_left_why[q] = c[SC_SEED_WHY + q];
         o.items = nitems;
         o.survivors = prefiltered ? nwork : nitems;
         o.mems = total;

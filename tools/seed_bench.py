@@ -41,7 +41,7 @@ print(json.dumps({"mems": total, "ms_per_step": el * 1e3, "MEMs_per_s": total / 
                   "seed_ms": tm["seed_ms_sum"] / ln, "k8_ms": tm["k8_ms_sum"] / ln, "k8a_ms": tm["prefilter_ms_sum"] / ln,
                   "search_total_ms": tm["search_total_ms"]}), flush=True)
 st = engine.search_stats(m, reads, offsets, minlen)
-print(json.dumps({k: v for k, v in st.items() if k.startswith("seed_") or k in ("survivors", "items", "mems", "overflow_records")}), flush=True)
+print(json.dumps({k: v for k, v in st.items() if (k.startswith("seed_")) or k in ("survivors", "items", "mems", "overflow_records")}), flush=True)
 # digest of the MEM set as tests/golden/known_answers.json records it: count, sum of lengths
 boff = m.block_offsets.cpu().numpy()
 mm = m.mems[: int(boff[-1])].cpu().numpy().view(np.uint32)
