@@ -2052,6 +2052,22 @@ __global__ void __launch_bounds__(256, SLAMEM_PF_WAVES) k_prefilter(SearchArgs A
     }
 }
 
+// K8a on a LIST of items (the strands K8s left to the index walk): the presence tests of prefilter_item for each, survivors
+// appended to a second list.  A read is left with BOTH strands (a bucket that holds more k-mers than it has slots says nothing
+// about either), and the strand that holds nothing -- the wrong strand of the read -- is the expensive one for K8: 150 positions
+// of failing extensions, a millisecond of dependent steps.  The filter proves nearly all of those empty in a few lines each;
+// the list is then made again from alive[].
+__global__ void __launch_bounds__(256) k_prefilter_list(SearchArgs A, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+                                                        uint8_t* __restrict__ alive) {
+    const uint32_t count = *list_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint32_t g = list[i];
+        const ItemDesc d = A.items[g];
+        uint32_t n_probe = 0, n_qload = 0;
+        if (!prefilter_item<false>(A, d, n_probe, n_qload)) alive[g] = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K8s: seed-and-compare -- the search for READS (k_seed_mems)
 // ------------------------------------------------------------------------------------------
@@ -2924,6 +2940,14 @@ int SearchJob::prep(hipStream_t stream) {
             STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
             A.work_ids = d_ids;
             A.work_count = d_nwork;
+            if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k && !want_stats) {
+                // the strands K8s left, through the presence filter (the wrong strand of a read that was left whole dies here),
+                // and the list again from what is left of alive[]
+                hipLaunchKernelGGL(k_prefilter_list, dim3(512), dim3(256), 0, stream, A, (const uint32_t*)d_ids, (const uint32_t*)d_nwork, d_alive);
+                STEP(hipGetLastError(), "k_prefilter_list");
+                need2 = w.select_bytes;
+                STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
+            }
         } else if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
             uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
             if (want_stats) hipLaunchKernelGGL(k_prefilter<true>, dim3(grid_for(nitems)), dim3(256), 0, stream, A, d_alive);
