@@ -10,8 +10,9 @@ than --gpus asks for.
 
 Workload (config.workload): synthetic 100 Mbp reference (SURVEY.md Appendix C.2 generator, seed 42), 10 M x 150 bp
 reads with 2 % substitutions, half of them reverse-complemented, `-b -l 20` (BASELINE.json configs[2], the
-configuration the metric is quoted on).  One "step" = one pass of the hot path (slamem_find_mems_device: K8a
-prefilter + K8 search + K9 output placement) over the rank's read batch, inputs already resident in HBM.  Reads shard
+configuration the metric is quoted on).  One "step" = one pass of the hot path (slamem_find_mems_device: K8s
+seed-and-compare for the reads, the presence filter + K8 index walk for the strands it leaves, K9 output placement) over
+the rank's read batch, inputs already resident in HBM.  Reads shard
 across ranks with no data-path collective (slamem.c:90-95: records are independent); the index is built once on rank
 0 and broadcast over RCCL/xGMI straight from its arena; per-rank MEM counts are gathered every step.
   --scaling weak   (default; the contract's mode for sharded paths) every rank matches its own 10 M reads
@@ -20,12 +21,15 @@ With N > 1 the line also carries the other mode's rate, measured in the same pro
 (`strong_scaling` / `weak_scaling`), so one launch gives both.
 
 Rank 0 prints ONE JSON line.
-  roofline      the dominant kernel (K8 k_find_mems_v3): `traffic` = bytes the kernel's lanes asked HBM for, counted by
-                the kernel's diagnostic instantiation on the same batch in this run (64 B per FM-block / row-record
-                line, 16 B per packed query window); `achieved` = traffic / K8's mean duration (HIP events on its stream);
-                `frac` = achieved / 8 TB/s.  `request_rate_frac` = lines/s over a dependent-random-line ceiling measured
-                in this process on this index arena.  The SURVEY 8(d) reference-work formula is kept as
-                `reference_work_GBps` (it charges the reference's work, not what this engine moves).
+  roofline      the dominant kernel (K8s k_seed_mems since round 4; K8 k_find_mems_v3 when the batch does not take the seed
+                path): `traffic` = bytes the kernel's lanes asked the memory system for, counted by the kernel's
+                diagnostic instantiation on the same batch in this run (K8s: 64 B per seed-table line = one per window,
+                80 B per compare = four 16-byte units of the text bit-planes + two words of the unit mask, the reads'
+                own bytes, 12 B per MEM written, 5 B of flags / counts per strand); `achieved` = traffic / the kernel's
+                mean duration (HIP events on its stream); `frac` = achieved / 8 TB/s.  `request_rate_frac` = 64-byte
+                lines/s over a dependent-random-line ceiling measured in this process on this index arena.  The SURVEY
+                8(d) reference-work formula is kept as `reference_work_GBps` (it charges the reference's work, not what
+                this engine moves).
   cpu_baseline  the oracle (our CPU restatement of the reference algorithm) on a bounded sample of the same reads on
                 this box's host cores: one thread (`cpu_baseline`) and all of this box's share (`cpu_baseline_all_cores`).
 """
@@ -257,7 +261,7 @@ def main():
         tm = engine.timings()
         launches = max(1, tm["search_launches"])
         vals = torch.tensor([elapsed, tm["search_kernel_ms_sum"] / launches, tm["k8_ms_sum"] / launches,
-                             tm["prefilter_ms_sum"] / launches], dtype=torch.float64, device=cdev)
+                             tm["prefilter_ms_sum"] / launches, tm["seed_ms_sum"] / launches], dtype=torch.float64, device=cdev)
         lo = vals.clone()
         if world > 1:
             dist.all_reduce(vals, op=dist.ReduceOp.MAX)
@@ -266,7 +270,7 @@ def main():
         reads_total = torch.tensor([count], dtype=torch.int64, device=cdev)
         if world > 1:
             dist.all_reduce(reads_total)
-        return {"elapsed": v[0], "kernel_ms": v[1], "k8_ms": v[2], "prefilter_ms": v[3], "kernel_ms_min": lo[1],
+        return {"elapsed": v[0], "kernel_ms": v[1], "k8_ms": v[2], "prefilter_ms": v[3], "seed_ms": v[4], "kernel_ms_min": lo[1],
                 "mems": int(counts_all.sum().item()), "reads": int(reads_total.item()), "matcher": matcher,
                 "batch": batch}
 
@@ -309,9 +313,11 @@ def main():
             "index_build_ms": build_t,
             "index_bytes": arena_bytes,
             "index_broadcast_s": bcast_s,
-            "kernel": "K8a k_prefilter + K8 k_find_mems_v3 (HIP events on their stream)",
+            "kernel": "K8s k_seed_mems (+ presence filter and K8 k_find_mems_v3 for the strands it leaves; K8a k_prefilter + K8 "
+                      "for batches that do not take the seed path); HIP events on their stream",
             "kernel_ms": r["kernel_ms"],
             "kernel_ms_min_over_ranks": r["kernel_ms_min"],
+            "k8s_ms": r["seed_ms"],
             "k8_ms": r["k8_ms"],
             "k8a_ms": r["prefilter_ms"],
         }
@@ -335,24 +341,49 @@ def main():
         # sequential within a strand's 80 bytes
         k8_bytes = 64 * k8_lines + 16 * (st["query_loads"] + st.get("dir_group_loads", 0) + st.get("skip_group_loads", 0))
         k8a_bytes = 64 * st["prefilter_probes"] + 16 * st["prefilter_query_loads"]
-        k8_s = r["k8_ms"] * 1e-3
+        k8_s = max(1e-9, r["k8_ms"] * 1e-3)
         ceiling = engine.random_line_ceiling(index) if hasattr(engine, "random_line_ceiling") else None
-        achieved = k8_bytes / k8_s / 1e9
         bases = float(count) * L * strands
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "k_find_mems_v3", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS if not a.no_stats else None, "traffic": k8_bytes if not a.no_stats else None,
-            "traffic_source": "load counters of the kernel's diagnostic instantiation on this batch (this run); "
-                              "cross-check against rocprofv3 FETCH_SIZE in profiles/",
-            "kernel_ms": r["k8_ms"], "lines_64B": k8_lines, "lines_per_s": k8_lines / k8_s,
-            "random_line_ceiling_per_s": ceiling, "request_rate_frac": (k8_lines / k8_s / ceiling) if ceiling else None,
-            "lane_use": st["lane_trips"] / max(1, 64 * st["wave_trips"]),
-            "lines_per_query_base": k8_lines / bases,
-            "prefilter": {"kernel": "k_prefilter", "traffic": k8a_bytes, "kernel_ms": r["prefilter_ms"],
-                          "achieved": k8a_bytes / max(1e-9, r["prefilter_ms"] * 1e-3) / 1e9,
-                          "frac": k8a_bytes / max(1e-9, r["prefilter_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "counters": st,
-        }
+        walk = {"kernel": "k_find_mems_v3", "traffic": k8_bytes, "kernel_ms": r["k8_ms"], "lines_64B": k8_lines,
+                "achieved": k8_bytes / k8_s / 1e9, "frac": k8_bytes / k8_s / 1e9 / HBM_PEAK_GBS, "lines_per_s": k8_lines / k8_s,
+                "lane_use": st["lane_trips"] / max(1, 64 * st["wave_trips"]), "strands": st.get("survivors", 0)}
+        pf = {"kernel": "k_prefilter", "traffic": k8a_bytes, "kernel_ms": r["prefilter_ms"],
+              "achieved": k8a_bytes / max(1e-9, r["prefilter_ms"] * 1e-3) / 1e9,
+              "frac": k8a_bytes / max(1e-9, r["prefilter_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if r["seed_ms"] > 0 and st.get("seed_reads", 0):
+            # K8s: one seed-table line per window, four text units + two unit-mask words per compare (+ four letter-mask words for
+            # the few whose units hold a letter that is not A,C,G,T), the reads' bytes once, 12 B per MEM and 5 B per strand out
+            s_s = r["seed_ms"] * 1e-3
+            s_bytes = (64 * st["seed_windows"] + 80 * st["seed_compares"] + 32 * st["seed_letter_masks"] + st["seed_query_bytes"]
+                       + 12 * st["seed_mems"] + 5 * st["items"])
+            s_lines = st["seed_windows"] + st["seed_compares"] + st["seed_query_bytes"] // 64
+            achieved = s_bytes / s_s / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_seed_mems", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": s_bytes,
+                "traffic_source": "counters of the kernel's diagnostic instantiation on this batch (this run): 64 B per window "
+                                  "(seed-table line), 80 B per compare (text bit-planes), the reads' bytes, 12 B per MEM, 5 B per "
+                                  "strand; cross-check against rocprofv3 FETCH_SIZE + WRITE_SIZE in profiles/",
+                "kernel_ms": r["seed_ms"], "lines_64B": s_lines, "lines_per_s": s_lines / s_s,
+                "random_line_ceiling_per_s": ceiling, "request_rate_frac": (s_lines / s_s / ceiling) if ceiling else None,
+                "lines_per_query_base": s_lines / bases, "windows_per_read": st["seed_windows"] / max(1, st["seed_reads"]),
+                "compares_per_read": st["seed_compares"] / max(1, st["seed_reads"]),
+                "strands_left_to_index_walk": st["seed_strands_left"], "index_walk": walk, "counters": st,
+            }
+        else:
+            achieved = k8_bytes / k8_s / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_find_mems_v3", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if not a.no_stats else None, "traffic": k8_bytes if not a.no_stats else None,
+                "traffic_source": "load counters of the kernel's diagnostic instantiation on this batch (this run); "
+                                  "cross-check against rocprofv3 FETCH_SIZE in profiles/",
+                "kernel_ms": r["k8_ms"], "lines_64B": k8_lines, "lines_per_s": k8_lines / k8_s,
+                "random_line_ceiling_per_s": ceiling, "request_rate_frac": (k8_lines / k8_s / ceiling) if ceiling else None,
+                "lane_use": st["lane_trips"] / max(1, 64 * st["wave_trips"]),
+                "lines_per_query_base": k8_lines / bases,
+                "prefilter": pf,
+                "counters": st,
+            }
 
         # ---- CPU baseline + parity of the GPU result on the sample (the checker, not the thing measured) ----------------
         bytes_per_base = FIXED_BYTES_PER_BASE

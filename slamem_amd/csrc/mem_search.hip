@@ -2940,7 +2940,7 @@ int SearchJob::prep(hipStream_t stream) {
             STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
             A.work_ids = d_ids;
             A.work_count = d_nwork;
-            if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k && !want_stats) {
+            if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
                 // the strands K8s left, through the presence filter (the wrong strand of a read that was left whole dies here),
                 // and the list again from what is left of alive[]
                 hipLaunchKernelGGL(k_prefilter_list, dim3(512), dim3(256), 0, stream, A, (const uint32_t*)d_ids, (const uint32_t*)d_nwork, d_alive);
