@@ -19,6 +19,7 @@
 #include "common.h"
 #include "prims.h"
 
+#include <atomic>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
@@ -211,6 +212,22 @@ struct SearchArgs {
         uint32_t* block_counts;
         uint8_t* item_attempt;
     } prev;
+    // kDefer (repeat-rich texts, reads): enumeration jobs leave the strand's chain of dependent steps.  The lane that meets an
+    // interval of several rows / an ancestor still >= min_len deep puts the job into a queue and walks on; k_enum_jobs runs the
+    // queue with every wave of the chip; K9 gives the MEMs their places from (records before the job, MEMs of the jobs before).
+    struct DeferCtx {
+        struct JobRec* queue;      // [pool_cap]
+        unsigned int* njobs;
+        uint32_t* pool;            // per deferring strand: {jobs, MEMs the lane reported itself, MEMs of job 0, 1, ...} -> prefix sums (K9)
+        unsigned int* pool_next;
+        uint32_t pool_cap;
+        uint32_t queue_cap;        // places of the queue: pool_cap (a job per counter at most) + a chunk per wave
+        uint32_t epoch;            // stamp of this launch in the queue's records: the waves reserve queue places in chunks, what they leave unused holds no (or an older) stamp
+        uint32_t* raw_seg;         // beside raw_key / raw_mem: where in `pool` the record's offset is (0xFFFFFFFF: its ordinal is final)
+        uint2* list;               // {strand block, its place in the pool}
+        unsigned int* nlist;
+        uint8_t* inline_valid;     // per item: 0, or 1 + the inline slots that hold MEMs (those reported before the first job)
+    } defer;
     const struct CarryRec* carry_in;       // lanes of the previous launch that were not finished (nullptr: none)
     const unsigned int* carry_in_count;
     struct CarryRec* carry_out;            // nullptr: run every strand to its end (a stand-alone launch, or the last of a stream)
@@ -754,6 +771,16 @@ struct __attribute__((aligned(16))) CarryRec {
 };
 static_assert(sizeof(CarryRec) == 64, "carry record is one line");
 
+// A deferred enumeration job (kDefer): what wave_enumerate needs, and where its MEM count goes
+struct __attribute__((aligned(16))) JobRec {
+    uint32_t g, kbase, t, b;
+    uint32_t depth_pos;   // depth | pos << 16   (reads only: both below 65536)
+    uint32_t left_flags;  // left letter | level0 << 8 | walk up << 9
+    uint32_t segabs;      // place of the job's count in the pool
+    uint32_t epoch;       // DeferCtx::epoch of the launch that wrote the record
+};
+static_assert(sizeof(JobRec) == 32, "job record is 32 bytes");
+
 // emit3_at with the output side chosen per lane: `old` lanes (carried in from the previous launch) write to A.prev
 template <bool kCarry>
 __device__ __forceinline__ void emit3_sel(const SearchArgs& A, bool old, uint32_t g, uint32_t kk, uint32_t tag, uint32_t row,
@@ -770,6 +797,22 @@ __device__ __forceinline__ void emit3_sel(const SearchArgs& A, bool old, uint32_
             (old ? A.prev.raw_key : A.raw_key)[slot] = RawKey{g, kk | tag};
             (old ? A.prev.raw_mem : A.raw_mem)[slot] = slamem_mem{row, pos, len};
         }
+    }
+}
+
+// kDefer: a MEM the lane reports itself AFTER its strand's first deferred job: its ordinal counts only what the lane reported
+// (the jobs' MEMs before it are not known yet); the record goes to the list with the place of its offset in the pool
+__device__ __forceinline__ void emit_provisional(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t row, uint32_t pos, uint32_t len,
+                                                 uint32_t segabs) {
+#ifdef SLAMEM_DIAG_NO_PROV   // (timing experiments only: wrong results)
+    return;
+#endif
+    if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(A.total) + 9, 1u);
+    const unsigned long long slot = atomicAdd(A.total, 1ull);
+    if (slot < A.capacity) {
+        A.raw_key[slot] = RawKey{g, kk};
+        A.raw_mem[slot] = slamem_mem{row, pos, len};
+        A.defer.raw_seg[slot] = segabs;
     }
 }
 
@@ -930,6 +973,220 @@ __device__ __forceinline__ uint32_t wave_enumerate_merged(const SearchArgs& A, b
         if (msz < L) break;
     }
     return k;
+}
+
+// ---- K8e: the queue of deferred enumeration jobs (kDefer) -------------------------------------------------------------------
+// One step of a queued job: the rows the wave reports go to the list (never to inline slots: the strand's MEM numbers are
+// provisional), places reserved kOvfChunk at a time as in wave_emit_step<*, true>
+__device__ __forceinline__ uint32_t wave_emit_queued(const SearchArgs& A, uint32_t lane, uint32_t g, uint32_t k, bool ok, uint32_t row,
+                                                     uint32_t pos, uint32_t len, uint32_t segabs, unsigned long long& ovf_base,
+                                                     uint32_t& ovf_left) {
+    const unsigned long long m = __ballot(ok);
+    if (m == 0ull) return k;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t need = (uint32_t)__popcll(m);
+    if (ovf_left < need) {  // (wave-uniform) a new chunk; what is left of the old one stays marked as unused
+        const uint32_t chunk = need > kOvfChunk ? need : kOvfChunk;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0ull;
+        if ((int)lane == leader) base = atomicAdd(A.total, (unsigned long long)chunk);
+        ovf_base = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader),
+                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader));
+        ovf_left = chunk;
+    }
+    if (ok) {
+        const uint32_t kk = k + (uint32_t)__popcll(m & below);
+        if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(A.total) + 9, 1u);
+        const unsigned long long slot = ovf_base + (unsigned long long)__popcll(m & below);
+        if (slot < A.capacity) {
+            A.raw_key[slot] = RawKey{g, kk};
+            A.raw_mem[slot] = slamem_mem{row, pos, len};  // ref_pos holds the ROW until K9
+            A.defer.raw_seg[slot] = segabs;
+        }
+    }
+    ovf_base += need;
+    ovf_left -= need;
+    return k + need;
+}
+
+// Every wave of the chip takes jobs from the queue, FOUR at a time: a group of 16 lanes per job.  A job is a chain of levels (the
+// interval, then its ancestors down to min_len: one memory round trip each), and on a repeat-rich text most rows of a level
+// are NOT reported -- the copies of a family mostly agree on the letter to the left -- so the rows are not looked at one per
+// lane: a lane takes 64 rows at once as the three plane words of their half FM block and finds the rows whose letter differs
+// from the query's with a few bitwise operations (a group: 1,024 rows above and 1,024 below per step).  Order as in
+// wave_enumerate (slamem.c:139-193): the new rows above ascending, then the new rows below descending, then the parent.  All
+// groups of a wave step together (a group without a job idles through the step); MEM numbers come from sums over the group,
+// places in the list from the wave's chunk.  The job's MEM count goes to its place in the pool.
+__global__ void __launch_bounds__(256) k_enum_jobs(SearchArgs A) {
+    const IndexView& ix = A.ix;
+    const uint4* R = reinterpret_cast<const uint4*>(ix.rec);
+    const int L = (int)A.min_len;
+    const uint32_t lane = threadIdx.x & 63u, gl = lane & 15u;
+    const uint32_t ngroups = gridDim.x * (blockDim.x >> 4), group = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const uint32_t nres = *A.defer.njobs;  // places of the queue given out (in chunks: some hold no record of this launch)
+    const uint32_t njobs = nres < A.defer.queue_cap ? nres : A.defer.queue_cap;
+    unsigned long long ovf_base = 0ull;  // the wave's chunk of the list (wave-uniform)
+    uint32_t ovf_left = 0u;
+    uint32_t q = group;                  // the group's next job
+    bool busy = false;
+    // the group's job (the same in its 16 lanes)
+    uint32_t g = 0, k = 0, kbase = 0, t = 0, b = 0, pt = 0, pb = 0, pos = 0, left = 0, segabs = 0, aoff = 0, boff = 0;
+    int msz = 0;
+    bool walk_up = false;
+#ifdef SLAMEM_DIAG_TRIPS
+    uint32_t dg_steps = 0, dg_busy = 0;
+#endif
+    for (;;) {
+#ifdef SLAMEM_DIAG_TRIPS
+        dg_steps++; dg_busy += (uint32_t)__popcll(__ballot(busy)) >> 4;
+#endif
+        if (!busy && q < njobs) {
+            const uint4* jr = reinterpret_cast<const uint4*>(A.defer.queue + q);
+            const uint4 j0 = jr[0], j1 = jr[1];
+            q += ngroups;
+            g = j0.x; kbase = k = j0.y; t = j0.z; b = j0.w;
+            msz = (int)(j1.x & 0xFFFFu); pos = j1.x >> 16; left = j1.y & 0xFFu;
+            walk_up = (j1.y & 0x200u) != 0u;
+            pt = (j1.y & 0x100u) ? b + 1u : t;  // rows already reported: [pt, pb]
+            pb = b;
+            segabs = j1.z;
+            aoff = 0; boff = 0;
+            busy = j1.w == A.defer.epoch;  // (else: a place nobody filled in this launch -- the group idles through this step)
+        }
+        if (__ballot(busy) == 0ull) {  // (wave-uniform) nobody has a job: the end, unless a group's next place just held none
+            if (__ballot(q < njobs) == 0ull) break;
+            continue;
+        }
+        // ---- one memory phase: this lane's half block above, its half block below, the records of [t,b] -------------------
+        const uint32_t na = pt - t, nb = b - pb;                 // new rows above [t, pt) / below (pb, b] at this level
+        const bool do_a = busy && aoff < na;
+        const uint32_t a_lo = t + aoff;                          // first row above not looked at yet
+        const uint32_t a_end = (a_lo & ~63u) + 1024u;            // the group's 16 half blocks end here (wraps only behind 2^32 rows)
+        const bool a_last = !do_a || a_end >= pt || a_end < a_lo;  // the rows above are through with this step
+        const bool do_b = busy && a_last && boff < nb;
+        const uint32_t b_hi = b - boff;                          // last row below not looked at yet
+        const uint32_t b_blk = b_hi & ~63u;                      // first row of its half block
+        const bool b_reach = b_blk < 960u || b_blk - 960u <= pb + 1u;  // the group's 16 half blocks reach down to pb + 1
+        const bool b_last = a_last && (!do_b || b_reach);        // ... and the rows below: the level ends
+        const uint32_t ha = (a_lo & ~63u) + 64u * gl;            // this lane's half block above: rows [ha, ha + 64)
+        const bool wa = do_a && ha < pt && ha >= (a_lo & ~63u);
+        const bool wb = do_b && b_blk >= 64u * gl && b_blk - 64u * gl + 63u > pb;
+        const uint32_t hb = b_blk - 64u * gl;                    // this lane's half block below: rows [hb, hb + 64)
+        uint64_t ea = 0, a0 = 0, a1 = 0, eb = 0, b0 = 0, b1 = 0;
+        if (wa) { const FMBlock* blk = ix.fm + (ha >> kFmRowsLog2); const uint32_t hs = (ha & (kFmRows - 1u)) >> 6; ea = blk->ex[hs]; a0 = blk->p0[hs]; a1 = blk->p1[hs]; }
+        if (wb) { const FMBlock* blk = ix.fm + (hb >> kFmRowsLog2); const uint32_t hs = (hb & (kFmRows - 1u)) >> 6; eb = blk->ex[hs]; b0 = blk->p0[hs]; b1 = blk->p1[hs]; }
+        uint4 rt = make_uint4(0, 0, 0, 0), rbm = rt;
+        if (busy && b_last && walk_up) { rt = R[t]; rbm = R[b]; }
+        // (every load of the step is out before anything is looked at)
+        asm volatile("" : "+v"(ea), "+v"(a0), "+v"(a1), "+v"(eb), "+v"(b0), "+v"(b1));
+        asm volatile("" : "+v"(rt.x), "+v"(rt.y), "+v"(rt.z), "+v"(rt.w), "+v"(rbm.x), "+v"(rbm.y), "+v"(rbm.z), "+v"(rbm.w));
+        // rows of a half block whose BWT letter differs from `left` (left: 2..5 = A,C,G,T; 1 = N; 0xFF at a strand's end: every row)
+        auto differs = [&](uint32_t row0, uint64_t e, uint64_t p0, uint64_t p1) -> uint64_t {
+            const uint32_t c2 = left - 2u;
+            const uint64_t f0 = (c2 & 1u) ? ~0ull : 0ull, f1 = (c2 & 2u) ? ~0ull : 0ull;
+            uint64_t same = left >= 2u && left <= 5u ? (~(p0 ^ f0) & ~(p1 ^ f1) & ~e) : 0ull;  // rows that hold the letter itself
+            if (left == 1u) {  // N: the exception rows but the one of '$'
+                same = e;
+                if (ix.dollar_row >= row0 && ix.dollar_row - row0 < 64u) same &= ~(1ull << (ix.dollar_row - row0));
+            }
+            return ~same;
+        };
+        uint64_t ma = 0, mb = 0;
+        if (wa) {
+            const uint32_t lo = a_lo > ha ? a_lo - ha : 0u, hi = pt - ha < 64u ? pt - ha : 64u;  // rows [ha + lo, ha + hi)
+            ma = differs(ha, ea, a0, a1) & (hi >= 64u ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << lo) - 1ull);
+        }
+        if (wb) {
+            const uint32_t lo = pb + 1u > hb ? pb + 1u - hb : 0u, hi = b_hi - hb + 1u < 64u ? b_hi - hb + 1u : 64u;  // rows [hb + lo, hb + hi)
+            mb = differs(hb, eb, b0, b1) & (hi >= 64u ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << lo) - 1ull);
+        }
+        // ---- MEM numbers: above first (lanes, then bits, ascending), then below (lanes ascending = rows descending) ---------
+        const uint32_t ca = (uint32_t)__popcll(ma), cb = (uint32_t)__popcll(mb);
+        uint32_t sa = ca, sb = cb, sw = ca + cb;  // inclusive sums over the lanes of the group (sa, sb) and of the wave (sw)
+#pragma unroll
+        for (uint32_t d = 1; d < 16u; d <<= 1) {
+            const uint32_t xa = __shfl_up(sa, d, 16), xb = __shfl_up(sb, d, 16);
+            if (gl >= d) { sa += xa; sb += xb; }
+        }
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t xw = __shfl_up(sw, d);
+            if (lane >= d) sw += xw;
+        }
+        const uint32_t ta = __shfl(sa, 15, 16), tb = __shfl(sb, 15, 16);       // the group's totals
+        const uint32_t need = (uint32_t)__builtin_amdgcn_readlane((int)sw, 63);   // the wave's
+        if (need != 0u) {
+            if (ovf_left < need) {  // (wave-uniform) a new chunk; what is left of the old one stays marked as unused
+                const uint32_t chunk = need > kOvfChunk ? need : kOvfChunk;
+                unsigned long long base = 0ull;
+                if (lane == 0u) base = atomicAdd(A.total, (unsigned long long)chunk);
+                ovf_base = u64_of((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)));
+                ovf_left = chunk;
+            }
+            unsigned long long slot = ovf_base + (sw - ca - cb);
+            uint32_t kk = k + (sa - ca);
+            for (uint64_t m = ma; m != 0ull; m &= m - 1ull, slot++, kk++) {
+                const uint32_t row = ha + (uint32_t)__builtin_ctzll(m);
+                if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(A.total) + 9, 1u);
+                if (slot < A.capacity) {
+                    A.raw_key[slot] = RawKey{g, kk};
+                    A.raw_mem[slot] = slamem_mem{row, pos, (uint32_t)msz};  // ref_pos holds the ROW until K9
+                    A.defer.raw_seg[slot] = segabs;
+                }
+            }
+            kk = k + ta + (sb - cb);
+            for (uint64_t m = mb; m != 0ull; slot++, kk++) {
+                const uint32_t bit = 63u - (uint32_t)__builtin_clzll(m);
+                m &= ~(1ull << bit);
+                if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(A.total) + 9, 1u);
+                if (slot < A.capacity) {
+                    A.raw_key[slot] = RawKey{g, kk};
+                    A.raw_mem[slot] = slamem_mem{hb + bit, pos, (uint32_t)msz};
+                    A.defer.raw_seg[slot] = segabs;
+                }
+            }
+            k += ta + tb;
+            ovf_base += need;
+            ovf_left -= need;
+        }
+        // ---- advance ----------------------------------------------------------------------------------------------------
+        if (busy) {
+            if (do_a) aoff = a_end - t;                          // (at least na when the rows above are through)
+            if (do_b) boff = b_reach ? nb : b - (b_blk - 960u) + 1u;
+            if (b_last) {  // the level is through
+                bool done = !walk_up;
+                if (!done) {
+                    pt = t; pb = b;
+                    msz = parent_from(rt, rbm, t, b);  // (slamem.c:192)
+                    aoff = 0; boff = 0;
+                    done = msz < L;
+                }
+                if (done) {
+                    if (gl == 0u) A.defer.pool[segabs] = k - kbase;
+                    busy = false;
+                }
+            }
+        }
+    }
+#ifdef SLAMEM_DIAG_TRIPS
+    if (lane == 0u) { atomicMax(A.defer.njobs + 11, dg_steps); atomicAdd(A.defer.njobs + 12, dg_steps); atomicAdd(A.defer.njobs + 13, dg_busy); }
+#endif
+}
+
+// K9 for the strands with deferred jobs: the jobs' MEM counts of a strand -> what comes before each job (and before what the lane
+// reported behind it), and the strand's total.  One lane per strand (a read has at most a job per position).
+__global__ void __launch_bounds__(256) k_defer_prefix(SearchArgs A) {
+    const uint32_t n = *A.defer.nlist;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 e = A.defer.list[i];
+        uint32_t* c = A.defer.pool + e.y;
+        const uint32_t jobs = c[0], own = c[1];
+        uint32_t run = 0;
+        for (uint32_t s2 = 0; s2 < jobs; s2++) { const uint32_t v = c[2u + s2]; c[2u + s2] = run; run += v; }
+        c[2u + jobs] = run;
+        A.block_counts[e.x] = own + run;
+    }
 }
 
 // Counters of a diagnostic launch (template parameter kStats; the timed kernels are the kStats = false instantiations,
@@ -1104,7 +1361,7 @@ enum : uint32_t { ST_EXT = 0, ST_REC = 1, ST_FLUSH = 2, ST_DSA = 3, ST_DIR = 4, 
 // exact, 27 % fewer lines and 32 % fewer lane trips, but the same time -- the kernel is bound by instruction issue and
 // every trip pays for the union of the states its lanes are in -- so the default kernel is the one without them
 // (SLAMEM_SKIP=1 selects this one).
-template <bool kStats, bool kSkip, bool kSliced, bool kMam, bool kCarry, bool kChunk = false>
+template <bool kStats, bool kSkip, bool kSliced, bool kMam, bool kCarry, bool kChunk = false, bool kDefer = false>
 __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 : SLAMEM_V3_WAVES) k_find_mems_v3(SearchArgs A) {
     __shared__ ItemDesc lds_item[4][kFetch];
     __shared__ uint64_t lds_pk[4][kFetch];
@@ -1184,6 +1441,28 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
         }
     }
 
+    // kDefer: jobs of this lane's strand that went to the queue, and the strand's place in the pool (0: none yet, ~0: refused --
+    // the pool was full: the strand's jobs run in the wave as in the other instantiations)
+    uint32_t seg = 0, jobbase = 0;
+#ifdef SLAMEM_DIAG_TRIPS
+    uint32_t dg_trips = 0, dg_wtrips = 0;
+#endif
+    // (kDefer) a MEM the lane reports itself behind its strand's first queued job waits in these registers for the end of the trip,
+    // where the wave gives the trip's records places from its chunk of the list (one atomic per 128 places: with an atomic per
+    // record on the list's one counter -- and another per queued job -- the waves of a repeat-rich batch spent their time in the
+    // queue of that counter: 13 us per trip); a second one in the same trip (a strand's last position) takes the counter
+    bool em_on = false;
+    uint32_t em_row = 0, em_pos = 0, em_len = 0, em_k = 0;
+#define SLAMEM_EMIT(row_, pos_, len_)                                                                                         \
+    do {                                                                                                                      \
+        if (kDefer && seg != 0u) {                                                                                             \
+            if (!em_on) { em_on = true; em_row = (row_); em_pos = (pos_); em_len = (len_); em_k = k; }                         \
+            else emit_provisional(A, g, k, (row_), (pos_), (len_), jobbase + 2u + seg);                                        \
+        } else emit3_sel<kCarry>(A, old, g, k, attempt << 28, (row_), (pos_), (len_));                                         \
+    } while (0)
+    __shared__ uint32_t lds_q_base[kDefer ? 4 : 1], lds_q_left[kDefer ? 4 : 1];  // the wave's chunk of the job queue
+    if (kDefer) { lds_q_base[wv] = 0u; lds_q_left[wv] = 0u; }
+
     for (;;) {
         // ---- hand the next items to idle lanes ----------------------------------------------------------------
         unsigned long long idle = __ballot(!active);
@@ -1193,6 +1472,10 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
             // are what the other, drained, waves wait for (measured on a 1 M-read batch: +38 % with fixed pieces of 64)
             uint32_t want = (nitems - seen) / (2u * nwaves) & ~7u;
             want = want < 8u ? 8u : want > kFetch ? kFetch : want;
+            // a list shorter than one full piece per wave (the strands K8s left, a small batch): whole pieces at once, so that
+            // few, full waves do the work and the others leave -- a wave trip costs the same instructions whatever its lanes do,
+            // and with the guided sizes every one of 4,096 waves ran a quarter full: 29 % lane use on a repeat-rich text (round 4)
+            if (seen == 0u && nitems < kFetch * nwaves) want = kFetch;
             uint32_t base = 0;
             if (lane == 0u) base = atomicAdd(A.work_cursor, want);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1230,6 +1513,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                 attempt = 0;
                 j = d.len - b_pos < kWarmUp ? d.len : b_pos + kWarmUp;  // scan start e (one past the first position)
                 top = 0; bot = ix.n; depth = 0; pub = -1; pend = false; st = ST_EXT; k = 0; dcool = false;
+                if (kDefer) { seg = 0; jobbase = 0; }
                 if (kCarry) old = false;
                 if (kMam) { prev_top = 0; prev_bot = ix.n; }
                 // the first K letters through the jump table: no position that shallow can emit (K < L), and the scan
@@ -1403,9 +1687,9 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                 asm volatile("" : "+v"(rt.x), "+v"(rt.y), "+v"(rt.z), "+v"(rt.w), "+v"(flag8));
                 asm volatile("" : "+v"(rb0.x), "+v"(rb0.y), "+v"(rb1.x), "+v"(rb1.y));
             }
-            if (kMam) {
+            if (kMam || kChunk) {
                 // keeps the compiler from copying parts of the record out of its load's registers right behind the load (an
-                // s_waitcnt between the loads of one trip: seen in this instantiation's ISA): the values "change" here
+                // s_waitcnt between the loads of one trip: seen in these instantiations' ISA): the values "change" here
                 asm volatile("" : "+v"(rt.x), "+v"(rt.y), "+v"(rt.z), "+v"(rt.w));
             }
             const uint4 rb = make_uint4(rb0.x, rb0.y, rb1.x, rb1.y);
@@ -1417,7 +1701,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                 st = ST_EXT;
                 uint32_t t2 = top, b2 = bot;
                 pub = parent_from(rt, rb, t2, b2);
-                if (pub < L && top == bot) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; }
+                if (pub < L && top == bot) { SLAMEM_EMIT(top, 0u, (uint32_t)depth); k++; }
                 else { e_on = true; e_level0 = true; e_up = pub >= L; e_pos = 0u; e_left = 0xFFu; }
                 pend = false;
                 finished = true;
@@ -1471,7 +1755,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                     // certified.  The position in front of the disagreeing letter is left-maximal: its one row (text position
                     // dir_r) is emitted if it is long enough (no ancestor can qualify: its class was checked when the run stopped)
                     const bool in_slice = j >= a_pos && j < b_pos;
-                    if (depth >= L && in_slice) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, dir_r, j, (uint32_t)depth | 0x80000000u); k++; }
+                    if (depth >= L && in_slice) { SLAMEM_EMIT(dir_r, j, (uint32_t)depth | 0x80000000u); k++; }
                     j -= skw + 1u; dir_r -= skw + 1u; depth = (int)skw;
                     pend = false;
                     st = ST_DIR;
@@ -1558,7 +1842,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                 } else if (dmis && rt.w != 0u && !(pend && pdepth >= L)) {
                     // the letter to the left differs from the text's: what EXT + REC would do -- the pending row is
                     // left-maximal (slamem.c:141), then the interval widens to its parent and the letter is retried
-                    if (pend) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, top, j, (uint32_t)depth); k++; pend = false; }
+                    if (pend) { SLAMEM_EMIT(top, j, (uint32_t)depth); k++; pend = false; }
                     top = rt.y; bot = rt.z; depth = pdepth; pub = pdepth - 1;
                     dcool = false;
                 }
@@ -1601,7 +1885,7 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                         anc = pub >= L;
                     }
                     if (!anc && (!lvl0 || size == 1u)) {  // the common case: at most this one row, no ancestors
-                        if (lvl0) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, top, j, (uint32_t)depth); k++; }
+                        if (lvl0) { SLAMEM_EMIT(top, j, (uint32_t)depth); k++; }
                         pend = false;
                     } else {  // several rows and/or ancestors: the wave does it together, below; this trip only emits
                         e_on = true; e_level0 = lvl0; e_up = anc; e_pos = j; e_left = c;
@@ -1655,11 +1939,78 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                 finished = true;
                 if (pend && pub >= L && !pub_exact) { st = ST_FLUSH; finished = false; }  // parent depth needed: next trip
                 else if (pend && pub >= L) { e_on = true; e_level0 = true; e_up = true; e_pos = 0u; e_left = 0xFFu; }
-                else if (pend && top == bot) { emit3_sel<kCarry>(A, old, g, k, attempt << 28, top, 0u, (uint32_t)depth); k++; pend = false; }
+                else if (pend && top == bot) { SLAMEM_EMIT(top, 0u, (uint32_t)depth); k++; pend = false; }
                 else if (pend) { e_on = true; e_level0 = true; e_up = false; e_pos = 0u; e_left = 0xFFu; }
             }
         }
 
+        if (kDefer) {
+            // the job goes to the queue and the lane walks on: `pub` is already the exact depth of the parent whenever ancestors are
+            // to be reported (it was read with this trip's records), and the strand's MEM numbers are put right by K9
+            bool put = e_on && jobbase != 0xFFFFFFFFu;
+            if (put && jobbase == 0u) {  // the strand's first job: counters for every job it can still have (one per position left, and the end)
+                // (positions j .. a_pos can each have one, the strand's end another; two words in front, one behind for the total)
+                const uint32_t need = (j - a_pos) + 6u;
+                const uint32_t base = atomicAdd(A.defer.pool_next, need) + 1u;  // (place 0 is never given out: 0 = no place yet)
+                if (base <= A.defer.pool_cap && need <= A.defer.pool_cap - base) {
+                    jobbase = base;
+                    A.defer.inline_valid[g] = (uint8_t)(1u + (k < kInlineMems ? k : kInlineMems));
+                } else { jobbase = 0xFFFFFFFFu; put = false; }
+            }
+            const unsigned long long pm = __ballot(put);
+            if (pm != 0ull) {
+                // places in the queue from the wave's chunk of 64 (every lane stores the same wave-uniform values: see lds_ovf_base)
+                const uint32_t cnt = (uint32_t)__popcll(pm);
+                uint32_t q_base = lds_q_base[wv], q_left = lds_q_left[wv];
+                uint32_t q_new = 0;  // a new chunk when the old one does not hold them all: its first places take the rest
+                if (q_left < cnt) {
+                    unsigned int nb = 0;
+                    if (lane == 0u) nb = atomicAdd(A.defer.njobs, 64u);
+                    q_new = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+                }
+                if (put) {
+                    const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                    const uint32_t q = rank < q_left ? q_base + rank : q_new + (rank - q_left);
+                    if (q < A.defer.queue_cap) {
+                        uint4* w = reinterpret_cast<uint4*>(A.defer.queue + q);
+                        w[0] = make_uint4(g, k, top, bot);
+                        w[1] = make_uint4((uint32_t)depth | (e_pos << 16), e_left | (e_level0 ? 0x100u : 0u) | (e_up ? 0x200u : 0u), jobbase + 2u + seg,
+                                          A.defer.epoch);
+                        seg++;
+                        pend = false;  // the next trip extends from the same interval with the same letter
+                        e_on = false;
+                    }  // (else: the queue is full -- never, while every strand's jobs have their counters -- the job runs in the wave)
+                }
+                if (q_left < cnt) { lds_q_base[wv] = q_new + (cnt - q_left); lds_q_left[wv] = 64u - (cnt - q_left); }
+                else { lds_q_base[wv] = q_base + cnt; lds_q_left[wv] = q_left - cnt; }
+            }
+            // the MEMs of this trip that wait for their places
+            const unsigned long long sm = __ballot(em_on);
+            if (sm != 0ull) {
+                const uint32_t cnt = (uint32_t)__popcll(sm);
+                unsigned long long ovf_base = lds_ovf_base[wv];
+                uint32_t ovf_left = lds_ovf_left[wv];
+                if (ovf_left < cnt) {
+                    unsigned long long nb = 0ull;
+                    if (lane == 0u) nb = atomicAdd(A.total, (unsigned long long)kOvfChunk);
+                    ovf_base = u64_of((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nb >> 32)));
+                    ovf_left = kOvfChunk;
+                }
+                if (em_on) {
+                    const unsigned long long slot = ovf_base + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
+                    if (em_k >> 28) atomicOr(reinterpret_cast<unsigned int*>(A.total) + 9, 1u);
+                    if (slot < A.capacity) {
+                        A.raw_key[slot] = RawKey{g, em_k};
+                        A.raw_mem[slot] = slamem_mem{em_row, em_pos, em_len};
+                        // (the record was made before this trip's job, if any, was queued: seg may have moved on by one)
+                        A.defer.raw_seg[slot] = jobbase + 2u + seg - ((put && !e_on) ? 1u : 0u);
+                    }
+                    em_on = false;
+                }
+                lds_ovf_base[wv] = ovf_base + cnt;
+                lds_ovf_left[wv] = ovf_left - cnt;
+            }
+        }
         // ---- enumeration jobs, one strand at a time, all 64 lanes on its rows (every lane reaches this point) ----
         const unsigned long long t_en0 = (kStats && __ballot(e_on) != 0ull) ? wall_clock64() : 0ull;
         for (unsigned long long em = __ballot(e_on); em != 0ull; em &= em - 1ull) {
@@ -1694,6 +2045,22 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
 
         if (kStats && t_en0 != 0ull && lane == 0u) t_enum += wall_clock64() - t_en0;
 
+#ifdef SLAMEM_DIAG_TRIPS
+        if (kDefer) {
+            dg_wtrips++;
+            if (active) dg_trips++;
+            if (active && finished) {
+                atomicMax(A.defer.njobs + 4, dg_trips); atomicAdd(A.defer.njobs + 5, dg_trips); atomicAdd(A.defer.njobs + 6, 1u);
+                if (seg) { atomicAdd(A.defer.njobs + 7, dg_trips); atomicAdd(A.defer.njobs + 8, 1u); }
+                dg_trips = 0;
+            }
+        }
+#endif
+        if (kDefer && active && finished && seg != 0u) {  // K9 adds the jobs' MEMs: {jobs, MEMs the lane reported} head the strand's counters
+            A.defer.pool[jobbase] = seg;
+            A.defer.pool[jobbase + 1u] = k;
+            A.defer.list[atomicAdd(A.defer.nlist, 1u)] = make_uint2(g, jobbase);
+        }
         if (active && finished) {
             (kCarry && old ? A.prev.block_counts : A.block_counts)[g] = k;
             (kCarry && old ? A.prev.item_attempt : A.item_attempt)[g] = (uint8_t)attempt;
@@ -1701,6 +2068,9 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
         }
         if (kStats) n_enum += e_on;
     }
+#ifdef SLAMEM_DIAG_TRIPS
+    if (kDefer && lane == 0u) { atomicMax(A.defer.njobs + 9, dg_wtrips); atomicAdd(A.defer.njobs + 10, dg_wtrips); }
+#endif
     if (kStats) {
         stat_flush<kStats>(A.stats + SC_FM_TOP, n_kt); stat_flush<kStats>(A.stats + SC_FM_BOT, n_kb);
         stat_flush<kStats>(A.stats + SC_REC_FAIL_LINES, n_rec_fail); stat_flush<kStats>(A.stats + SC_REC_PEND_LINES, n_rec_pend);
@@ -2492,14 +2862,16 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
 __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__ inl, const uint32_t* __restrict__ counts,
                                                       const uint64_t* __restrict__ item_off, uint64_t nitems,
                                                       const uint32_t* __restrict__ sa, uint64_t capacity,
-                                                      slamem_mem* __restrict__ out) {
+                                                      slamem_mem* __restrict__ out, const uint8_t* __restrict__ inline_valid) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nitems) return;
     // three memory phases whatever the count (count + offset; the rows; their text positions), not two per MEM
     uint32_t cnt = counts[g];
     uint64_t off = item_off[g];
-    asm volatile("" : "+v"(cnt), "+v"(off));
+    uint32_t iv = inline_valid ? inline_valid[g] : 0u;  // (kDefer) a strand with deferred jobs: only what it reported before the first
+    asm volatile("" : "+v"(cnt), "+v"(off), "+v"(iv));
     if (cnt > kInlineMems) cnt = kInlineMems;
+    if (iv && cnt > iv - 1u) cnt = iv - 1u;
     if (cnt == 0u) return;
     static_assert(kInlineMems == 4, "k_place_inline is written for four inline slots");
     const RawRow* in = inl + g * kInlineMems;
@@ -2530,7 +2902,8 @@ __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict
                                                         const uint64_t* __restrict__ item_off,
                                                         const uint8_t* __restrict__ item_attempt,
                                                         const uint32_t* __restrict__ sa, uint64_t capacity,
-                                                        slamem_mem* __restrict__ out) {
+                                                        slamem_mem* __restrict__ out, const uint32_t* __restrict__ raw_seg,
+                                                        const uint32_t* __restrict__ pool) {
     uint64_t count = *listed;
     if (count > capacity) count = capacity;  // (records beyond the capacity were never stored: emit3_at)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -2540,6 +2913,10 @@ __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict
         if ((kk.k >> 28) != item_attempt[kk.block]) continue;  // written by an attempt that was abandoned
         slamem_mem m = raw[i];
         uint64_t pos = item_off[kk.block] + (kk.k & 0x0FFFFFFFu);
+        if (raw_seg) {  // (kDefer) a provisional number: the MEMs of the strand's jobs before this record come first
+            const uint32_t sg = raw_seg[i];
+            if (sg != 0xFFFFFFFFu) pos += pool[sg];
+        }
         if (pos >= capacity) continue;
         if (m.length >> 31) m.length &= 0x7FFFFFFFu;  // ref_pos already is the text position
         else m.ref_pos = sa[m.ref_pos];
@@ -2654,7 +3031,7 @@ constexpr uint64_t kCarryLanes = kK8Waves * 64;
 
 struct WorkspaceLayout {
     uint64_t off_total, off_cnt, off_first, off_scan32, off_items, off_counts, off_attempt, off_alive, off_workids, off_select, select_bytes, off_itemoff, off_rawkey,
-        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, off_mamstate, off_mamrun, off_itemblock, off_slicestate, off_carry, max_bounds, max_items, bytes;
+        off_rawmem, off_inline, off_scan, scan_bytes, off_wps, off_wscan, off_itempk, off_pq, pq_bytes, off_pq2, off_itemflags, off_mamstate, off_mamrun, off_itemblock, off_slicestate, off_carry, off_defscal, off_jobq, off_pool, off_rawseg, off_deflist, pool_cap, max_bounds, max_items, bytes;
 };
 
 // max_items bounds the work items of ANY batch with this many records and characters
@@ -2701,6 +3078,16 @@ WorkspaceLayout layout_workspace(uint64_t num_queries, uint64_t strands, uint64_
     w.off_itemblock = off; off = align_up(off + w.max_items * 4, 256);
     w.off_slicestate = off; off = align_up(off + w.max_bounds * sizeof(SliceState), 256);  // start states of slices (k_slice_states)
     w.off_carry = off;    off = align_up(off + kCarryLanes * sizeof(CarryRec), 256);  // lanes handed to the next launch (kCarry)
+    // kDefer: the queue of enumeration jobs, the strands' job counters, the records' places in them, the list of such strands.
+    // A counter per query position (and a few per strand) covers every job a batch can have; capped at 32 M (a batch of 10 M
+    // reads in which every tenth strand is repeat-heavy): a strand that finds the pool full runs its jobs in its wave
+    w.pool_cap = strands * (query_bytes + 6 * num_queries) + 64;
+    if (w.pool_cap > (32ull << 20)) w.pool_cap = 32ull << 20;
+    w.off_defscal = off;  off = align_up(off + 64, 256);
+    w.off_jobq = off;     off = align_up(off + (w.pool_cap + 64 * kK8Waves) * sizeof(JobRec), 256);
+    w.off_pool = off;     off = align_up(off + (w.pool_cap + 16) * 4, 256);
+    w.off_rawseg = off;   off = align_up(off + capacity * 4, 256);
+    w.off_deflist = off;  off = align_up(off + w.max_items * 8, 256);
     w.bytes = off;
     return w;
 }
@@ -2731,6 +3118,7 @@ struct SearchJob {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // before K8a, after K8, after K9, after K8a, before K8, after K7q
     bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
     bool rawkey_marked = false;  // the overflow list already carries its "unused" marks (kChunk)
+    bool deferred = false;       // this launch ran K8's kDefer instantiation: k_enum_jobs and k_defer_prefix follow
     bool seeded = false;  // this batch's MEMs come from K8s (k_seed_mems); K8 scans only the strands it left
     bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
     unsigned long long scal_own[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -3049,6 +3437,7 @@ int SearchJob::search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_o
     launched = true;
     carried_out = false;
     chunked = false;
+    deferred = false;
     if (carry_from && !(carry_from->carried_out && carry_from->can_carry_into(*this))) {
         set_error("internal: K8 asked to take in the lanes of a launch that cannot pass them on");
         return SLAMEM_ERR_ARG;
@@ -3083,8 +3472,43 @@ int SearchJob::search_k8(hipStream_t stream, SearchJob* carry_from, bool carry_o
             // a repeat-rich text at this minimum length: the instantiation whose enumeration jobs take their places in the
             // overflow list chunk-wise (wave_emit_step); every place of the list starts as "unused"
             if (mems_capacity && !rawkey_marked) STEP(hipMemsetAsync(ws + w.off_rawkey, 0xFF, mems_capacity * sizeof(RawKey), stream), "memset");
+            // reads, -mem: the jobs leave the strands' chains (kDefer; SLAMEM_ENUM_DEFER=0: in the waves, as for slices and -mam)
+            const bool env_defer = [] { const char* v = getenv("SLAMEM_ENUM_DEFER"); return !(v && atoi(v) == 0); }();
             if (sliced) hipLaunchKernelGGL((k_find_mems_v3<false, false, true, false, false, true>), grid8, dim3(256), 0, stream, A);
             else if (mam_v3) hipLaunchKernelGGL((k_find_mems_v3<false, false, false, true, false, true>), grid8, dim3(256), 0, stream, A);
+            else if (env_defer && mems_capacity) {
+                deferred = true;
+                A.defer.queue = reinterpret_cast<JobRec*>(ws + w.off_jobq);
+                unsigned int* ds = reinterpret_cast<unsigned int*>(ws + w.off_defscal);
+                A.defer.njobs = ds; A.defer.pool_next = ds + 1; A.defer.nlist = ds + 2;
+                A.defer.pool = reinterpret_cast<uint32_t*>(ws + w.off_pool);
+                A.defer.pool_cap = (uint32_t)w.pool_cap;
+                A.defer.queue_cap = (uint32_t)(w.pool_cap + 64 * kK8Waves);
+                {
+                    static std::atomic<uint32_t> launch_stamp{0x5EED0000u};
+                    A.defer.epoch = launch_stamp.fetch_add(1u) + 1u;
+                }
+                A.defer.raw_seg = reinterpret_cast<uint32_t*>(ws + w.off_rawseg);
+                A.defer.list = reinterpret_cast<uint2*>(ws + w.off_deflist);
+                A.defer.inline_valid = reinterpret_cast<uint8_t*>(ws + w.off_itemflags);
+                STEP(hipMemsetAsync(ds, 0, 64, stream), "memset");
+                STEP(hipMemsetAsync(A.defer.raw_seg, 0xFF, mems_capacity * 4, stream), "memset");
+                STEP(hipMemsetAsync(A.defer.inline_valid, 0, nitems, stream), "memset");
+                hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, false, true, true>), grid8, dim3(256), 0, stream, A);
+                STEP(hipGetLastError(), "k_find_mems_v3 (kDefer)");
+                hipLaunchKernelGGL(k_enum_jobs, dim3((unsigned)(kK8Waves / 4)), dim3(256), 0, stream, A);
+                STEP(hipGetLastError(), "k_enum_jobs");
+                hipLaunchKernelGGL(k_defer_prefix, dim3(256), dim3(256), 0, stream, A);
+#ifdef SLAMEM_DIAG_TRIPS
+                {
+                    unsigned int h[16];
+                    (void)hipMemcpyAsync(h, ds, 64, hipMemcpyDeviceToHost, stream);
+                    (void)hipStreamSynchronize(stream);
+                    fprintf(stderr, "[defer] jobs %u pool %u strands-with-jobs %u | lane trips: max %u, sum %u over %u strands; of deferring strands: sum %u over %u | wave trips: max %u sum %u | job steps per wave: max %u, sum %u, busy groups sum %u\n",
+                            h[0], h[1], h[2], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13]);
+                }
+#endif
+            }
             else hipLaunchKernelGGL((k_find_mems_v3<false, false, false, false, false, true>), grid8, dim3(256), 0, stream, A);
         } else if (A.skip_w) {  // (the skipping variant: one instantiation, with the slice logic)
             if (want_stats) hipLaunchKernelGGL((k_find_mems_v3<true, true, true, false, false>), grid8, dim3(256), 0, stream, A);
@@ -3189,11 +3613,12 @@ int SearchJob::place(hipStream_t stream) {
     STEP(hipGetLastError(), "k_block_offsets");
     if (nitems && mems_capacity) {
         hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
-                           d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev);
+                           d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev, deferred ? (const uint8_t*)A.defer.inline_valid : (const uint8_t*)nullptr);
         STEP(hipGetLastError(), "k_place_inline");
         const uint64_t ob = (mems_capacity + 255) / 256;
         hipLaunchKernelGGL(k_place_overflow, dim3((unsigned)(ob < 2048 ? ob : 2048)), dim3(256), 0, stream, A.raw_key, A.raw_mem,
-                           (const unsigned long long*)d_total, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev);
+                           (const unsigned long long*)d_total, d_itemoff, A.item_attempt, idx->view.sa, mems_capacity, mems_dev,
+                           deferred ? (const uint32_t*)A.defer.raw_seg : (const uint32_t*)nullptr, deferred ? (const uint32_t*)A.defer.pool : (const uint32_t*)nullptr);
         STEP(hipGetLastError(), "k_place_overflow");
     }
     (void)hipEventRecord(ev[2], stream);

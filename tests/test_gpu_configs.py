@@ -401,4 +401,26 @@ def test_config4_genome_like_repeat_load_known_answer(eng):
     ref_h = ref.cpu().numpy()
     reads_h = reads[: nreads * L].cpu().numpy().reshape(nreads, L)
     check_complete(ref_h, ref, reads_h, rows, sample, min_len, "config4_genome_like_verifier")
+    # Round 4: on this text K8 queues its enumeration jobs (kDefer: k_enum_jobs runs them with the whole chip, K9 puts the MEM
+    # numbers right).  The same reads at -l 20 (3,800 MEMs per read, single strands with 10^5), jobs in the queue against jobs in
+    # the waves (SLAMEM_ENUM_DEFER=0, the path the line above pins at -l 50 through the same kernels' in-wave form), and the
+    # index walk alone against the seed path in front of it: every strand's MEMs row for row in the same order.
+    import os
+    from conftest import search_path
+    small = 20_000
+    ms = idx.matcher(small, True, 120_000_000, small * L)
+    outs = {}
+    for name, defer, path in (("queue", "1", "seed"), ("waves", "0", "seed"), ("queue, index walk only", "1", "walk")):
+        os.environ["SLAMEM_ENUM_DEFER"] = defer
+        try:
+            with search_path(path):
+                tot = ms.run(reads[: small * L + 16], offsets[: small + 1], 20)
+        finally:
+            os.environ.pop("SLAMEM_ENUM_DEFER", None)
+        outs[name] = (tot, ms.block_offsets.clone(), ms.mems[:tot].clone())
+    t0, b0, r0 = outs["waves"]
+    assert t0 > 50_000_000
+    for name in ("queue", "queue, index walk only"):
+        t1, b1, r1 = outs[name]
+        assert t1 == t0 and torch.equal(b1, b0) and torch.equal(r1, r0), name
     idx.close()

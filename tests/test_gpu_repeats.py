@@ -132,12 +132,15 @@ def test_reference_with_long_diverged_repeats_builds_exactly():
     g.close()
 
 
-@pytest.mark.parametrize("chunks", ["0", "1"])
-def test_enumeration_in_chunks_equals_oracle(chunks):
+@pytest.mark.parametrize("chunks,defer,walk", [("0", "1", "0"), ("1", "1", "0"), ("1", "1", "1"), ("1", "0", "1")],
+                         ids=["plain", "chunks+queue", "chunks+queue, index walk only", "chunks in the waves, index walk only"])
+def test_enumeration_in_chunks_equals_oracle(chunks, defer, walk):
     """K8's kChunk instantiation (enumeration jobs take their places in the overflow list chunk-wise: chosen by itself on
     repeat-rich texts, ArenaHeader::lcp_ge; forced here both ways with SLAMEM_ENUM_CHUNKS in a child process) must give the
     oracle's MEMs in the oracle's order on a text that is mostly one repeat family (thousands of MEMs per strand, nearly all
-    through the overflow list), -mem and -mam, reads and a long record in slices, with the capacity retry on the way."""
+    through the overflow list), -mem and -mam, reads and a long record in slices, with the capacity retry on the way.
+    Round 4: the batch of reads alone takes K8's kDefer instantiation (the jobs go to a queue that k_enum_jobs runs with the
+    whole chip, K9 puts the MEM numbers right: SLAMEM_ENUM_DEFER), with and without the seed path in front of it."""
     import subprocess
     import sys
     import torch
@@ -166,23 +169,25 @@ for i in range(1500):
     mut = rng.random(L) < 0.02
     q[mut] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(mut.sum()))
     qs.append(q)
-qs.append(text[100_000:112_000].copy())  # a record cut into slices
-off = np.zeros(len(qs) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(x) for x in qs])
-q = np.concatenate(qs)
 o = po.OracleIndex(text.tobytes())
 g = engine.Index.build(text)
-for mam in (False, True):
-    for l in (12, 25):
-        om, obc = o.match_batch(q, off, l, True, mam=mam)
-        gm, goff = g.find_mems(q, off, l, True, mam=mam)
-        assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64)), (mam, l)
-        for f in ("ref_pos", "query_pos", "length"):
-            assert np.array_equal(gm[f], om[f]), (mam, l, f)
-        print(mam, l, len(om), int(obc.max()))
+for with_long in (True, False):  # with a record cut into slices (K8's kSliced instantiation), and the reads alone (kDefer)
+    qq = qs + [text[100_000:112_000].copy()] if with_long else qs
+    off = np.zeros(len(qq) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(x) for x in qq])
+    q = np.concatenate(qq)
+    for mam in (False, True):
+        for l in (12, 25):
+            om, obc = o.match_batch(q, off, l, True, mam=mam)
+            gm, goff = g.find_mems(q, off, l, True, mam=mam)
+            assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64)), (with_long, mam, l)
+            for f in ("ref_pos", "query_pos", "length"):
+                assert np.array_equal(gm[f], om[f]), (with_long, mam, l, f)
+            print(mam, l, len(om), int(obc.max()))
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", child, root], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       env=dict(os.environ, SLAMEM_ENUM_CHUNKS=chunks), timeout=600)
+                       env=dict(os.environ, SLAMEM_ENUM_CHUNKS=chunks, SLAMEM_ENUM_DEFER=defer, **({"SLAMEM_SEED_SEARCH": "0"} if walk == "1" else {})),
+                       timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = r.stdout.decode().split("\n")
     assert int(lines[0].split()[2]) > 200_000  # the case is enumeration-heavy

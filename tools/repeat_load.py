@@ -42,7 +42,8 @@ def run(model, idx, ref, lay, reads_n, min_len):
     per_block = (boff[1:] - boff[:-1])
     print(json.dumps({"model": model, "n": n, "min_len": min_len, "reads": reads_n, "mems": total, "mems_per_read": total / reads_n,
                       "max_mems_per_strand": int(per_block.max().item()), "strands_over_1000": int((per_block > 1000).sum().item()),
-                      "step_ms": round(step_ms, 3), "k8_ms": round(tm["k8_ms_sum"] / 3, 3), "k8a_ms": round(tm["prefilter_ms_sum"] / 3, 3),
+                      "step_ms": round(step_ms, 3), "k8s_ms": round(tm["seed_ms_sum"] / 3, 3), "k8_ms": round(tm["k8_ms_sum"] / 3, 3), "k8a_ms": round(tm["prefilter_ms_sum"] / 3, 3),
+                      "seed": {k: st[k] for k in ("seed_reads", "seed_windows", "seed_compares", "seed_mems", "seed_strands_left", "seed_left_why")},
                       "ms_per_million_reads": round(step_ms / reads_n * 1e6, 2), "capacity_retries": retries,
                       "overflow_share": st["overflow_records"] / max(1, total), "survivors": st["survivors"], "items": st["items"],
                       "lines_per_read": (st["fm_lines_top"] + st["fm_lines_bottom"] + st["rec_lines_fail"] + st["rec_lines_pend"]
