@@ -1475,7 +1475,8 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
             // a list shorter than one full piece per wave (the strands K8s left, a small batch): whole pieces at once, so that
             // few, full waves do the work and the others leave -- a wave trip costs the same instructions whatever its lanes do,
             // and with the guided sizes every one of 4,096 waves ran a quarter full: 29 % lane use on a repeat-rich text (round 4)
-            if (seen == 0u && nitems < kFetch * nwaves) want = kFetch;
+            // (a list of fewer than 16 strands per wave is a matter of latency, not of issue slots: spread thin, as the guided sizes do)
+            if (seen == 0u && nitems < kFetch * nwaves && nitems >= 16u * nwaves) want = kFetch;
             uint32_t base = 0;
             if (lane == 0u) base = atomicAdd(A.work_cursor, want);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
