@@ -430,6 +430,14 @@ def main():
             out.update(engine.host_to_host_leg(index, reads, count, L, a.min_len, both, steps=max(3, a.steps // 2) | 1))
             out["value_device_resident"] = out["value"]
             out["host_to_host_frac_of_device_resident"] = out["value_host_to_host"] / out["value"]
+            # the link's share: the reads' letters and offsets one way at the 57 GB/s measured on these boxes
+            link_ms = (count * L + 8 * count) / 57e9 * 1e3
+            out["host_to_host_link_floor_ms"] = link_ms
+            out["host_to_host_frac_of_link_floor"] = link_ms / out["host_to_host_ms"]
+            # the same leg for a caller that holds its reads as bit-planes (slamem_stream_submit_packed: 48 B per 150 letters)
+            pk = engine.host_to_host_leg(index, reads, count, L, a.min_len, both, steps=max(3, a.steps // 2) | 1, packed=True)
+            out["host_to_host_packed"] = {"value": pk["value_host_to_host"], "ms": pk["host_to_host_ms"], "mems": pk["host_to_host_mems"],
+                                          "frac_of_device_resident": pk["value_host_to_host"] / out["value"], **pk["host_to_host"]}
             if a.long_stream_reads > count:
                 # the same leg on a longer stream of the same reads' generator: ramp and end amortised, batches large enough for
                 # K8's per-launch cost; the reads are made in pieces (one generator thread per letter)

@@ -340,6 +340,20 @@ int slamem_stream_create(const slamem_index *idx, int slots, uint64_t max_batch_
                          int both_strands, int match_type, slamem_stream **out);
 int slamem_stream_submit(slamem_stream *s, const char *queries, const uint64_t *offsets, uint32_t num_queries,
                          uint32_t min_len);
+/* The same for reads the caller holds PACKED (ABI 4; no reference counterpart: the reference reads letters, sequence.c:89-270).
+ * Since the search takes ~9 ms for 10 M reads the link bounds this path (1.5 GB of letters: 26 ms); packed reads are a third.
+ *   planes   16-byte units {p0, p1} (two 64-bit words): bit i of p0 / p1 = low / high bit of letter 64u+i of the record
+ *            (A,C,G,T = 0..3; a letter that is none of them: 0 and its bit in `other`).  A record starts a new unit: record i
+ *            of `len` letters takes (len + 63) / 64 units, the units of the batch's records follow each other.
+ *   other    per unit: bit i = letter 64u+i is not one of A,C,G,T (it is searched as N, sequence.c:61-81); NULL: no such letter
+ *   offsets  as for slamem_stream_submit (in letters; only differences are used)
+ *   num_units  the units of the batch (slamem_pack_reads counts them), or 0: counted from the offsets (1 ms per million records)
+ * slamem_pack_reads makes the two arrays from letters (host, `threads` threads; units_out: their number).  16-byte aligned
+ * `planes`; pinned memory for full link rate. */
+int slamem_stream_submit_packed(slamem_stream *s, const void *planes, const uint64_t *other, const uint64_t *offsets,
+                                uint32_t num_queries, uint64_t num_units, uint32_t min_len);
+int slamem_pack_reads(const char *queries, const uint64_t *offsets, uint32_t num_queries, void *planes_out, uint64_t *other_out,
+                      uint64_t *units_out, int threads);
 int slamem_stream_next(slamem_stream *s, const slamem_mem **mems_out, const uint64_t **block_offsets_out,
                        uint64_t *total_out, uint32_t *num_queries_out, slamem_timings *timings_out);
 int slamem_stream_destroy(slamem_stream *s);

@@ -19,6 +19,7 @@
 // One thread per SLOT doing everything in turn was measured before that: the slots fall into lockstep, 62 ms.)
 // No CPU fallback: every batch is searched on the GPU.
 #include "common.h"
+#include "prims.h"
 
 #include <chrono>
 #include <condition_variable>
@@ -27,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <vector>
 
 namespace slamem {
 
@@ -59,6 +61,14 @@ struct Slot {
     const uint64_t* offs = nullptr;
     uint32_t nq = 0, min_len = 0;
     bool all_short = false;  // no record longer than a slice (seen by the upload stage while the copy engines work)
+    // a batch handed in as bit-planes (slamem_stream_submit_packed): what goes up, and the device side of it
+    const void* planes = nullptr;       // 16-byte units {p0, p1}: letters 64u .. 64u+63 of a record; a record starts a new unit
+    const uint64_t* other = nullptr;    // per unit: letters that are not A,C,G,T (nullptr: none)
+    void* d_planes = nullptr;
+    uint64_t* d_other = nullptr;
+    uint32_t* d_ucnt = nullptr;         // units per record, then their prefix sums (and the scan's scratch behind them)
+    uint64_t cap_units = 0;
+    uint64_t units_hint = 0;            // the batch's units as the caller counted them (0: count here)
     // its result
     uint64_t total = 0;
     int rc = SLAMEM_OK;
@@ -131,6 +141,114 @@ inline const char* device_queries(const Slot& sl) {
     const uint64_t base = sl.offs[0];
     return static_cast<const char*>(sl.d_q) + kFront + (base & 15u) - base;
 }
+// ---- reads that come as bit-planes (slamem_stream_submit_packed) -------------------------------------------------------------
+// The link is what bounds the host-to-host path since the search takes 9 ms for 10 M reads (1.5 GB of letters: 26 ms at 57
+// GB/s); a caller that holds its reads packed -- two bits a letter in the layout of the index's text planes, 48 bytes per 150
+// letters -- sends a third of that.  On the device the letters are written out again (k_unpack_reads: 0.5 ms per 1.5 GB) and the
+// batch goes the way of every other; letters that are not A,C,G,T travel as a third plane (or not at all: other = nullptr).
+__global__ void __launch_bounds__(256) k_unit_counts(const uint64_t* __restrict__ offsets, uint32_t nq, uint32_t* __restrict__ cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nq) return;
+    cnt[i] = i < nq ? (uint32_t)((offsets[i + 1] - offsets[i] + 63u) >> 6) : 0u;  // cnt[nq] = 0: the scan leaves the total there
+}
+constexpr uint32_t kUnpackRecords = 128, kUnpackBytes = 32768;
+// a block writes the letters of kUnpackRecords consecutive records: decoded into LDS (16 letters per lane and step), then out in
+// aligned 16-byte pieces; records too long for the buffer are written letter by letter
+__global__ void __launch_bounds__(256) k_unpack_reads(const uint4* __restrict__ planes, const uint64_t* __restrict__ other,
+                                                      const uint32_t* __restrict__ uoff, const uint64_t* __restrict__ offsets, uint32_t nq,
+                                                      char* __restrict__ out /* where record offset offsets[0] goes */) {
+    __shared__ __attribute__((aligned(16))) char buf[kUnpackBytes + 16];
+    const uint32_t r0 = blockIdx.x * kUnpackRecords, r1 = r0 + kUnpackRecords < nq ? r0 + kUnpackRecords : nq;
+    if (r0 >= nq) return;
+    const uint64_t base = offsets[0], lo = offsets[r0], hi = offsets[r1];
+    char* dst = out + (lo - base);
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);  // buf[shift + x] is byte x of the range
+    const bool staged = hi - lo <= kUnpackBytes;
+    auto letter = [&](uint64_t p0, uint64_t p1, uint64_t ot, uint32_t bit) -> char {
+        const uint32_t c = (uint32_t)((p0 >> bit) & 1ull) | ((uint32_t)((p1 >> bit) & 1ull) << 1);
+        return ((ot >> bit) & 1ull) ? 'N' : "ACGT"[c];
+    };
+    // 2 lanes per record; a lane takes 16 letters at a time, 32 apart
+    for (uint32_t r = r0 + (threadIdx.x >> 1); r < r1; r += 128u) {
+        const uint64_t ro = offsets[r];
+        const uint32_t len = (uint32_t)(offsets[r + 1] - ro);
+        const uint32_t u0 = uoff[r];
+        for (uint32_t x = (threadIdx.x & 1u) * 16u; x < len; x += 32u) {
+            const uint4 pu = planes[u0 + (x >> 6)];
+            const uint64_t p0 = ((uint64_t)pu.y << 32) | pu.x, p1 = ((uint64_t)pu.w << 32) | pu.z;
+            const uint64_t ot = other ? other[u0 + (x >> 6)] : 0ull;
+            const uint32_t n = len - x < 16u ? len - x : 16u;
+            char* w = staged ? buf + shift + (uint32_t)(ro - lo) + x : dst + (ro - lo) + x;
+            for (uint32_t i = 0; i < n; i++) w[i] = letter(p0, p1, ot, (x & 63u) + i);
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    const uint32_t nbytes = (uint32_t)(hi - lo);
+    // bytes [0, nbytes) of the range sit at buf[shift ..]; global address dst - shift is 16-byte aligned
+    const uint32_t first_full = shift ? 16u - shift : 0u;  // range bytes in front of the first aligned piece
+    for (uint32_t i = threadIdx.x; i < first_full && i < nbytes; i += 256u) dst[i] = buf[shift + i];
+    if (nbytes > first_full) {
+        const uint32_t pieces = (nbytes - first_full) >> 4;
+        uint4* g = reinterpret_cast<uint4*>(dst + first_full);
+        const uint4* l = reinterpret_cast<const uint4*>(buf + shift + first_full);
+        for (uint32_t i = threadIdx.x; i < pieces; i += 256u) g[i] = l[i];
+        for (uint32_t i = first_full + (pieces << 4) + threadIdx.x; i < nbytes; i += 256u) dst[i] = buf[shift + i];
+    }
+}
+
+int stage_upload_packed(slamem_stream* s, Slot& sl, char* dst) {
+    // the units of the batch: as the caller says, or counted here (a pass over the offsets: ~1 ms per million records, in front
+    // of the copies -- a caller that knows the number from slamem_pack_reads saves it)
+    uint64_t units = sl.units_hint;
+    if (units == 0)
+        for (uint32_t i = 0; i < sl.nq; i++) units += (sl.offs[i + 1] - sl.offs[i] + 63u) >> 6;
+    if (units >= 0xFFFFFFFFull) { set_error("slamem_stream_submit_packed: fewer than 2^32 units (64 letters) per batch"); return SLAMEM_ERR_ARG; }
+    if (!sl.d_planes || units > sl.cap_units) {
+        if (sl.d_planes) (void)hipFree(sl.d_planes);
+        if (sl.d_other) (void)hipFree(sl.d_other);
+        sl.d_planes = nullptr; sl.d_other = nullptr; sl.cap_units = 0;
+        const uint64_t want = units > (s->max_chars >> 6) + s->max_q ? units : (s->max_chars >> 6) + s->max_q;
+        SLAMEM_HIP(hipMalloc(&sl.d_planes, (want + 1) * 16));
+        SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_other), (want + 1) * 8));
+        sl.cap_units = want;
+    }
+    if (!sl.d_ucnt) SLAMEM_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_ucnt), ((uint64_t)sl.cap_q + 2 + scan_u32_tmp_words((uint64_t)sl.cap_q + 1)) * 4));
+    hipStream_t st = s->st[0];
+    SLAMEM_HIP(hipMemcpyAsync(sl.d_off, sl.offs, ((uint64_t)sl.nq + 1) * 8, hipMemcpyHostToDevice, st));
+    // the planes on the copy streams side by side (as the letters of an ordinary batch)
+    const uint64_t pbytes = units * 16;
+    const int ways = (s->upload_split > 1 && pbytes >= (8u << 20)) ? s->upload_split : 1;
+    uint64_t at = 0;
+    for (int wy = 0; wy < ways; wy++) {
+        const uint64_t end = wy + 1 == ways ? pbytes : ((pbytes * (uint64_t)(wy + 1) / (uint64_t)ways) & ~(uint64_t)4095);
+        hipStream_t cs = wy == 0 ? st : s->st_upx[wy - 1];
+        if (end > at) SLAMEM_HIP(hipMemcpyAsync(static_cast<char*>(sl.d_planes) + at, static_cast<const char*>(sl.planes) + at, end - at, hipMemcpyHostToDevice, cs));
+        at = end;
+    }
+    if (sl.other && units) SLAMEM_HIP(hipMemcpyAsync(sl.d_other, sl.other, units * 8, hipMemcpyHostToDevice, st));
+    if (sl.nq) {
+        hipLaunchKernelGGL(k_unit_counts, dim3((unsigned)(((uint64_t)sl.nq + 1 + 255) / 256)), dim3(256), 0, st, (const uint64_t*)sl.d_off, sl.nq, sl.d_ucnt);
+        SLAMEM_HIP(exclusive_scan_u32(sl.d_ucnt, sl.d_ucnt, (uint64_t)sl.nq + 1, sl.d_ucnt + sl.cap_q + 2, st));
+    }
+    {   // while the copy engines work: is any record longer than a slice?  (as in stage_upload)
+        uint64_t longest = 0;
+        for (uint32_t i = 0; i < sl.nq; i++) {
+            const uint64_t len = sl.offs[i + 1] - sl.offs[i];
+            longest = len > longest ? len : longest;
+        }
+        sl.all_short = longest <= kSearchSliceLen;
+    }
+    for (int wy = 1; wy < ways; wy++) SLAMEM_HIP(hipStreamSynchronize(s->st_upx[wy - 1]));  // (the letters are written on st: every piece must be there)
+    if (sl.nq) {
+        hipLaunchKernelGGL(k_unpack_reads, dim3((sl.nq + kUnpackRecords - 1) / kUnpackRecords), dim3(256), 0, st, (const uint4*)sl.d_planes,
+                           sl.other ? (const uint64_t*)sl.d_other : (const uint64_t*)nullptr, (const uint32_t*)sl.d_ucnt, (const uint64_t*)sl.d_off, sl.nq, dst);
+        SLAMEM_HIP(hipGetLastError());
+    }
+    SLAMEM_HIP(hipStreamSynchronize(st));
+    return SLAMEM_OK;
+}
+
 int stage_upload(slamem_stream* s, Slot& sl) {
     const uint64_t base = sl.offs[0], qbytes = sl.offs[sl.nq] - base;
     if (!sl.d_q || qbytes > sl.cap_chars || sl.nq > sl.cap_q) {
@@ -143,6 +261,8 @@ int stage_upload(slamem_stream* s, Slot& sl) {
         if (sl.d_boff) (void)hipFree(sl.d_boff);
         if (sl.d_mems) (void)hipFree(sl.d_mems);
         if (sl.d_ws) (void)hipFree(sl.d_ws);
+        if (sl.d_ucnt) (void)hipFree(sl.d_ucnt);
+        sl.d_ucnt = nullptr;
         sl.d_q = nullptr; sl.d_off = nullptr; sl.d_boff = nullptr; sl.d_mems = nullptr; sl.d_ws = nullptr;  // (the prepare stage sizes its own)
         sl.cap_chars = 0; sl.cap_q = 0;  // until all three are there: a failed allocation must not leave stale room behind
         SLAMEM_HIP(hipMalloc(&sl.d_q, nchars + 2 * kFront + 32));
@@ -152,6 +272,7 @@ int stage_upload(slamem_stream* s, Slot& sl) {
         sl.cap_q = nrec;
     }
     char* dst = static_cast<char*>(sl.d_q) + kFront + (base & 15u);
+    if (sl.planes) return stage_upload_packed(s, sl, dst);
     const char* src = sl.chars + base;
     // Beside K8 -- which keeps the memory system at its random-request ceiling -- ONE copy engine moves 42 GB/s instead of the
     // link's 57 (measured: 3.56 ms per 158 MB instead of 2.76, which made the upload the pipeline's period); the pieces of a
@@ -365,6 +486,9 @@ void free_slot(Slot& sl) {
     if (sl.d_boff) (void)hipFree(sl.d_boff);
     if (sl.d_mems) (void)hipFree(sl.d_mems);
     if (sl.d_ws) (void)hipFree(sl.d_ws);
+    if (sl.d_planes) (void)hipFree(sl.d_planes);
+    if (sl.d_other) (void)hipFree(sl.d_other);
+    if (sl.d_ucnt) (void)hipFree(sl.d_ucnt);
     if (sl.h_boff) (void)hipHostFree(sl.h_boff);
     if (sl.h_mems) (void)hipHostFree(sl.h_mems);
     if (sl.h_scal) (void)hipHostFree(sl.h_scal);
@@ -383,6 +507,47 @@ int slamem_pinned_alloc(void** out, uint64_t bytes) {
     if (!out) return SLAMEM_ERR_ARG;
     *out = nullptr;
     SLAMEM_HIP(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return SLAMEM_OK;
+}
+
+// letters -> bit-planes on the host (what a caller without packed reads of its own puts in front of slamem_stream_submit_packed)
+int slamem_pack_reads(const char* queries, const uint64_t* offsets, uint32_t num_queries, void* planes_out, uint64_t* other_out,
+                      uint64_t* units_out, int threads) {
+    if (!offsets || (num_queries && (!queries || !planes_out))) { set_error("slamem_pack_reads: null argument"); return SLAMEM_ERR_ARG; }
+    // the first unit of every record: a prefix sum (one pass), then the records in ranges, a thread each
+    std::vector<uint64_t> first((size_t)num_queries + 1);
+    uint64_t units = 0;
+    for (uint32_t i = 0; i < num_queries; i++) { first[i] = units; units += (offsets[i + 1] - offsets[i] + 63u) >> 6; }
+    first[num_queries] = units;
+    if (units_out) *units_out = units;
+    uint64_t* pl = static_cast<uint64_t*>(planes_out);
+    auto work = [&](uint32_t a, uint32_t b) {
+        for (uint32_t r = a; r < b; r++) {
+            const unsigned char* q = reinterpret_cast<const unsigned char*>(queries) + offsets[r];
+            const uint64_t len = offsets[r + 1] - offsets[r];
+            for (uint64_t u = 0; u * 64 < len; u++) {
+                uint64_t p0 = 0, p1 = 0, ot = 0;
+                const uint64_t n = len - u * 64 < 64 ? len - u * 64 : 64;
+                for (uint64_t i = 0; i < n; i++) {
+                    const unsigned c = q[u * 64 + i] & 0xDFu;  // upper case
+                    const unsigned x = (c >> 1) & 3u, code = x ^ (x >> 1);  // A 0, C 1, G 2, T 3
+                    const bool ok = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+                    if (ok) { p0 |= (uint64_t)(code & 1u) << i; p1 |= (uint64_t)(code >> 1) << i; } else ot |= 1ull << i;
+                }
+                pl[2 * (first[r] + u)] = p0;
+                pl[2 * (first[r] + u) + 1] = p1;
+                if (other_out) other_out[first[r] + u] = ot;
+            }
+        }
+    };
+    const int nt = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+    if (nt == 1 || num_queries < 4096u) work(0, num_queries);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back(work, (uint32_t)((uint64_t)num_queries * t / nt), (uint32_t)((uint64_t)num_queries * (t + 1) / nt));
+        for (auto& x : th) x.join();
+    }
     return SLAMEM_OK;
 }
 
@@ -509,6 +674,37 @@ int slamem_stream_submit(slamem_stream* s, const char* queries, const uint64_t* 
     }
     sl.seq = s->submitted;
     sl.chars = queries;
+    sl.planes = nullptr;
+    sl.other = nullptr;
+    sl.offs = offsets;
+    sl.nq = num_queries;
+    sl.min_len = min_len;
+    sl.rc = SLAMEM_OK;
+    sl.err[0] = 0;
+    sl.total = 0;
+    sl.state = QUEUED;
+    s->submitted++;
+    lk.unlock();
+    s->cv.notify_all();
+    return SLAMEM_OK;
+}
+
+int slamem_stream_submit_packed(slamem_stream* s, const void* planes, const uint64_t* other, const uint64_t* offsets, uint32_t num_queries,
+                                uint64_t num_units, uint32_t min_len) {
+    if (!s || !offsets || (num_queries && !planes)) { set_error("slamem_stream_submit_packed: null argument"); return SLAMEM_ERR_ARG; }
+    if (((uintptr_t)planes & 15u) != 0) { set_error("slamem_stream_submit_packed: planes must be 16-byte aligned"); return SLAMEM_ERR_ARG; }
+    if (min_len < 1) { set_error("slamem_stream_submit_packed: minimum MEM length must be >= 1"); return SLAMEM_ERR_ARG; }
+    std::unique_lock<std::mutex> lk(s->mu);
+    Slot& sl = s->slot[s->submitted % (uint64_t)s->nslots];
+    if (sl.state != FREE) {
+        set_error("slamem_stream_submit_packed: all %d slots are in use (collect a result with slamem_stream_next first)", s->nslots);
+        return SLAMEM_ERR_ARG;
+    }
+    sl.seq = s->submitted;
+    sl.chars = nullptr;
+    sl.planes = planes;
+    sl.other = other;
+    sl.units_hint = num_units;
     sl.offs = offsets;
     sl.nq = num_queries;
     sl.min_len = min_len;

@@ -297,6 +297,14 @@ class Stream:
         capi.check(capi.lib().slamem_stream_submit(self._h, chars.ctypes.data, offsets.ctypes.data, offsets.shape[0] - 1,
                                                    int(min_len)))
 
+    def submit_packed(self, planes: np.ndarray, other, offsets: np.ndarray, min_len: int, units: int = 0) -> None:
+        """planes: uint8 view of the batch's 16-byte units (slamem_pack_reads layout), other: uint64 per unit or None; offsets:
+        uint64[num+1] in letters.  All must stay alive and unchanged until collected."""
+        assert planes.dtype == np.uint8 and offsets.dtype == np.uint64 and offsets.flags.c_contiguous
+        self._keep.append((planes, other, offsets))
+        capi.check(capi.lib().slamem_stream_submit_packed(self._h, planes.ctypes.data, other.ctypes.data if other is not None else None,
+                                                          offsets.ctypes.data, offsets.shape[0] - 1, int(units), int(min_len)))
+
     def next(self, copy: bool = True):
         """(mems structured array, block_offsets uint64 array, timings dict) of the oldest batch.  copy=False returns
         views of the stream's pinned buffers, valid until the next call."""
@@ -325,8 +333,16 @@ class Stream:
             pass
 
 
+def pack_reads(chars: np.ndarray, offsets: np.ndarray, planes_out: np.ndarray, other_out, threads: int = 16) -> int:
+    """slamem_pack_reads: letters -> bit-planes (16-byte units) on the host; returns the number of units."""
+    units = C.c_uint64()
+    capi.check(capi.lib().slamem_pack_reads(chars.ctypes.data, offsets.ctypes.data, offsets.shape[0] - 1, planes_out.ctypes.data,
+                                            other_out.ctypes.data if other_out is not None else None, C.byref(units), int(threads)))
+    return int(units.value)
+
+
 def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len: int, min_len: int, both: bool,
-                     steps: int = 2, batch_reads: int = 1_000_000, slots: int = 6, schedule=None) -> dict:
+                     steps: int = 2, batch_reads: int = 1_000_000, slots: int = 6, schedule=None, packed: bool = False) -> dict:
     """SURVEY.md 8(d)'s metric as defined -- reads resident in host memory -> MEM triples in host memory -- through
     slamem_stream_*: the reads sit in pinned host memory, batches of `batch_reads` are pipelined over `slots` lanes, and
     the clock runs from the first submit to the last result.  Returns fields for the bench line."""
@@ -353,14 +369,24 @@ def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len
         cuts.append(pos)
     nb = len(cuts) - 1
     biggest = int(np.diff(np.array(cuts)).max())
+    pbuf, upr = None, (L + 63) // 64  # packed: the reads as bit-planes in pinned memory (made once, before the clock starts)
+    if packed:
+        pbuf = PinnedBuffer(count * upr * 16 + 64)
+        assert pack_reads(buf.array, offsets, pbuf.array, None) == count * upr
     st = Stream(index, slots, biggest * L, biggest, both)
+
+    def submit(b):
+        if packed:
+            st.submit_packed(pbuf.array[cuts[b] * upr * 16:], None, offsets[cuts[b]: cuts[b + 1] + 1], min_len, units=(cuts[b + 1] - cuts[b]) * upr)
+        else:
+            st.submit(buf.array, offsets[cuts[b]: cuts[b + 1] + 1], min_len)
     passes, total_mems, kernel_ms = [], 0, 0.0
     try:
         for rep in range(steps + 1):  # first pass warms the stream's buffers up
             t0 = time.perf_counter()
             got, kms = 0, 0.0
             for b in range(min(slots - 1, nb)):
-                st.submit(buf.array, offsets[cuts[b]: cuts[b + 1] + 1], min_len)
+                submit(b)
             marks = []
             for b in range(nb):
                 m, _, tm = st.next(copy=False)
@@ -369,7 +395,7 @@ def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len
                 marks.append((time.perf_counter(), len(m)))
                 nxt = b + slots - 1
                 if nxt < nb:
-                    st.submit(buf.array, offsets[cuts[nxt]: cuts[nxt + 1] + 1], min_len)
+                    submit(nxt)
             dt = time.perf_counter() - t0
             if rep:
                 # the pipeline's rate once it is full: results of the full-size batches in the middle of the run
@@ -382,12 +408,15 @@ def host_to_host_leg(index: Index, reads_dev: torch.Tensor, count: int, read_len
         offsets = None
         obuf.close()
         buf.close()
+        if pbuf is not None:
+            pbuf.close()
     passes.sort(key=lambda x: x[0])
     best = passes[0][0]
     med, steady = passes[len(passes) // 2] if len(passes) % 2 else \
         ((passes[len(passes) // 2 - 1][0] + passes[len(passes) // 2][0]) / 2, passes[len(passes) // 2][1])
     return {"value_host_to_host": total_mems / med, "host_to_host_ms": med * 1e3, "host_to_host_mems": int(total_mems),
-            "host_to_host": {"batches": nb, "batch_reads": batch_reads, "slots": slots, "h2d_bytes": count * L,
+            "host_to_host": {"batches": nb, "batch_reads": batch_reads, "slots": slots,
+                             "h2d_bytes": (count * upr * 16 if packed else count * L) + 8 * (count + nb), "packed": bool(packed),
                              "passes_ms": [round(p[0] * 1e3, 3) for p in passes], "best_ms": best * 1e3,
                              "d2h_bytes": 12 * int(total_mems) + 8 * (count * (2 if both else 1) + nb),
                              "kernel_ms_sum": kernel_ms,

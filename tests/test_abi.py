@@ -183,3 +183,39 @@ def test_index_build_bytes_is_host_arithmetic():
     assert pc100 < pf100 and pc3g < pf3g < 288 * 2**30  # the full layout of a 3.1 Gbp text fits an MI355X while it is built
     assert L.slamem_index_build_bytes(0, capi.LAYOUT_FULL, C.byref(a), C.byref(p)) == capi.SLAMEM_ERR_ARG
     assert L.slamem_index_build_bytes(1000, capi.LAYOUT_AUTO, C.byref(a), C.byref(p)) == capi.SLAMEM_ERR_ARG
+
+
+def test_pack_reads_is_host_code_and_matches_numpy():
+    """slamem_pack_reads (what a caller puts in front of slamem_stream_submit_packed): letters -> two bit-planes + the plane of
+    letters that are not A,C,G,T, 16-byte units, a record starts a new unit; no GPU involved."""
+    import numpy as np
+    from slamem_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 63, 64, 65, 128, 150, 150, 300, 7]
+    recs = [rng.choice(np.frombuffer(b"ACGTacgtNRY", dtype=np.uint8), size=n) for n in lens]
+    q = np.concatenate(recs)
+    off = np.zeros(len(recs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    units = sum((n + 63) // 64 for n in lens)
+    for threads in (1, 4):
+        pl = np.zeros(2 * units + 2, dtype=np.uint64)
+        ot = np.zeros(units + 1, dtype=np.uint64)
+        got = C.c_uint64()
+        assert L.slamem_pack_reads(q.ctypes.data, off.ctypes.data, len(recs), pl.ctypes.data, ot.ctypes.data, C.byref(got), threads) == 0
+        assert got.value == units
+        u = 0
+        code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
+        for r in recs:
+            for k in range(0, len(r), 64):
+                p0 = p1 = o = 0
+                for i, ch in enumerate(r[k:k + 64]):
+                    c = code.get(int(ch) & 0xDF)
+                    if c is None:
+                        o |= 1 << i
+                    else:
+                        p0 |= (c & 1) << i
+                        p1 |= (c >> 1) << i
+                assert (int(pl[2 * u]), int(pl[2 * u + 1]), int(ot[u])) == (p0, p1, o)
+                u += 1
+        assert u == units

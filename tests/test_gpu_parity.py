@@ -316,6 +316,44 @@ def test_stream_host_to_host_matches_device_path(eng):
     idx.close()
 
 
+def test_stream_packed_reads_match_the_letters(eng):
+    """slamem_stream_submit_packed: the same batches handed in as bit-planes (slamem_pack_reads; letters that are not A,C,G,T in
+    the third plane) give what the letters give -- the oracle's MEMs in order -- for reads of every length incl. empty ones,
+    long records (cut into slices), N, windows of the offsets with a non-zero base, and with the `other` plane left out when
+    the batch has no such letter."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(44)
+    text = rand_text(rng, 80000, "ACGT", 20, max_rep=300)
+    qs = make_queries(rng, text, 700, "ACGTN") + [np.frombuffer(bytes(text[5000:14000]), dtype=np.uint8), np.zeros(0, dtype=np.uint8)]
+    qs += [np.frombuffer(bytes(text[a:a + 150]), dtype=np.uint8) for a in rng.integers(0, 70000, 600)]
+    q, off = pack(qs)
+    idx = eng.Index.build(text)
+    o = po.OracleIndex(bytes(text))
+    nq = len(qs)
+    per = 211
+    wins = [off[b * per: min(nq, (b + 1) * per) + 1] for b in range((nq + per - 1) // per)]
+    chars = np.frombuffer(q, dtype=np.uint8) if not isinstance(q, np.ndarray) else q
+    st = eng.Stream(idx, 3, 1 << 17, per, True)
+    keep = []
+    for b, w in enumerate(wins):
+        units = int(((np.diff(w) + 63) // 64).sum())
+        pl = eng.PinnedBuffer(units * 16 + 64)
+        ot = np.zeros(units + 1, dtype=np.uint64)
+        assert eng.pack_reads(chars, w, pl.array, ot, threads=3) == units
+        has_other = bool(ot.any())
+        keep.append(pl)
+        st.submit_packed(pl.array, ot if has_other or b % 2 == 0 else None, w, 13, units=units if b % 3 else 0)
+        m, boff, _ = st.next()
+        om, obc = o.match_batch(chars[int(w[0]): int(w[-1])], w - w[0], 13, True)
+        assert np.array_equal(np.diff(boff.astype(np.int64)), obc.astype(np.int64)), b
+        for f in ("ref_pos", "query_pos", "length"):
+            assert np.array_equal(m[f], om[f]), (b, f)
+    st.close()
+    for pl in keep:
+        pl.close()
+    idx.close()
+
+
 def test_a_slice_with_2_to_the_28_mems_is_an_error_not_wrong_output(eng):
     """The overflow records carry the MEM's ordinal within its work item in 28 bits.  A text of 1.4 M copies of one 20-mer,
     each behind a different letter than the query's, and a 4095-letter query of 195 copies: 273 M MEMs from ONE slice.
