@@ -355,7 +355,7 @@ def test_stream_packed_reads_match_the_letters(eng):
 
 
 def test_a_slice_with_2_to_the_28_mems_is_an_error_not_wrong_output(eng):
-    """The overflow records carry the MEM's ordinal within its work item in 28 bits.  A text of 1.4 M copies of one 20-mer,
+    """The overflow records carry the MEM's ordinal within its work item (since round 4: within its job, when K8 queues them) in 28 bits.  A text of 1.4 M copies of one 20-mer,
     each behind a different letter than the query's, and a 4095-letter query of 195 copies: 273 M MEMs from ONE slice.
     The call must fail with SLAMEM_ERR_ARG and a message that names the limit (not SLAMEM_ERR_CAPACITY, which callers
     answer by asking again)."""
@@ -370,9 +370,25 @@ def test_a_slice_with_2_to_the_28_mems_is_an_error_not_wrong_output(eng):
     assert query.shape[0] == 4095
     idx = eng.Index.build(text.reshape(-1))
     off = np.array([0, query.shape[0]], dtype=np.uint64)
-    with pytest.raises(capi.SlamemError) as e:
-        idx.find_mems(query, off, 20, False)
+    import os
+    os.environ["SLAMEM_ENUM_DEFER"] = "0"  # the jobs in the waves: one MEM numbering per strand, 28 bits of it in a record
+    try:
+        with pytest.raises(capi.SlamemError) as e:
+            idx.find_mems(query, off, 20, False)
+    finally:
+        os.environ.pop("SLAMEM_ENUM_DEFER", None)
     assert e.value.code == capi.SLAMEM_ERR_ARG and "2^28" in str(e.value)
+    # Round 4: with the jobs in the queue (the default on such a text) a record's number counts within its job and K9 adds what
+    # comes before in 64 bits: the same call answers -- every one of the 195 copies in the query against every copy in the text
+    import torch
+    m = idx.matcher(1, False, 280_000_000, query.shape[0])
+    qd = torch.zeros(4096 + 16, dtype=torch.uint8, device="cuda:0")
+    qd[:4095] = torch.from_numpy(query).to("cuda:0")
+    total = m.run(qd, torch.from_numpy(off.view(np.int64)).to("cuda:0"), 20)
+    assert total == 195 * copies
+    got = m.mems[:total]
+    assert int(got[:, 2].min()) == 20 and int(got[:, 2].max()) == 20 and torch.equal(got[::copies, 1].cpu(), torch.arange(194, -1, -1, dtype=torch.int32) * 21 + 1)
+    del m, got
     # one letter fewer per copy of the query's motif: nothing reaches min_len, and the same index answers normally
     m, boff = idx.find_mems(np.tile(np.concatenate([np.frombuffer(b"G", dtype=np.uint8), motif[:19]]), 100), np.array([0, 2000], dtype=np.uint64), 20, False)
     assert len(m) == 0 and list(boff) == [0, 0]
