@@ -81,7 +81,7 @@ def check(eng, text, qs, l, both, expect_seed=True, max_left_frac=None, min_left
         if expect_seed:
             assert g.info.seed_k >= 4 and l >= g.info.seed_k + 3
             assert st["seed_reads"] == len(qs), "the seed path did not take this batch"
-            assert st["survivors"] == st["seed_strands_left"]
+            assert st["survivors"] <= st["seed_strands_left"]  # (what K8 scans: the strands left, less those the presence filter proves empty)
             if max_left_frac is not None:
                 assert st["seed_strands_left"] <= max_left_frac * st["items"], st
             assert st["seed_strands_left"] >= min_left, st
@@ -305,4 +305,5 @@ def test_full_size_headline_both_paths_agree_in_order(eng):
     with search_path("seed"):
         st = eng.search_stats(m, reads, offsets, 20)
     assert st["seed_reads"] == nreads and st["seed_windows"] == 27 * nreads and st["seed_strands_left"] < 0.01 * 2 * nreads
+    assert st["survivors"] < 0.6 * st["seed_strands_left"]  # the wrong strands of the reads that were left whole die in the presence filter
     idx.close()
