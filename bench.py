@@ -51,11 +51,13 @@ FIXED_BYTES_PER_BASE = 155.0  # SURVEY.md 8(d) figure for these reads
 # tests/tools/calibrate_port_vs_reference.py (its output is committed: profiles/r03_port_vs_reference.json); the port is the
 # faster of the two, i.e. a conservative CPU baseline.  1.22 = round 1's measurement (30.0 k vs 24.5 k MEMs/s, one Xeon core).
 def _port_vs_reference_ratio() -> float:
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_port_vs_reference.json")) as f:
-            return float(json.load(f)["port_vs_reference_ratio"])
-    except (OSError, KeyError, ValueError):
-        return 1.22
+    for name in ("r04_port_vs_reference.json", "r03_port_vs_reference.json"):  # the latest calibration that is there
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)["port_vs_reference_ratio"])
+        except (OSError, KeyError, ValueError):
+            pass
+    return 1.22
 
 
 PORT_VS_REFERENCE_RATIO = _port_vs_reference_ratio()

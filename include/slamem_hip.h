@@ -360,6 +360,8 @@ int slamem_stream_destroy(slamem_stream *s);
 /* Page-locked host memory for a front end's read buffers (hipHostMalloc / hipHostFree). */
 int slamem_pinned_alloc(void **out, uint64_t bytes);
 int slamem_pinned_free(void *p);
+/* hipMemcpy device -> host (for a front end that fills its pinned buffers from device memory). */
+int slamem_copy_to_host(void *dst_host, const void *src_dev, uint64_t bytes);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,8 @@ MEM_DTYPE = np.dtype([("ref_pos", "<u4"), ("query_pos", "<u4"), ("length", "<u4"
 
 
 def build_lib(force: bool = False) -> str:
+    if os.environ.get("SLAMEM_ORACLE_LIB"):  # another build of the restatement (oracle/Makefile: liboracle_asan.so)
+        return os.environ["SLAMEM_ORACLE_LIB"]
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

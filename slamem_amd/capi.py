@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "slamem_find_mams_device", "slamem_find_mams_host",
     "slamem_stream_create", "slamem_stream_submit", "slamem_stream_submit_packed", "slamem_pack_reads", "slamem_stream_next",
     "slamem_stream_destroy",
-    "slamem_pinned_alloc", "slamem_pinned_free",
+    "slamem_pinned_alloc", "slamem_pinned_free", "slamem_copy_to_host",
 )
 
 
@@ -141,6 +141,7 @@ def _declare(L):
     L.slamem_find_mams_host.argtypes = L.slamem_find_mems_host.argtypes
     L.slamem_stream_create.argtypes = [vp, i32, u64, u32, i32, i32, C.POINTER(vp)]
     L.slamem_stream_submit.argtypes = [vp, vp, vp, u32, u32]
+    L.slamem_copy_to_host.argtypes = [vp, vp, u64]
     L.slamem_stream_submit_packed.argtypes = [vp, vp, vp, vp, u32, u64, u32]
     L.slamem_pack_reads.argtypes = [vp, vp, u32, vp, vp, C.POINTER(u64), i32]
     L.slamem_stream_next.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u32), C.POINTER(Timings)]

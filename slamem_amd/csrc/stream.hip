@@ -98,9 +98,10 @@ struct slamem_stream {
     hipStream_t st_upx[3] = {nullptr, nullptr, nullptr};  // more copy streams of the upload stage (SLAMEM_STREAM_UPLOAD_SPLIT = 2..4)
     int upload_split = 2;
     int nthreads = kThreads;
-    // SLAMEM_STREAM_CARRY=1: K8 without its tail (below).  Off by default: it raises the pipeline's steady rate (868 M against
-    // 714 M MEMs/s with million-read batches) but every result then waits for the NEXT batch's K8, and on the 12 batches of
-    // the headline workload that latency costs more than the tails did (40.0 ms against 38.5; profiles/r03_host_leg.jsonl)
+    // SLAMEM_STREAM_CARRY=1: K8 without its tail (below).  Off by default: it does not pay -- every result then waits for the
+    // NEXT batch's K8, and the carried lanes finish their strands at the head of that launch instead of the tail of this one
+    // (headline workload, round 3: 39.5-40.0 ms against 38.5; a stream of 30 M reads 113.8 against 108.6 ms; the "steady rate" of
+    // 868 M MEMs/s the first runs showed was an artefact of where the results' time stamps fall; profiles/r03_host_leg.jsonl)
     bool carry = false;
     Slot* pending = nullptr;     // search stage only: the batch whose K8 has passed its unfinished lanes on
     hipStream_t st_place = nullptr;    // K9 of every batch: behind the K8 that finished it, but not in front of the next K8
@@ -551,6 +552,14 @@ int slamem_pack_reads(const char* queries, const uint64_t* offsets, uint32_t num
     return SLAMEM_OK;
 }
 
+// device -> host copy for a front end that fills its (pinned) read buffers from device memory (bench.py, tools): one DMA into
+// page-locked memory instead of the runtime's staged copy of pageable memory
+int slamem_copy_to_host(void* dst_host, const void* src_dev, uint64_t bytes) {
+    if (bytes && (!dst_host || !src_dev)) { set_error("slamem_copy_to_host: null argument"); return SLAMEM_ERR_ARG; }
+    if (bytes) SLAMEM_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return SLAMEM_OK;
+}
+
 int slamem_pinned_free(void* p) {
     if (p) SLAMEM_HIP(hipHostFree(p));
     return SLAMEM_OK;
@@ -573,6 +582,15 @@ int slamem_stream_destroy(slamem_stream* s) {
     for (int k = 0; k < s->nthreads; k++)
         if (s->th[k].joinable()) s->th[k].join();
     (void)hipSetDevice(s->idx->device);
+    // every copy and kernel of the stream's own HIP streams is through before buffers and streams go (the stages wait for their
+    // work batch by batch; this is for whatever a failed batch left behind, and for tools that watch the copies: a profiler waited
+    // 30 s at exit for completion callbacks of copies whose streams were destroyed under it, profiles/README.md)
+    for (int k = 0; k < kThreads; k++)
+        if (s->st[k]) (void)hipStreamSynchronize(s->st[k]);
+    for (int k = 0; k < 3; k++)
+        if (s->st_upx[k]) (void)hipStreamSynchronize(s->st_upx[k]);
+    if (s->st_search2) (void)hipStreamSynchronize(s->st_search2);
+    if (s->st_place) (void)hipStreamSynchronize(s->st_place);
     for (int k = 0; k < s->nslots; k++) free_slot(s->slot[k]);
     for (int k = 0; k < kThreads; k++)
         if (s->st[k]) (void)hipStreamDestroy(s->st[k]);

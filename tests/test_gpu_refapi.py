@@ -102,7 +102,8 @@ def test_the_reference_driver_runs_on_the_gpu_index(tmp_path):
     exe = os.path.join(ROOT, "oracle", "_ref", "slaMEM-gpu-index")
     layer()  # (fails without a GPU)
     if not os.path.exists(exe):
-        return
+        # (the binary is built from /root/reference where that exists and travels with the tree: a box without it must say so)
+        pytest.skip("oracle/_ref/slaMEM-gpu-index not present: the reference's driver on the GPU index was NOT run (22 file comparisons)")
     for case in CASES:
         ref_fa, q_fa, exp_mems, _ = case_paths(case)
         out = str(tmp_path / (case + ".txt"))

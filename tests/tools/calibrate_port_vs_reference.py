@@ -6,7 +6,7 @@ compiled by oracle/Makefile from /root/reference).  Same reference text, same re
     real reference   oracle/_ref/slaMEM -b -l 20, matching = wall of the whole run - wall of a run with ONE read
                      (load + index build), stdout to a file (keep stdout off pipes when timing)
 
-Writes profiles/r03_port_vs_reference.json; bench.py reads the ratio from there.
+Writes profiles/r04_port_vs_reference.json; bench.py reads the ratio from there.
     tests/tools/calibrate_port_vs_reference.py [ref_len=100000000] [reads=200000]"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -55,7 +55,7 @@ out = {"ref_len": n, "reads": R, "read_len": L, "options": "-b -l 20", "mems": r
        "host": "build container, one core each (the other cores busy with two reference runs of the round)" if os.environ.get("CAL_BUSY") else "build container, one core each",
        "nproc": os.cpu_count()}
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-with open(os.path.join(ROOT, "profiles", "r03_port_vs_reference.json"), "w") as f:
+with open(os.path.join(ROOT, "profiles", "r04_port_vs_reference.json"), "w") as f:
     json.dump(out, f, indent=1)
     f.write("\n")
 print(json.dumps(out))
