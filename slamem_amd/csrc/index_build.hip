@@ -1016,6 +1016,8 @@ static void plan_arena(uint32_t n, uint32_t num_n, int layout, ArenaHeader& hdr)
             while ((4ull << lg) < (uint64_t)n) lg++;
             uint32_t k = (lg + 7u) / 2u;
             if (k > 16u) k = 16u;
+            // (experiments: SLAMEM_SEED_K=<k> asks for shorter seeds -- fewer windows per read, more chance occurrences)
+            if (se && atoi(se) >= 8 && (uint32_t)atoi(se) < k && 2u * (uint32_t)atoi(se) >= lg) k = (uint32_t)atoi(se);
             hdr.seed_k = k;
             hdr.seed_log2 = lg;
             const uint64_t units = text_units(n);
