@@ -173,7 +173,8 @@ def test_arena_export_attach_save_load(eng, tmp_path):
 
 
 def test_config2_known_answer_full_size(eng):
-    """BASELINE.json configs[1] at full size: 100 Mbp reference, 1 M x 150 bp reads, forward, -l 20.
+    """BASELINE.json configs[1] at full size: 100 Mbp reference, 1 M x 150 bp reads, forward, -l 20 (and the index through a
+    file: an arena of 8.2 GB saved, loaded, searched again).
     Known answers recorded from the REAL reference in SURVEY.md Appendix C.3 (2,412,288 MEMs, sum of lengths
     133,301,375, sha256 prefix 9d583ab9312e1698 of the numerically sorted 'ref<TAB>query<TAB>len' lines)."""
     import hashlib
@@ -210,7 +211,26 @@ def test_config2_known_answer_full_size(eng):
     order = np.lexsort((ln, q, r))
     lines = b"".join(b"%d\t%d\t%d\n" % (r[i] + 1, q[i] + 1, ln[i]) for i in order)
     assert hashlib.sha256(lines).hexdigest().startswith("9d583ab9312e1698")
-    idx.close()
+    # save -> load of an arena beyond 4 GiB (8.2 GB: 64-bit offsets, sections in every size class), then the same search on the
+    # loaded index -- both paths, since the file must carry the seed sections and the index walk's alike
+    import os
+    import tempfile
+    from conftest import search_path
+    assert idx.info.arena_bytes > (4 << 30)
+    first = m.mems[:total].clone()
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+        path = os.path.join(td, "index.slamem")
+        idx.save(path)
+        assert os.path.getsize(path) == idx.info.arena_bytes
+        idx.close()
+        idx2 = eng.Index.load(path, "cuda:0")
+    assert idx2.info.arena_bytes > (4 << 30) and idx2.info.seed_k == 16
+    m2 = idx2.matcher(nreads, False, 4 * nreads, nreads * L)
+    for path_name in ("seed", "walk"):
+        with search_path(path_name):
+            assert m2.run(reads, offsets, 20) == total
+        assert torch.equal(m2.mems[:total], first) and torch.equal(m2.block_offsets, m.block_offsets), path_name
+    idx2.close()
 
 
 def test_config3_known_answer_full_size(eng):
