@@ -103,21 +103,40 @@ void slh_free_seqset(slh_seqset *s) {
     memset(s, 0, sizeof(*s));
 }
 
-/* 1 if the `len` bytes at p are all upper-case A, C, G or T (a line of a read file almost always is: it is then copied
- * as it stands instead of going through the table byte by byte) */
-static int line_is_acgt(const unsigned char *p, size_t len) {
+/* A whole line at once (sequence.c:61-81 for a line that holds nothing but letters): the `len` bytes at p are written to dst as
+ * the table would write them -- A,C,G,T of either case as upper case; every other letter as 'N' (allow_ns), or none may occur
+ * (!allow_ns: such a line takes the byte loop, which drops them).  Returns 0 -- whatever it wrote so far is to be ignored -- when
+ * the line holds a byte the rule does not cover (a digit, a blank, '>', '*', ...): the byte loop then does the line.  A
+ * soft-masked assembly (half of it lower case) and IUPAC letters stay on this path; 16 bytes per step with SSE2. */
+static int line_of_letters(unsigned char *dst, const unsigned char *p, size_t len, int allow_ns) {
     size_t i = 0;
+    static int slow = -1; /* SLAMEM_LOADER_BYTEWISE=1: every line through the byte loop (what the tests compare this path with) */
+    if (slow < 0) { const char *v = getenv("SLAMEM_LOADER_BYTEWISE"); slow = v && atoi(v) != 0; }
+    if (slow) return 0;
 #if defined(__SSE2__)
-    const __m128i a = _mm_set1_epi8('A'), c = _mm_set1_epi8('C'), g = _mm_set1_epi8('G'), t = _mm_set1_epi8('T');
+    const __m128i fold = _mm_set1_epi8((char)0xDF), a = _mm_set1_epi8('A'), c = _mm_set1_epi8('C'), g = _mm_set1_epi8('G'),
+                  t = _mm_set1_epi8('T'), n = _mm_set1_epi8('N'), z = _mm_set1_epi8(25);
     for (; i + 16 <= len; i += 16) {
         const __m128i x = _mm_loadu_si128((const __m128i *)(p + i));
-        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(x, a), _mm_cmpeq_epi8(x, c)),
-                                        _mm_or_si128(_mm_cmpeq_epi8(x, g), _mm_cmpeq_epi8(x, t)));
-        if (_mm_movemask_epi8(ok) != 0xFFFF) return 0;
+        const __m128i u = _mm_and_si128(x, fold);
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, a), _mm_cmpeq_epi8(u, c)),
+                                        _mm_or_si128(_mm_cmpeq_epi8(u, g), _mm_cmpeq_epi8(u, t)));
+        if (allow_ns) {
+            const __m128i v = _mm_sub_epi8(u, a);                              /* 0..25 for a letter (as unsigned bytes) */
+            if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, z), v)) != 0xFFFF) return 0;
+            _mm_storeu_si128((__m128i *)(dst + i), _mm_or_si128(_mm_and_si128(ok, u), _mm_andnot_si128(ok, n)));
+        } else {
+            if (_mm_movemask_epi8(ok) != 0xFFFF) return 0;
+            _mm_storeu_si128((__m128i *)(dst + i), u);
+        }
     }
 #endif
-    for (; i < len; i++)
-        if (p[i] != 'A' && p[i] != 'C' && p[i] != 'G' && p[i] != 'T') return 0;
+    for (; i < len; i++) {
+        const unsigned char u = (unsigned char)(p[i] & 0xDF);
+        const int ok = u == 'A' || u == 'C' || u == 'G' || u == 'T';
+        if (!ok && !(allow_ns && u >= 'A' && u <= 'Z')) return 0;
+        dst[i] = ok ? u : (unsigned char)'N';
+    }
     return 1;
 }
 
@@ -194,9 +213,9 @@ static int load_mem(const unsigned char *data, long fsize, int merge, int acgt_o
                 while (p < pe && *p != '>') { /* line by line; a '>' anywhere ends the record (sequence.c:157) */
                     const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(pe - p));
                     const unsigned char *end = nl ? nl : pe;
-                    if (line_is_acgt(p, (size_t)(end - p))) {
-                        memcpy(dst, p, (size_t)(end - p));
-                        dst += end - p;
+                    const unsigned char *le = (end > p && end[-1] == '\r') ? end - 1 : end; /* (a CR is skipped like the LF) */
+                    if (line_of_letters(dst, p, (size_t)(le - p), !acgt_only)) {
+                        dst += le - p;
                         p = end;
                     } else {
                         while (p < end) {
@@ -218,6 +237,28 @@ static int load_mem(const unsigned char *data, long fsize, int merge, int acgt_o
             } else
             while ((c = rd(&r)) != '>' && c != EOF) {
                 char t = table[c];
+                if (t && seqsize != 0 && seqlen + 1 < maxseqlen) {
+                    /* inside a record (its first letter, with the separator 'N' of sequence.c:163-165, is behind us) and not at
+                       one of the steps of maxseqlen: this letter, then whole lines while they hold nothing but letters */
+                    const unsigned char *p = r.p, *pe = r.end;
+                    chars[seqlen++] = t;
+                    seqsize++;
+                    for (;;) {
+                        const unsigned char *nl, *end, *le;
+                        if (p < pe && (*p == '\n' || *p == '\r')) { p++; continue; }
+                        if (p >= pe || *p == '>') break;
+                        nl = (const unsigned char *)memchr(p, '\n', (size_t)(pe - p));
+                        end = nl ? nl : pe;
+                        le = (end > p && end[-1] == '\r') ? end - 1 : end;
+                        if ((uint64_t)(le - p) + seqlen + 1 >= maxseqlen || (uint64_t)(le - p) + seqlen >= 0xFFFFFFF0ull) break;
+                        if (!line_of_letters((unsigned char *)chars + seqlen, p, (size_t)(le - p), !acgt_only)) break;
+                        seqlen += (uint64_t)(le - p);
+                        seqsize += (uint32_t)(le - p);
+                        p = end;
+                    }
+                    r.p = p;
+                    continue;
+                }
                 if (t) {
                     if (seqlen == maxseqlen) { /* sequence.c:160-166 */
                         maxseqlen += (1u << 20);

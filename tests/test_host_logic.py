@@ -315,3 +315,62 @@ def test_loader_fast_paths_follow_the_byte_by_byte_rules(seed, tmp_path):
         a = hostlib.Loaded(str(p), 0, acgt_only)
         assert a.names == names
         assert a.chars == b"".join(seqs) and a.sizes == [len(x) for x in seqs]
+
+
+def _messy_fasta(rng, big=False):
+    """Records of soft-masked / IUPAC / clean lines, CR LF, digits and blanks, '>' inside a line, empty records; `big`: one
+    record long enough to cross the loader's 1 M-letter steps several times."""
+    alph = [b"ACGT", b"acgt", b"ACGTacgt", b"ACGTNRYKMSWacgtnryk", b"ACGT*-1 \t", b"N", b"n"]
+    parts = []
+    for r in range(int(rng.integers(3, 25))):
+        parts.append(b">chr%d some text %d" % (r, r))
+        parts.append([b"\n", b"\r\n"][int(rng.integers(0, 2))])
+        nlines = int(rng.integers(0, 12)) if not (big and r == 1) else 40_000
+        for _ in range(nlines):
+            L = int(rng.integers(0, 120)) if not (big and r == 1) else 70
+            a = alph[int(rng.integers(0, len(alph)))] if not (big and r == 1) else alph[2 + int(rng.integers(0, 2))]
+            parts.append(bytes(rng.choice(np.frombuffer(a, dtype=np.uint8), size=L)))
+            if rng.random() < 0.02:
+                parts.append(b">inner%d\nACGTTGCA" % r)
+            parts.append([b"\n", b"\n", b"\r\n"][int(rng.integers(0, 3))])
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_loader_whole_line_path_equals_the_byte_loop(seed, tmp_path):
+    """Round 4: lines that hold nothing but letters -- soft-masked (lower-case) stretches, IUPAC letters -- are translated 16
+    bytes at a time (`line_of_letters`: case folded, every letter that is not A,C,G,T an N, sequence.c:61-81), for reads AND for
+    the reference's records (behind a record's first letter and its separator N, between the loader's 1 M-letter steps).
+    Against the same library with SLAMEM_LOADER_BYTEWISE=1 (a child process: the switch is read once): names, sizes, letters
+    and merged starts equal, with and without -n, with a minimum record length."""
+    import json
+    import subprocess
+    import sys
+    rng = np.random.default_rng(4000 + seed)
+    data = _messy_fasta(rng, big=(seed == 0))
+    if seed % 2:
+        data = data.rstrip(b"\r\n")
+    p = tmp_path / "m.fa"
+    p.write_bytes(data)
+    child = r"""
+import hashlib, json, sys
+sys.path.insert(0, sys.argv[1])
+import hostlib
+out = {}
+for merge in (0, 1):
+    for acgt_only in (0, 1):
+        for min_len in (0, 50):
+            a = hostlib.Loaded(sys.argv[2], merge, acgt_only, min_len)
+            out["%d%d%d" % (merge, acgt_only, min_len)] = [a.n, [x.decode("latin1") for x in a.names], a.sizes, hashlib.sha256(a.chars).hexdigest(), len(a.chars),
+                                                             a.merged_start, a.offsets]
+print(json.dumps(out))
+"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", child, here, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, SLAMEM_LOADER_BYTEWISE=mode), timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        res[mode] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert res["0"] == res["1"]
+    assert any(v[4] > 0 for v in res["0"].values())
