@@ -7,7 +7,7 @@ import os
 import sys
 
 root = sys.argv[1]
-kernels = ("k_find_mems", "k_prefilter", "k_pack_queries", "k_place_inline", "k_lcp_kasai", "k_links")
+kernels = ("k_seed_mems", "k_find_mems", "k_enum_jobs", "k_prefilter", "k_pack_queries", "k_place_inline", "k_lcp_kasai", "k_links")
 out = {}
 for d in sorted(glob.glob(os.path.join(root, "*"))):
     if not os.path.isdir(d):
