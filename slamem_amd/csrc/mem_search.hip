@@ -2467,21 +2467,24 @@ __global__ void __launch_bounds__(256) k_prefilter_list(SearchArgs A, const uint
 #define SLAMEM_SEED_READS 16
 #endif
 constexpr uint32_t kSeedReads = SLAMEM_SEED_READS;     // reads of a wave (at most 16: a flag word holds two bits per read)
-constexpr uint32_t kSeedMaxLen = 192;   // letters of a strand the planes hold (three words)
+constexpr uint32_t kSeedMaxLen = 192;   // letters of a strand the planes hold in the instantiation for reads of up to 192 letters (three words)
+constexpr uint32_t kSeedMaxLenLong = 384;  // ... and in the one for longer reads (six words: 2 x 250 bp runs; a batch takes it when its reads average more than 192)
 constexpr uint32_t kSeedJobs = 256;     // compares of one wave
 constexpr uint32_t kSeedMems = 192;     // MEMs of one wave
 
+template <uint32_t NW>  // plane words of a strand (64 letters each)
 struct SeedWave {
-    uint64_t pl[kSeedReads][2][2][4];   // [read][strand][plane][word]; word 3 stays 0 (a window's second word)
+    static constexpr uint32_t kJobs = kSeedJobs * (NW / 3u), kMems = kSeedMems * (NW / 3u);  // (longer strands: more windows, more MEMs)
+    uint64_t pl[kSeedReads][2][2][NW + 1];   // [read][strand][plane][word]; the last word stays 0 (a window's second word)
     uint32_t len[kSeedReads];           // letters (0: the read takes no part)
     uint32_t nwin[kSeedReads];          // windows
     union {
         // first the wave's reads as they are (their bytes, 16-byte chunks of the query buffer), while the planes are made ...
-        uint4 raw[kSeedReads * kSeedMaxLen / 16 + 1];
+        uint4 raw[kSeedReads * NW * 4 + 1];
         // ... then the compares and the MEMs
         struct {
-            uint32_t job_p[kSeedJobs], job_x[kSeedJobs];
-            uint32_t mem_key[kSeedMems], mem_ref[kSeedMems], mem_g[kSeedMems];
+            uint32_t job_p[kJobs], job_x[kJobs];
+            uint32_t mem_key[kMems], mem_ref[kMems], mem_g[kMems];
         };
     };
     uint32_t flags;                     // bit 2 * read + strand: the strand is left to K8
@@ -2519,9 +2522,10 @@ __device__ __forceinline__ uint32_t byte_tops(uint32_t m) {
 #ifndef SLAMEM_SEED_WAVES
 #define SLAMEM_SEED_WAVES 1
 #endif
-template <bool kStats>
+template <bool kStats, uint32_t NW>
 __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs A, uint8_t* __restrict__ alive) {
-    __shared__ SeedWave lds[4];
+    constexpr uint32_t kMaxLen = 64u * NW;
+    __shared__ SeedWave<NW> lds[4];
     __shared__ uint8_t lut[256];  // ASCII -> 2-bit code | 4 (one of A,C,G,T), or 8
     {
         const uint32_t u = threadIdx.x & 0xDFu, x = (u >> 1) & 3u;
@@ -2530,7 +2534,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     __syncthreads();
     const IndexView& ix = A.ix;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    SeedWave& S = lds[wv];
+    SeedWave<NW>& S = lds[wv];
     const uint32_t strands = A.strands, k = ix.seed_k, L = A.min_len, s = L - k + 1u;
     const uint32_t kmask = (1u << k) - 1u, tb = 2u * k - ix.seed_log2, tagmask = (1u << tb) - 1u;
     const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wv) * kSeedReads;
@@ -2547,7 +2551,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     bool left = false;  // both strands of the read are left to K8
     if (lane < nr) {
         const uint64_t l64 = offn - off;
-        if (l64 > kSeedMaxLen) left = l64 >= L; else len = (uint32_t)l64;
+        if (l64 > kMaxLen) left = l64 >= L; else len = (uint32_t)l64;
         if (len >= L) nwin = (len - k) / s + 1u;
         if (nwin > 64u) { left = true; nwin = 0; }
     }
@@ -2568,7 +2572,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     const uint64_t span1 = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)nr), (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)nr));
     const uint64_t chunk0 = span0 >> 4;
     const uint32_t nchunks = span1 > span0 ? (uint32_t)(((span1 - 1u) >> 4) - chunk0 + 1u) : 0u;
-    const bool staged = nchunks <= kSeedReads * kSeedMaxLen / 16u + 1u;
+    const bool staged = nchunks <= kSeedReads * NW * 4u + 1u;
     if (staged) {
         const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + chunk0;
         for (uint32_t c = lane; c < nchunks; c += 64u) S.raw[c] = src[c];
@@ -2581,10 +2585,10 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         if (Li) {
             const uint64_t base = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)i),
                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)i));
-            uint64_t f0[3], f1[3];
+            uint64_t f0[NW], f1[NW];
             unsigned long long other = 0ull;
 #pragma unroll
-            for (uint32_t j = 0; j < 3u; j++) {
+            for (uint32_t j = 0; j < NW; j++) {
                 const uint32_t x = 64u * j + lane;
                 uint32_t v = 0;
                 if (x < Li) v = lut[staged ? rawbytes[(uint32_t)(base - (chunk0 << 4)) + x] : qbytes[base + x]];
@@ -2597,25 +2601,30 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 keep_len = 0; keep_win = 0;
             } else {
                 // reverse strand: letter x of it is the complement (both plane bits flipped) of letter Li-1-x
-                const uint32_t sh = 192u - Li, q = sh >> 6, r = sh & 63u;
-                uint64_t g0[3], g1[3];
+                const uint32_t sh = kMaxLen - Li, q = sh >> 6, r = sh & 63u;  // the reversed planes come down by this many letters
+                uint64_t g0[NW], g1[NW];
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++) {
                     const uint64_t* f = pl ? f1 : f0;
-                    const uint64_t t0 = __brevll(f[2]), t1 = __brevll(f[1]), t2 = __brevll(f[0]);
-                    const uint64_t a0 = q == 0u ? t0 : q == 1u ? t1 : t2, a1 = q == 0u ? t1 : q == 1u ? t2 : 0ull, a2 = q == 0u ? t2 : 0ull;
                     uint64_t* g = pl ? g1 : g0;
-                    g[0] = ~funnel64(a0, a1, r) & bits_range(0, (int)Li);
-                    g[1] = ~funnel64(a1, a2, r) & bits_range(0, (int)Li - 64);
-                    g[2] = ~funnel64(a2, 0ull, r) & bits_range(0, (int)Li - 128);
+                    // t[w] = word w of the bit-reversed planes (word 0 lowest), words behind the last are 0
+                    auto rv = [&](uint32_t w) -> uint64_t {
+                        uint64_t v = 0ull;
+#pragma unroll
+                        for (uint32_t u = 0; u < NW; u++) v = (w == u) ? __brevll(f[NW - 1u - u]) : v;
+                        return v;
+                    };
+#pragma unroll
+                    for (uint32_t w = 0; w < NW; w++)
+                        g[w] = ~funnel64(rv(w + q), rv(w + q + 1u), r) & bits_range(0, (int)Li - 64 * (int)w);
                 }
                 if (lane == 0u) {
 #pragma unroll
-                    for (uint32_t j = 0; j < 3u; j++) {
+                    for (uint32_t j = 0; j < NW; j++) {
                         S.pl[i][0][0][j] = f0[j]; S.pl[i][0][1][j] = f1[j];
                         S.pl[i][1][0][j] = g0[j]; S.pl[i][1][1][j] = g1[j];
                     }
-                    S.pl[i][0][0][3] = 0ull; S.pl[i][0][1][3] = 0ull; S.pl[i][1][0][3] = 0ull; S.pl[i][1][1][3] = 0ull;
+                    S.pl[i][0][0][NW] = 0ull; S.pl[i][0][1][NW] = 0ull; S.pl[i][1][0][NW] = 0ull; S.pl[i][1][1][NW] = 0ull;
                 }
             }
         }
@@ -2702,13 +2711,13 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             const bool job = hv && !((pn >= 1u && ps1 == st && pp1 == w) || (pn >= 2u && ps2 == st && pp2 == w));
             const unsigned long long qb = __ballot(job);
             const uint32_t at = njobs + (uint32_t)__popcll(qb & below);
-            if (job && at < kSeedJobs) {
+            if (job && at < SeedWave<NW>::kJobs) {
                 S.job_p[at] = p;
                 S.job_x[at] = (st ? Lr - k - o : o) | (st << 15) | (rs << 16);
             }
             njobs += (uint32_t)__popcll(qb);
         }
-        if (njobs > kSeedJobs) {  // (many repeated windows) every read of this trip is left to K8
+        if (njobs > SeedWave<NW>::kJobs) {  // (many repeated windows) every read of this trip is left to K8
             for (uint32_t i = t0; i < t0 + rpt && i < kSeedReads; i++) wflags |= 3u << (2u * i);
             if (kStats && lane == 0u) atomicAdd(A.stats + SC_SEED_WHY + 3u, 1ull);
             njobs = njobs0;
@@ -2732,43 +2741,50 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             bool is_mem = false;
             uint32_t key = 0, ref = 0, g = 0;
             if (has) {
-                int64_t ui[4];
+                constexpr int NU = (int)NW + 1;  // units of the text the strand faces: NW words from any start inside a unit
+                int64_t ui[NU];
 #pragma unroll
-                for (int i = 0; i < 4; i++) { const int64_t u = u0 + i; ui[i] = u < 0 ? 0 : u > ulast ? ulast : u; }
+                for (int i = 0; i < NU; i++) { const int64_t u = u0 + i; ui[i] = u < 0 ? 0 : u > ulast ? ulast : u; }
                 const uint4* T = reinterpret_cast<const uint4*>(ix.tpl);
-                const uint4 t0 = T[ui[0]], t1 = T[ui[1]], t2 = T[ui[2]], t3 = T[ui[3]];
-                const uint64_t c0 = ix.tnb[ui[0] >> 6], c3 = ix.tnb[ui[3] >> 6];
+                uint4 tu[NU];
+#pragma unroll
+                for (int i = 0; i < NU; i++) tu[i] = T[ui[i]];
+                const uint64_t c0 = ix.tnb[ui[0] >> 6], c3 = ix.tnb[ui[NU - 1] >> 6];
                 uint32_t anyn = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) anyn |= (uint32_t)((((ui[i] >> 6) == (ui[0] >> 6) ? c0 : c3) >> (ui[i] & 63)) & 1ull);
-                uint64_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+                for (int i = 0; i < NU; i++) anyn |= (uint32_t)((((ui[i] >> 6) == (ui[0] >> 6) ? c0 : c3) >> (ui[i] & 63)) & 1ull);
+                uint64_t nu[NU];
+#pragma unroll
+                for (int i = 0; i < NU; i++) nu[i] = 0ull;
                 if (anyn) {  // (rare) some unit holds a letter that is not A,C,G,T: it disagrees with every letter of a strand that has none
-                    n0 = ix.tnm[ui[0]]; n1 = ix.tnm[ui[1]]; n2 = ix.tnm[ui[2]]; n3 = ix.tnm[ui[3]];
+#pragma unroll
+                    for (int i = 0; i < NU; i++) nu[i] = ix.tnm[ui[i]];
                     if (kStats) n_nm++;
                 }
                 const uint64_t* R0 = S.pl[jr][st][0];
                 const uint64_t* R1 = S.pl[jr][st][1];
-                uint64_t mm[3];
-                mm[0] = (funnel64(u64_of(t0.x, t0.y), u64_of(t1.x, t1.y), sh) ^ R0[0]) | (funnel64(u64_of(t0.z, t0.w), u64_of(t1.z, t1.w), sh) ^ R1[0]) | funnel64(n0, n1, sh);
-                mm[1] = (funnel64(u64_of(t1.x, t1.y), u64_of(t2.x, t2.y), sh) ^ R0[1]) | (funnel64(u64_of(t1.z, t1.w), u64_of(t2.z, t2.w), sh) ^ R1[1]) | funnel64(n1, n2, sh);
-                mm[2] = (funnel64(u64_of(t2.x, t2.y), u64_of(t3.x, t3.y), sh) ^ R0[2]) | (funnel64(u64_of(t2.z, t2.w), u64_of(t3.z, t3.w), sh) ^ R1[2]) | funnel64(n2, n3, sh);
+                uint64_t mm[NW];
+#pragma unroll
+                for (int w = 0; w < (int)NW; w++)
+                    mm[w] = (funnel64(u64_of(tu[w].x, tu[w].y), u64_of(tu[w + 1].x, tu[w + 1].y), sh) ^ R0[w]) |
+                            (funnel64(u64_of(tu[w].z, tu[w].w), u64_of(tu[w + 1].z, tu[w + 1].w), sh) ^ R1[w]) | funnel64(nu[w], nu[w + 1], sh);
                 // letters that face no text letter, or lie behind the strand, disagree
                 const int lo = d < 0 ? (int)(-d) : 0;
                 const int64_t room = (int64_t)ix.n - d;
                 const int hi = room < (int64_t)Lj ? (int)room : (int)Lj;
 #pragma unroll
-                for (int w = 0; w < 3; w++) mm[w] |= ~bits_range(lo - 64 * w, hi - 64 * w);
+                for (int w = 0; w < (int)NW; w++) mm[w] |= ~bits_range(lo - 64 * w, hi - 64 * w);
                 // the run of agreeing letters around the window [os, os + k): [a, b)
-                uint32_t a = 0, b = 192u;
+                uint32_t a = 0, b = kMaxLen;
                 bool broken = false;
 #pragma unroll
-                for (int w = 0; w < 3; w++) {
+                for (int w = 0; w < (int)NW; w++) {
                     const uint64_t lw = mm[w] & bits_range(0, (int)os - 64 * w);
                     if (lw) a = 64u * w + 64u - (uint32_t)__clzll((long long)lw);
                     if (mm[w] & bits_range((int)os - 64 * w, (int)(os + k) - 64 * w)) broken = true;
                 }
 #pragma unroll
-                for (int w = 2; w >= 0; w--) {
+                for (int w = (int)NW - 1; w >= 0; w--) {
                     const uint64_t hw = mm[w] & ~bits_range(0, (int)(os + k) - 64 * w);
                     if (hw) b = 64u * w + (uint32_t)__ffsll((unsigned long long)hw) - 1u;
                 }
@@ -2785,12 +2801,12 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             const unsigned long long mb = __ballot(is_mem);
             if (is_mem) {
                 const uint32_t at = nmems + (uint32_t)__popcll(mb & below);
-                if (at < kSeedMems) { S.mem_key[at] = key; S.mem_ref[at] = ref; S.mem_g[at] = g; }
+                if (at < SeedWave<NW>::kMems) { S.mem_key[at] = key; S.mem_ref[at] = ref; S.mem_g[at] = g; }
                 else { atomicOr(&S.flags, 1u << (2u * jr + st)); if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 5u, 1ull); }
             }
             nmems += (uint32_t)__popcll(mb);
         }
-        if (nmems > kSeedMems) nmems = kSeedMems;
+        if (nmems > SeedWave<NW>::kMems) nmems = SeedWave<NW>::kMems;
         wave_sync();
 
         // ---- phase 3: the strands' MEMs in the reference's emission order ------------------------------------------------
@@ -3305,7 +3321,7 @@ int SearchJob::prep(hipStream_t stream) {
         // (read per call, not once per process: the tests run both paths in one process)
         const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
         seeded = use_seed && match_type == 0 && nitems == num_blocks && idx->view.seed && min_len >= idx->view.seed_k + 3u &&
-                 min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLen;
+                 min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLenLong;
         if (seeded) {
             uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
             // (K8's kChunk instantiation wants every place of the overflow list marked "unused" before the launch: K8s puts
@@ -3317,8 +3333,15 @@ int SearchJob::prep(hipStream_t stream) {
             STEP(hipMemsetAsync(d_counts, 0, nitems * 4, stream), "memset");
             STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
             const dim3 gs(grid_for((uint64_t)num_queries, 4 * kSeedReads));
-            if (want_stats) hipLaunchKernelGGL(k_seed_mems<true>, gs, dim3(256), 0, stream, A, d_alive);
-            else hipLaunchKernelGGL(k_seed_mems<false>, gs, dim3(256), 0, stream, A, d_alive);
+            // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: six)
+            const bool long_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLen;
+            if (long_reads) {
+                if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 6>), gs, dim3(256), 0, stream, A, d_alive);
+                else hipLaunchKernelGGL((k_seed_mems<false, 6>), gs, dim3(256), 0, stream, A, d_alive);
+            } else {
+                if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 3>), gs, dim3(256), 0, stream, A, d_alive);
+                else hipLaunchKernelGGL((k_seed_mems<false, 3>), gs, dim3(256), 0, stream, A, d_alive);
+            }
             STEP(hipGetLastError(), "k_seed_mems");
             (void)hipEventRecord(ev[3], stream);
             prefiltered = true;

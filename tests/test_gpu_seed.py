@@ -114,15 +114,23 @@ def test_reads_on_random_text(eng, n, count, length, l, both, sub):
 
 
 def test_reads_longer_than_the_planes_go_to_the_index_walk(eng):
-    """193 letters: one more than the three plane words hold.  A batch of them does not qualify at all (the prefilter and the
-    index walk take it); mixed with shorter reads the seed kernel leaves them, strand by strand."""
+    """Two instantiations: three plane words a strand (reads of up to 192 letters) and six (up to 384: a batch whose reads average
+    more than 192 takes it).  In either, a longer read is left to the index walk strand by strand; a batch that averages more
+    than 384 letters does not take the seed path at all."""
     rng = np.random.default_rng(193)
     t = rng.choice(ACGT, size=100_000)
-    st, _ = check(eng, t, reads_from(rng, t, 300, 193, 0.02), 25, True, expect_seed=False)
+    st, _ = check(eng, t, reads_from(rng, t, 300, 193, 0.02), 25, True, max_left_frac=0.05)   # six words: nothing is left for its length
+    st, _ = check(eng, t, reads_from(rng, t, 300, 250, 0.02), 20, True, max_left_frac=0.05)
+    st, _ = check(eng, t, reads_from(rng, t, 200, 384, 0.02), 30, True, max_left_frac=0.05)
+    st, _ = check(eng, t, reads_from(rng, t, 100, 500, 0.02), 25, True, expect_seed=False)    # beyond both
     qs = reads_from(rng, t, 300, 193, 0.02) + reads_from(rng, t, 900, 100, 0.02) + reads_from(rng, t, 20, 400, 0.02)
     order = rng.permutation(len(qs))
-    st, _ = check(eng, t, [qs[i] for i in order], 25, True, min_left=2 * 320)
+    st, _ = check(eng, t, [qs[i] for i in order], 25, True, min_left=2 * 320)                 # three words (average 128): 193 and 400 are left
     assert st["seed_strands_left"] <= 2 * 320 + 40
+    qs = reads_from(rng, t, 600, 250, 0.02) + reads_from(rng, t, 300, 150, 0.02) + reads_from(rng, t, 40, 385, 0.02) + reads_from(rng, t, 30, 340, 0.02)
+    order = rng.permutation(len(qs))
+    st, _ = check(eng, t, [qs[i] for i in order], 20, True, min_left=2 * 40)                  # six words: the reads of 385 letters are left (340: 33 windows at s = 10, stay)
+    assert st["seed_strands_left"] <= 2 * 40 + 60
 
 
 def test_every_read_length_in_one_batch(eng):
@@ -136,6 +144,13 @@ def test_every_read_length_in_one_batch(eng):
             qs += reads_from(rng, t, 1, length, 0.02) if length else [np.zeros(0, dtype=np.uint8)]
     order = rng.permutation(len(qs))
     for l in (14, 20, 31):
+        st, _ = check(eng, t, [qs[i] for i in order], l, True)
+    # the same for the six-word instantiation: every length from 150 to 400, twice
+    qs = []
+    for length in range(150, 401):
+        qs += reads_from(rng, t, 2, length, 0.02)
+    order = rng.permutation(len(qs))
+    for l in (20, 27, 45):
         st, _ = check(eng, t, [qs[i] for i in order], l, True)
 
 
