@@ -2471,6 +2471,7 @@ constexpr uint32_t kSeedMaxLen = 192;   // letters of a strand the planes hold i
 constexpr uint32_t kSeedMaxLenLong = 384;  // ... and in the one for longer reads (six words: 2 x 250 bp runs; a batch takes it when its reads average more than 192)
 constexpr uint32_t kSeedJobs = 256;     // compares of one wave
 constexpr uint32_t kSeedMems = 192;     // MEMs of one wave
+constexpr uint32_t kSigLetters = 12, kSigMask = (1u << kSigLetters) - 1u, kSigKnown = 1u << 24;  // text letters kept behind a MEM (ties, phase 3)
 
 template <uint32_t NW>  // plane words of a strand (64 letters each)
 struct SeedWave {
@@ -2484,7 +2485,10 @@ struct SeedWave {
         // ... then the compares and the MEMs
         struct {
             uint32_t job_p[kJobs], job_x[kJobs];
-            uint32_t mem_key[kMems], mem_ref[kMems], mem_g[kMems];
+            uint32_t mem_key[kMems], mem_ref[kMems];
+            // bits 25-29: the strand (of the wave's 32); the kSigLetters text letters behind the match (plane 0: bits 0-11, plane 1:
+            // bits 12-23), bit 24: they are known
+            uint32_t mem_sig[kMems];
         };
     };
     uint32_t flags;                     // bit 2 * read + strand: the strand is left to K8
@@ -2682,11 +2686,14 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         hits &= count >= kSeedSlots ? 0xFFFu : (1u << count) - 1u;
         if (strands == 1u) hits &= ~rev;
         if (!act) hits = 0;
-        if (act && (count > kSeedSlots || (pal && hits && strands == 2u))) {
+        if (act && count > kSeedSlots) {
             atomicOr(&S.flags, 3u << (2u * rs));
-            if (kStats) atomicAdd(A.stats + SC_SEED_WHY + (count > kSeedSlots ? 1u : 2u), 1ull);
+            if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 1u, 1ull);
             hits = 0;
         }
+        // a window that is its own reverse complement lies in both strands: every hit is a compare for each
+        const bool both = pal != 0u && strands == 2u;
+        if (kStats && both && hits) atomicAdd(A.stats + SC_SEED_WHY + 2u, 1ull);  // (counted, no longer a reason to leave the read)
         // Every hit is a compare -- except one whose neighbour window (the one s letters earlier in the forward strand) hit the
         // same diagonal: the two windows overlap or touch, so they lie in the same match and that window, or one before it,
         // reports the MEM.  (The neighbour's first two hits are looked at; a hit this misses is sorted out by its compare.)
@@ -2700,13 +2707,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             if (wi == 0u) pn = 0;
         }
         const uint32_t njobs0 = njobs;
-        uint32_t rem = hits;
-        for (uint32_t it = 0; __ballot(rem != 0u) != 0ull; it++) {
-            const bool hv = rem != 0u;
-            const uint32_t e = it == 0u ? e1 : it == 1u ? e2 : hv ? (uint32_t)__ffs((int)rem) - 1u : 0u;
-            rem &= rem - 1u;
-            const uint32_t p = it == 0u ? p1 : it == 1u ? p2 : sel12(b0, b1, b2, e);
-            const uint32_t st = (rev >> e) & 1u;
+        auto push = [&](bool hv, uint32_t p, uint32_t st) {
             const uint32_t w = st ? p + s : p - s;
             const bool job = hv && !((pn >= 1u && ps1 == st && pp1 == w) || (pn >= 2u && ps2 == st && pp2 == w));
             const unsigned long long qb = __ballot(job);
@@ -2716,6 +2717,15 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 S.job_x[at] = (st ? Lr - k - o : o) | (st << 15) | (rs << 16);
             }
             njobs += (uint32_t)__popcll(qb);
+        };
+        uint32_t rem = hits;
+        for (uint32_t it = 0; __ballot(rem != 0u) != 0ull; it++) {
+            const bool hv = rem != 0u;
+            const uint32_t e = it == 0u ? e1 : it == 1u ? e2 : hv ? (uint32_t)__ffs((int)rem) - 1u : 0u;
+            rem &= rem - 1u;
+            const uint32_t p = it == 0u ? p1 : it == 1u ? p2 : sel12(b0, b1, b2, e);
+            push(hv, p, (rev >> e) & 1u);
+            if (__ballot(hv && both) != 0ull) push(hv && both, p, 1u);
         }
         if (njobs > SeedWave<NW>::kJobs) {  // (many repeated windows) every read of this trip is left to K8
             for (uint32_t i = t0; i < t0 + rpt && i < kSeedReads; i++) wflags |= 3u << (2u * i);
@@ -2739,7 +2749,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             const int64_t u0 = d >> 6;
             const uint32_t sh = (uint32_t)(d & 63);
             bool is_mem = false;
-            uint32_t key = 0, ref = 0, g = 0;
+            uint32_t key = 0, ref = 0, sig = 0;
             if (has) {
                 constexpr int NU = (int)NW + 1;  // units of the text the strand faces: NW words from any start inside a unit
                 int64_t ui[NU];
@@ -2790,18 +2800,33 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 }
                 // reported by the window with the smallest forward offset inside the match
                 const bool owner = st ? !(os + s + k <= b) : !(os >= s && os - s >= a);
-                g = (uint32_t)((r0 + jr) * strands + st);
                 if (broken) {  // (cannot happen: the table is exact) -- leave the strand to K8
                     atomicOr(&S.flags, 1u << (2u * jr + st));
                     if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 4u, 1ull);
                 }
-                else if (owner && b - a >= L) { is_mem = true; key = (a << 16) | (b - a); ref = (uint32_t)(d + (int64_t)a); }
+                else if (owner && b - a >= L) {
+                    is_mem = true; key = (a << 16) | (b - a); ref = (uint32_t)(d + (int64_t)a);
+                    // what the text goes on with behind the match: orders MEMs of one strand with the same start and length
+                    // (phase 3) as the rows of the suffix array would
+                    if (!anyn && b + kSigLetters <= kMaxLen && d + (int64_t)b + (int64_t)kSigLetters <= (int64_t)ix.n) {
+                        const uint32_t wb = b >> 6, sb = b & 63u;
+                        uint64_t l0 = 0, h0 = 0, l1 = 0, h1 = 0;
+#pragma unroll
+                        for (int w = 0; w < (int)NW; w++) {
+                            const uint64_t t0 = funnel64(u64_of(tu[w].x, tu[w].y), u64_of(tu[w + 1].x, tu[w + 1].y), sh);
+                            const uint64_t t1 = funnel64(u64_of(tu[w].z, tu[w].w), u64_of(tu[w + 1].z, tu[w + 1].w), sh);
+                            if ((uint32_t)w == wb) { l0 = t0; l1 = t1; }
+                            if ((uint32_t)w == wb + 1u) { h0 = t0; h1 = t1; }
+                        }
+                        sig = kSigKnown | ((uint32_t)funnel64(l0, h0, sb) & kSigMask) | (((uint32_t)funnel64(l1, h1, sb) & kSigMask) << kSigLetters);
+                    }
+                }
             }
             if (kStats) n_cmp += (uint32_t)__popcll(__ballot(has));
             const unsigned long long mb = __ballot(is_mem);
             if (is_mem) {
                 const uint32_t at = nmems + (uint32_t)__popcll(mb & below);
-                if (at < SeedWave<NW>::kMems) { S.mem_key[at] = key; S.mem_ref[at] = ref; S.mem_g[at] = g; }
+                if (at < SeedWave<NW>::kMems) { S.mem_key[at] = key; S.mem_ref[at] = ref; S.mem_sig[at] = sig | ((2u * jr + st) << 25); }
                 else { atomicOr(&S.flags, 1u << (2u * jr + st)); if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 5u, 1ull); }
             }
             nmems += (uint32_t)__popcll(mb);
@@ -2810,33 +2835,73 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         wave_sync();
 
         // ---- phase 3: the strands' MEMs in the reference's emission order ------------------------------------------------
-        // rank of a MEM = MEMs of its strand that come before it (greater start, or equal start and greater length); MEMs of a
-        // strand that tie (same start, same length) leave the strand to K8
+        // rank of a MEM = MEMs of its strand that come before it (greater start, or equal start and greater length; same start
+        // and length: tie_rank).  A strand is named by its bit of the flag word here (2 * read + strand)
         const uint32_t g0 = (uint32_t)(r0 * strands);
         auto rank_of = [&](uint32_t mi, uint32_t key, uint32_t g, uint32_t& rank, uint32_t& cnt, bool& tie) {
             rank = 0; cnt = 0; tie = false;
             for (uint32_t t2 = 0; t2 < nmems; t2++) {
-                const uint32_t kk = S.mem_key[t2], gg = S.mem_g[t2];
+                const uint32_t kk = S.mem_key[t2], gg = S.mem_sig[t2] >> 25;
                 const bool same = gg == g;
                 cnt += same ? 1u : 0u;
                 rank += (same && kk > key) ? 1u : 0u;
                 tie = tie || (same && kk == key && t2 != mi);
             }
         };
-        auto emit_mem = [&](uint32_t fl, uint32_t key, uint32_t ref, uint32_t g, uint32_t rank, uint32_t cnt) {
-            const uint32_t bit = strands == 2u ? g - g0 : 2u * (g - g0);
-            if ((fl >> bit) & 1u) return;
+        // MEMs of a strand with the same start a and length: rows of one interval of the walk at position a, which the
+        // reference lists around the interval it came up from (slamem.c:140,165): the rows above that child interval by
+        // ascending row, then those below it by descending row; all of them ascending when the interval is the deepest one at a.
+        // A deeper interval exists iff another match of the strand covers [a, b] and more to the right; a row lies above it iff
+        // its text letter behind the match is smaller than the strand's; rows compare as the text behind their matches does.
+        // Adds the tied MEMs that come before this one to rank; true: not decidable from kSigLetters letters (the strand is left to K8)
+        auto tie_rank = [&](uint32_t mi, uint32_t key, uint32_t g, uint32_t sig, uint32_t& rank) -> bool {
+            const uint32_t a = key >> 16, b = a + (key & 0xFFFFu);
+            bool child = false;
+            for (uint32_t t2 = 0; t2 < nmems; t2++) {
+                const uint32_t kk = S.mem_key[t2], a2 = kk >> 16, b2 = a2 + (kk & 0xFFFFu);
+                child = child || ((S.mem_sig[t2] >> 25) == g && kk != key && a2 <= a && b2 > b);
+            }
+            const uint32_t jr = g >> 1, st = g & 1u;
+            uint32_t qb = 0;
+            if (child) qb = (uint32_t)((S.pl[jr][st][0][b >> 6] >> (b & 63u)) & 1ull) | ((uint32_t)((S.pl[jr][st][1][b >> 6] >> (b & 63u)) & 1ull) << 1);
+            auto letter = [&](uint32_t sg, uint32_t t) { return ((sg >> t) & 1u) | (((sg >> (t + kSigLetters)) & 1u) << 1); };
+            const uint32_t my_side = child && letter(sig, 0u) > qb ? 1u : 0u;
+            bool bad = (sig & kSigKnown) == 0u;
+            for (uint32_t t2 = 0; t2 < nmems; t2++) {
+                const uint32_t so = S.mem_sig[t2];
+                if (t2 == mi || (so >> 25) != g || S.mem_key[t2] != key) continue;
+                if ((so & kSigKnown) == 0u) { bad = true; continue; }
+                const uint32_t o_side = child && letter(so, 0u) > qb ? 1u : 0u;
+                bool before;
+                if (o_side != my_side) before = o_side == 0u;
+                else {
+                    const uint32_t x = sig ^ so, diff = (x | (x >> kSigLetters)) & kSigMask;
+                    if (diff == 0u) { bad = true; continue; }
+                    const uint32_t t = (uint32_t)__ffs((int)diff) - 1u;
+                    const bool smaller = letter(so, t) < letter(sig, t);
+                    before = my_side == 0u ? smaller : !smaller;
+                }
+                rank += before ? 1u : 0u;
+            }
+            return bad;
+        };
+        auto emit_mem = [&](uint32_t fl, uint32_t key, uint32_t ref, uint32_t gb, uint32_t rank, uint32_t cnt) {
+            if ((fl >> gb) & 1u) return;
+            const uint32_t g = g0 + (strands == 2u ? gb : gb >> 1);
             emit3_at(A, g, rank, 0u, ref, key >> 16, (key & 0xFFFFu) | 0x80000000u);  // bit 31: ref_pos is the text position (K9)
             if (rank == 0u) A.block_counts[g] = cnt;
             if (kStats) n_mem++;
         };
         if (nmems <= 64u) {  // the usual case: one MEM per lane, one loop
             const bool has = lane < nmems;
-            const uint32_t key = has ? S.mem_key[lane] : 0u, ref = has ? S.mem_ref[lane] : 0u, g = has ? S.mem_g[lane] : 0xFFFFFFFFu;
+            const uint32_t key = has ? S.mem_key[lane] : 0u, ref = has ? S.mem_ref[lane] : 0u, g = has ? S.mem_sig[lane] >> 25 : 0xFFFFFFFFu;
             uint32_t rank, cnt;
             bool tie;
             rank_of(lane, key, g, rank, cnt, tie);
-            if (has && tie) { atomicOr(&S.flags, 1u << (strands == 2u ? g - g0 : 2u * (g - g0))); if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 6u, 1ull); }
+            if (has && tie && tie_rank(lane, key, g, S.mem_sig[lane], rank)) {
+                atomicOr(&S.flags, 1u << g);
+                if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 6u, 1ull);
+            }
             wave_sync();
             if (has) emit_mem(S.flags | wflags, key, ref, g, rank, cnt);
         } else {
@@ -2845,11 +2910,12 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 for (uint32_t m0i = 0; m0i < nmems; m0i += 64u) {
                     const uint32_t mi = m0i + lane;
                     const bool has = mi < nmems;
-                    const uint32_t key = has ? S.mem_key[mi] : 0u, ref = has ? S.mem_ref[mi] : 0u, g = has ? S.mem_g[mi] : 0xFFFFFFFFu;
+                    const uint32_t key = has ? S.mem_key[mi] : 0u, ref = has ? S.mem_ref[mi] : 0u, g = has ? S.mem_sig[mi] >> 25 : 0xFFFFFFFFu;
                     uint32_t rank, cnt;
                     bool tie;
                     rank_of(mi, key, g, rank, cnt, tie);
-                    if (!pass) { if (has && tie) atomicOr(&S.flags, 1u << (strands == 2u ? g - g0 : 2u * (g - g0))); }
+                    const bool bad = has && tie && tie_rank(mi, key, g, S.mem_sig[mi], rank);
+                    if (!pass) { if (bad) atomicOr(&S.flags, 1u << g); }
                     else if (has) emit_mem(fl, key, ref, g, rank, cnt);
                 }
                 wave_sync();

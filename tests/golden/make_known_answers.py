@@ -17,6 +17,7 @@ Cases (inputs: slamem_amd/synth.py generators, SURVEY.md Appendix C.2 + the repe
   config1_dups_pair / config1_dups_pair_mam   the pair with exact repeats in the genome (ecoli_like_pair(duplicates=True)):
                     -mem and -mam print different files there
   config5_first100k BASELINE.json configs[4]: 3.1 Gbp text (> 2^31 rows) with the repeat model, the first 100,000 reads, -b -l 20
+  config5_reads_7M  the same text, reads 7,000,000 .. 7,099,999 (a second, disjoint pin)
   config2_mam_first200k   the 100 Mbp reference of configs[1]/[2], its first 200,000 reads, -b -l 20 -mam
 
 Every MEM the reference prints is also checked here against the texts (real match, maximal on both sides) before the
@@ -168,20 +169,20 @@ def case_config1_pair_mam(tmp):
             "workload": f"ecoli_like_pair(): {ref.shape[0]} bp genome vs {qry.shape[0]} bp strain, -b -l 20 -mam"}
 
 
-def case_config5_first100k(tmp):
-    """BASELINE.json configs[4] stand-in: the 3.1 Gbp text (> 2^31 BWT rows) WITH the repeat model and the first 100,000 of
-    its reads, -b -l 20.  One core for hours and ~30 GB in the build container; a run that does not finish (time, memory,
-    a crash of the reference at this size) is recorded as such, with the tail of its stdout."""
+def case_config5_first100k(tmp, first=0):
+    """BASELINE.json configs[4] stand-in: the 3.1 Gbp text (> 2^31 BWT rows) WITH the repeat model and 100,000 of
+    its reads (first .. first+99,999), -b -l 20.  One core for hours and ~30 GB in the build container; a run that does not
+    finish (time, memory, a crash of the reference at this size) is recorded as such, with the tail of its stdout."""
     n, nreads, L, min_len = 3_100_000_000, 100_000, 150, 20
     assert (n + 1) % 64 != 0
     ref = synth.make_reference(n, 42)
     planted = synth.plant_repeats(ref, 42)
     if not os.path.exists(os.path.join(tmp, "ref.fa")):
         synth.write_fasta_reference(os.path.join(tmp, "ref.fa"), ref)
-    reads = synth.make_reads(ref, 0, nreads, L, 0.02, 42, 50)
+    reads = synth.make_reads(ref, first, nreads, L, 0.02, 42, 50)
     with open(os.path.join(tmp, "qry.fa"), "wb") as f:
-        f.write(b"".join(b">q%d\n" % i + reads[i].tobytes() + b"\n" for i in range(nreads)))
-    workload = (f"n={n} seed 42 + repeat model ({planted} planted letters), reads 0..{nreads - 1} of 150 bp, "
+        f.write(b"".join(b">q%d\n" % (first + i) + reads[i].tobytes() + b"\n" for i in range(nreads)))
+    workload = (f"n={n} seed 42 + repeat model ({planted} planted letters), reads {first}..{first + nreads - 1} of 150 bp, "
                 f"2% substitutions, 50% reverse-complemented, -b -l {min_len}")
     hours = float(os.environ.get("REF_TIMEOUT_HOURS", "5"))
     rc, secs = run_reference(["-b", "-l", str(min_len), "-o", "out.txt", "ref.fa", "qry.fa"], tmp,
@@ -197,6 +198,12 @@ def case_config5_first100k(tmp):
               "reference_valid": bad == 0, "invalid_rows": bad,
               "rows_beyond_2p31": int((rows[:, 1].astype(np.int64) > (1 << 31)).sum()), "workload": workload})
     return d
+
+
+def case_config5_reads_7M(tmp):
+    """A second, disjoint pin of configs[4]: reads 7,000,000 .. 7,099,999 of the same 12.5 M-read share (block numbers in the
+    digest are the file's: 0 .. 199,999)."""
+    return case_config5_first100k(tmp, 7_000_000)
 
 
 def case_config4_genome_like_first100k(tmp):
@@ -261,7 +268,7 @@ def case_config1_dups_pair_mam(tmp):
 
 
 CASES = {"config1_dups_pair_image": case_config1_dups_pair_image, "config4_genome_like_first100k": case_config4_genome_like_first100k, "config1_dups_pair": case_config1_dups_pair, "config1_dups_pair_mam": case_config1_dups_pair_mam,
-         "config5_first100k": case_config5_first100k, "config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
+         "config5_first100k": case_config5_first100k, "config5_reads_7M": case_config5_reads_7M, "config4_first1M": case_config4_first1M, "config1_pair": case_config1_pair,
          "config2_mam_first200k": case_config2_mam_first200k, "config1_pair_mam": case_config1_pair_mam}
 
 

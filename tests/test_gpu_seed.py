@@ -88,6 +88,7 @@ def check(eng, text, qs, l, both, expect_seed=True, max_left_frac=None, min_left
         else:
             assert st["seed_reads"] == 0
         st["seed_k"] = int(g.info.seed_k)
+        st["oracle_block_counts"] = obc
         return st, om
     finally:
         g.close()
@@ -215,20 +216,57 @@ def test_windows_that_occur_several_times_and_ties(eng):
             a = int(rng.integers(0, len(seg) - 100))
             r = mutate(rng, seg[a:a + 100 + int(rng.integers(0, min(50, len(seg) - a - 100) + 1))], 0.01)
             qs.append(rc(r) if rng.random() < 0.5 else r)
-    st, _ = check(eng, t, qs, 20, True, min_left=100)
-    assert st["seed_mems"] > 1500
+    st, _ = check(eng, t, qs, 20, True, min_left=20)
+    assert st["seed_mems"] > 1500 and st["seed_left_why"][6] > 0  # copies that go on alike behind the match: not decided here
+
+
+def test_ties_are_ordered_as_the_rows_of_the_suffix_array(eng):
+    """MEMs of one strand with the same start and length (a word of 22-30 letters planted 2-9 times in a random text, so the
+    copies go on differently behind it): the reference lists them in row order around the interval the walk came up from
+    (slamem.c:140,165) -- above it ascending, below it descending, all ascending when there is none.  Reads that hold a word
+    alone (no deeper interval), reads cut from around one copy (that copy's longer match is the deeper interval, the other
+    copies lie on both sides of it), with and without errors, both strands.  The seed path decides all of them itself."""
+    rng = np.random.default_rng(23)
+    n = 400_000
+    t = rng.choice(ACGT, size=n)
+    words = []
+    for copies in (2, 2, 3, 3, 4, 5, 7, 9) * 6:
+        wl = int(rng.integers(22, 31))
+        w = rng.choice(ACGT, size=wl)
+        spots = []
+        for _ in range(copies):
+            x = int(rng.integers(200, n - 200))
+            t[x:x + wl] = w
+            spots.append(x)
+        words.append((w, spots))
+    qs = reads_from(rng, t, 300, 150, 0.02)
+    for w, spots in words:
+        # the word between random letters: the interval of the word is the deepest one at its start
+        r = np.concatenate([rng.choice(ACGT, size=40), w, rng.choice(ACGT, size=50)])
+        qs += [r, rc(r)]
+        for x in spots[:3]:  # around one copy: a longer match there, the other copies tie below it
+            for lo, hi in ((60, 60), (0, 100), (100, 0), (3, 5)):
+                r = t[x - lo: x + len(w) + hi].copy()
+                qs += [r, rc(mutate(rng, r, 0.01))]
+    st, om = check(eng, t, qs, 20, True)
+    assert st["seed_left_why"][6] == 0, st["seed_left_why"]
+    # the batch does hold ties: same strand, start and length
+    obc = st["oracle_block_counts"].astype(np.int64)
+    key = np.stack([np.repeat(np.arange(len(obc)), obc), om["query_pos"].astype(np.int64), om["length"].astype(np.int64)], axis=1)
+    assert len(om) > len(np.unique(key, axis=0)) + 200
 
 
 def test_palindromic_windows(eng):
-    """A window that equals its own reverse complement (even seed length) hits BOTH strands at one text position: the read is
-    left to the index walk.  Planted so that a window of the read starts exactly on the palindrome."""
+    """A window that equals its own reverse complement (even seed length) hits BOTH strands at one text position: a compare
+    for each.  Planted so that a window of the read starts exactly on the palindrome."""
     rng = np.random.default_rng(19)
     n = 300_000  # 2^18 < n <= 2^19: seed_k = 12
     t = rng.choice(ACGT, size=n)
-    pal = np.frombuffer(b"ACGTACGTACGT", dtype=np.uint8)
-    assert np.array_equal(rc(pal), pal)
     spots = [int(x) for x in rng.integers(1000, n - 1000, size=30)]
-    for x in spots:
+    for i, x in enumerate(spots):  # ten palindromes, three copies of each (a bucket holds twelve k-mers)
+        half = np.random.default_rng(100 + i // 3).choice(ACGT, size=6)
+        pal = np.concatenate([half, rc(half)])
+        assert np.array_equal(rc(pal), pal)
         t[x:x + 12] = pal
     l = 21  # s = 10
     qs = reads_from(rng, t, 500, 150, 0.02)
@@ -236,8 +274,9 @@ def test_palindromic_windows(eng):
         for w in (0, 1, 5):  # the palindrome at a window start (offset 10 * w) of the read
             r = t[x - 10 * w: x - 10 * w + 150].copy()
             qs += [r, rc(r)]
-    st, _ = check(eng, t, qs, l, True, min_left=2 * 30)
-    assert st["seed_k"] == 12
+    st, _ = check(eng, t, qs, l, True)
+    assert st["seed_k"] == 12 and st["seed_left_why"][2] >= 2 * 30 and st["seed_left_why"][6] == 0, st
+    assert st["seed_strands_left"] <= 8, st
 
 
 @pytest.mark.parametrize("l", [13, 14, 15, 16, 17, 18, 19, 20, 21, 25, 40])

@@ -14,7 +14,7 @@ from slamem_amd import engine  # noqa: E402
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
 minlen = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-L = 150
+L = int(sys.argv[4]) if len(sys.argv) > 4 else 150
 dev = torch.device("cuda:0")
 ref = engine.synth_reference(n, 42, dev)
 t0 = time.time()
