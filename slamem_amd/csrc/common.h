@@ -15,7 +15,7 @@ namespace slamem {
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kArenaMagicLo = 0x4D414C53u;  // "SLAM"
 constexpr uint32_t kArenaMagicHi = 0x58494845u;  // "EHIX"
-constexpr uint32_t kArenaVersion = 12;  // 12: seed table + text bit-planes (the seed-and-compare path of the search); 11: presence filter in lines keyed by the (k-2)-mer; 10: k-mer occurrence bitmap; 9: K-mer jump table; 8: text-ordered groups + parent records
+constexpr uint32_t kArenaVersion = 13;  // 13: spill list of the seed table; 12: seed table + text bit-planes (the seed-and-compare path of the search); 11: presence filter in lines keyed by the (k-2)-mer; 10: k-mer occurrence bitmap; 9: K-mer jump table; 8: text-ordered groups + parent records
 constexpr uint64_t kHeaderBytes = 4096;
 constexpr uint32_t kFmRowsLog2 = 7;  // 128 BWT rows per FM block
 constexpr uint32_t kFmRows = 1u << kFmRowsLog2;
@@ -105,6 +105,10 @@ struct ArenaHeader {
     uint64_t off_tpl;     // TextPlanes[text_units(n)]    the text as two bit-planes, 64 letters per 16 bytes
     uint64_t off_tnm;     // uint64[text_units(n)]        bit per letter: not one of A,C,G,T
     uint64_t off_tnb;     // uint64[text_units(n)/64 + 1] bit per 64-letter unit: it holds such a letter
+    // (version 13)
+    uint64_t off_spill;   // uint64[spill_cap]            k-mers 13..28 of the buckets that hold that many (SeedBucket::count)
+    uint32_t spill_cap;   // entries the section holds
+    uint32_t spill_used;  // entries in use
 };
 // thresholds of ArenaHeader::lcp_ge
 __host__ __device__ constexpr uint32_t kLcpGe[10] = {18, 20, 25, 30, 40, 50, 75, 100, 150, 255};
@@ -120,9 +124,14 @@ static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 //   SeedBucket   : one 64-byte line: up to 12 text positions whose k-mer hashes here (ascending), a tag byte each (the low
 //                  bits of the hash -- the hash is a bijection of the canonical k-mer, so bucket + tag identify it exactly --
 //                  and bit 7: the text holds the reverse complement of the canonical form), and the number of k-mers that
-//                  hash here (13 = more than fit: a strand that meets the bucket is left to the index walk)
+//                  hash here.  More than 12: count = 13 (a strand that meets the bucket is left to the index walk), or, for
+//                  up to 28, bit 31 + the number beyond 12 in bits 24-28 + their place in the spill list (in units of four
+//                  entries, bits 0-23): entry = position | tag << 32, runs padded to four entries with ~0
 struct __attribute__((aligned(16))) TextPlanes { uint64_t p0, p1; };
 constexpr uint32_t kSeedSlots = 12;
+constexpr uint32_t kSeedSpillMax = 16;            // k-mers of a bucket beyond its slots that the spill list takes
+constexpr uint32_t kSeedSpilled = 0x80000000u;    // SeedBucket::count of such a bucket
+__host__ __device__ inline uint64_t seed_spill_entries(uint64_t n) { return ((n / 16 + 3) & ~3ull) + 64; }
 struct __attribute__((aligned(64))) SeedBucket {
     uint32_t pos[kSeedSlots];
     uint8_t tag[kSeedSlots];
@@ -178,6 +187,7 @@ struct IndexView {
     const TextPlanes* tpl;
     const uint64_t* tnm;
     const uint64_t* tnb;
+    const uint64_t* spill;
     uint32_t seed_k;
     uint32_t seed_log2;
 };

@@ -457,24 +457,53 @@ __global__ void __launch_bounds__(256) k_seed_keys(const TextPlanes* __restrict_
     vals[t] = (uint32_t)t;
 }
 // the sorted positions into their buckets: a lane finds its place in its bucket's run by looking back, the first lane of a
-// run also counts it (13 = more than fit)
+// run also counts it (13 = more than fit) and says how many entries of the spill list the run asks for (13 to 28 k-mers:
+// those beyond the twelfth, rounded up to four)
 __global__ void __launch_bounds__(256) k_seed_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                   uint64_t n, uint32_t log2b, SeedBucket* __restrict__ table) {
+                                                   uint64_t n, uint32_t log2b, SeedBucket* __restrict__ table,
+                                                   uint32_t* __restrict__ want) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t key = keys[i];
-    if (key >> (log2b + 8u)) return;
-    const uint64_t b = key >> 8;
-    uint32_t r = 0;
-    while (r < kSeedSlots && r < i && (keys[i - r - 1u] >> 8) == b) r++;
-    if (r >= kSeedSlots) return;
-    table[b].pos[r] = vals[i];
-    table[b].tag[r] = (uint8_t)(key & 0xFFu);
-    if (r == 0u) {
-        uint32_t c = 1;
-        while (c <= kSeedSlots && i + c < n && (keys[i + c] >> 8) == b) c++;
-        table[b].count = c;
+    uint32_t asks = 0;
+    if ((key >> (log2b + 8u)) == 0ull) {
+        const uint64_t b = key >> 8;
+        uint32_t r = 0;
+        while (r < kSeedSlots && r < i && (keys[i - r - 1u] >> 8) == b) r++;
+        if (r < kSeedSlots) {
+            table[b].pos[r] = vals[i];
+            table[b].tag[r] = (uint8_t)(key & 0xFFu);
+        }
+        if (r == 0u) {
+            uint32_t c = 1;
+            while (c <= kSeedSlots + kSeedSpillMax && i + c < n && (keys[i + c] >> 8) == b) c++;
+            table[b].count = c > kSeedSlots ? kSeedSlots + 1u : c;
+            if (c > kSeedSlots && c <= kSeedSlots + kSeedSpillMax) asks = (c - kSeedSlots + 3u) & ~3u;
+        }
     }
+    want[i] = asks;
+}
+// the runs that asked, at their places of the spill list (the exclusive sums of what was asked for, so the list does not
+// depend on the order the lanes run in); a run that does not fit the list any more stays "more than fit"
+__global__ void __launch_bounds__(256) k_seed_spill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                    const uint32_t* __restrict__ want, const uint32_t* __restrict__ place,
+                                                    uint64_t n, SeedBucket* __restrict__ table, uint64_t* __restrict__ spill,
+                                                    uint32_t cap, uint32_t* __restrict__ used) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t asks = want[i];
+    if (asks == 0u) return;
+    const uint32_t at = place[i];
+    if ((uint64_t)at + asks > (uint64_t)cap) return;
+    const uint64_t b = keys[i] >> 8;
+    uint32_t c = kSeedSlots;
+    while (c < kSeedSlots + kSeedSpillMax && i + c < n && (keys[i + c] >> 8) == b) c++;
+    for (uint32_t e = 0; e < asks; e++) {
+        const uint64_t j = i + kSeedSlots + e;
+        spill[at + e] = kSeedSlots + e < c ? ((uint64_t)vals[j] | ((keys[j] & 0xFFull) << 32)) : ~0ull;
+    }
+    table[b].count = kSeedSpilled | ((c - kSeedSlots) << 24) | (at >> 2);
+    atomicMax(used, at + asks);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -917,6 +946,7 @@ void make_view(slamem_index* idx) {
     idx->view.tpl = h.off_seed ? reinterpret_cast<const TextPlanes*>(base + h.off_tpl) : nullptr;
     idx->view.tnm = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tnm) : nullptr;
     idx->view.tnb = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tnb) : nullptr;
+    idx->view.spill = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_spill) : nullptr;
     idx->view.seed_k = h.off_seed ? h.seed_k : 0u;
     idx->view.seed_log2 = h.off_seed ? h.seed_log2 : 0u;
     idx->view.n = h.n;
@@ -1025,6 +1055,8 @@ static void plan_arena(uint32_t n, uint32_t num_n, int layout, ArenaHeader& hdr)
             hdr.off_tpl = off;  off = align_up(off + units * sizeof(TextPlanes), 256);
             hdr.off_tnm = off;  off = align_up(off + units * 8, 256);
             hdr.off_tnb = off;  off = align_up(off + (units / 64 + 1) * 8, 256);
+            hdr.spill_cap = (uint32_t)seed_spill_entries(n);
+            hdr.off_spill = off; off = align_up(off + (uint64_t)hdr.spill_cap * 8, 256);
         }
     }
     hdr.total_bytes = off;
@@ -1200,6 +1232,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
     SLAMEM_HIP(scan_sum_exclusive_uint4(nullptr, need, (const uint4*)nullptr, (uint4*)nullptr, nblocks, stream));
     tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
+    if (tmp_bytes < scan_u32_tmp_words(R) * 4) tmp_bytes = scan_u32_tmp_words(R) * 4;
     SLAMEM_HIP(sorttmp.alloc(tmp_bytes));
 
     SLAMEM_HIP(hipEventRecord(ev.a, stream));
@@ -1293,9 +1326,22 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysB.as<uint64_t>(), keysA.as<uint64_t>(), valsB.as<uint32_t>(),
                                       valsA.as<uint32_t>(), n, 8, (int)hdr.seed_log2 + 8 + 1, stream));
         SLAMEM_HIP(hipMemsetAsync(d_seed, 0, sizeof(SeedBucket) << hdr.seed_log2, stream));
+        // (the sort's input buffers are free: what the runs ask of the spill list, and the places they get)
+        uint32_t* d_want = valsB.as<uint32_t>();
+        uint32_t* d_place = keysB.as<uint32_t>();
         hipLaunchKernelGGL(k_seed_fill, dim3(grid_for(n)), dim3(256), 0, stream, (const uint64_t*)keysA.as<uint64_t>(),
-                           (const uint32_t*)valsA.as<uint32_t>(), (uint64_t)n, hdr.seed_log2, d_seed);
+                           (const uint32_t*)valsA.as<uint32_t>(), (uint64_t)n, hdr.seed_log2, d_seed, d_want);
         SLAMEM_HIP(hipGetLastError());
+        SLAMEM_HIP(exclusive_scan_u32(d_want, d_place, n, static_cast<uint32_t*>(sorttmp.p), stream));
+        SLAMEM_HIP(hipMemsetAsync(d_scal + 11, 0, 4, stream));
+        hipLaunchKernelGGL(k_seed_spill, dim3(grid_for(n)), dim3(256), 0, stream, (const uint64_t*)keysA.as<uint64_t>(),
+                           (const uint32_t*)valsA.as<uint32_t>(), (const uint32_t*)d_want, (const uint32_t*)d_place, (uint64_t)n,
+                           d_seed, reinterpret_cast<uint64_t*>(base + hdr.off_spill), hdr.spill_cap, d_scal + 11);
+        SLAMEM_HIP(hipGetLastError());
+        SLAMEM_HIP(hipMemcpyAsync(&hdr.spill_used, d_scal + 11, 4, hipMemcpyDeviceToHost, stream));
+        SLAMEM_HIP(hipStreamSynchronize(stream));
+        if (hdr.spill_used < hdr.spill_cap)  // (a saved index is its bytes: no stale memory in it)
+            SLAMEM_HIP(hipMemsetAsync(base + hdr.off_spill + (uint64_t)hdr.spill_used * 8, 0xFF, (uint64_t)(hdr.spill_cap - hdr.spill_used) * 8, stream));
         mark("K1d seed table");
     }
     if (hdr.off_kfilter) {

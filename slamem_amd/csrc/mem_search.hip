@@ -2686,7 +2686,9 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         hits &= count >= kSeedSlots ? 0xFFFu : (1u << count) - 1u;
         if (strands == 1u) hits &= ~rev;
         if (!act) hits = 0;
-        if (act && count > kSeedSlots) {
+        // more than twelve k-mers in the bucket: up to sixteen more in the spill list (looked at behind the twelve)
+        const uint32_t xn = act && (count & kSeedSpilled) ? (count >> 24) & 0x1Fu : 0u, xo = (count & 0xFFFFFFu) << 2;
+        if (act && count > kSeedSlots && !(count & kSeedSpilled)) {
             atomicOr(&S.flags, 3u << (2u * rs));
             if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 1u, 1ull);
             hits = 0;
@@ -2726,6 +2728,24 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             const uint32_t p = it == 0u ? p1 : it == 1u ? p2 : sel12(b0, b1, b2, e);
             push(hv, p, (rev >> e) & 1u);
             if (__ballot(hv && both) != 0ull) push(hv && both, p, 1u);
+        }
+        for (uint32_t e0 = 0; __ballot(e0 < xn) != 0ull; e0 += 4u) {  // (rare) four entries of the spill list per round
+            const bool on = e0 < xn;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+            if (on) {
+                const uint4* P = reinterpret_cast<const uint4*>(ix.spill + xo + e0);
+                v0 = P[0]; v1 = P[1];
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) {
+                const uint32_t p = q == 0u ? v0.x : q == 1u ? v0.z : q == 2u ? v1.x : v1.z;
+                const uint32_t d = ((q == 0u ? v0.y : q == 1u ? v0.w : q == 2u ? v1.y : v1.w) ^ want) & 0xFFu;
+                const uint32_t st = d >> 7;
+                const bool hv = on && e0 + q < xn && (d & 0x7Fu) == 0u && !(strands == 1u && st);
+                if (__ballot(hv) == 0ull) continue;
+                push(hv, p, st);
+                if (__ballot(hv && both) != 0ull) push(hv && both, p, 1u);
+            }
         }
         if (njobs > SeedWave<NW>::kJobs) {  // (many repeated windows) every read of this trip is left to K8
             for (uint32_t i = t0; i < t0 + rpt && i < kSeedReads; i++) wflags |= 3u << (2u * i);

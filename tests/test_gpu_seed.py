@@ -249,7 +249,9 @@ def test_ties_are_ordered_as_the_rows_of_the_suffix_array(eng):
                 r = t[x - lo: x + len(w) + hi].copy()
                 qs += [r, rc(mutate(rng, r, 0.01))]
     st, om = check(eng, t, qs, 20, True)
-    assert st["seed_left_why"][6] == 0, st["seed_left_why"]
+    # (a word in nine copies shares its bucket with the bucket's other k-mers: more than twelve, read from the spill list)
+    # (what is left: a few trips whose compares did not fit the wave's list)
+    assert st["seed_left_why"][6] == 0 and st["seed_left_why"][1] == 0 and st["seed_strands_left"] <= 64, st["seed_left_why"]
     # the batch does hold ties: same strand, start and length
     obc = st["oracle_block_counts"].astype(np.int64)
     key = np.stack([np.repeat(np.arange(len(obc)), obc), om["query_pos"].astype(np.int64), om["length"].astype(np.int64)], axis=1)
@@ -307,6 +309,36 @@ def test_matches_that_are_barely_long_enough(eng, l):
     assert st["seed_k"] == 10 and len(om) >= len(qs)
 
 
+@pytest.mark.parametrize("copies,left", [(10, False), (14, False), (18, False), (40, True)])
+def test_buckets_with_more_than_twelve_kmers(eng, copies, left):
+    """A 60-letter word in 10 .. 40 exact copies: every k-mer of it has that many text positions, all in one bucket with the same
+    tag.  Up to 28 k-mers of a bucket are kept (twelve in its line, the rest in the spill list) and each is a compare; beyond,
+    the strand is left to the index walk.  Reads that hold the word (with letters around it from one of the copies, from none)
+    on both strands; the equal matches of the copies tie and are ordered from the text behind them."""
+    rng = np.random.default_rng(31 + copies)
+    n = 200_000
+    t = rng.choice(ACGT, size=n)
+    w = rng.choice(ACGT, size=60)
+    spots = [int(x) for x in rng.choice(np.arange(300, n - 300, 200), size=copies, replace=False)]
+    for x in spots:
+        t[x:x + 60] = w
+    qs = []
+    for i in range(40):  # (among other reads: a wave's sixteen reads share one list of compares)
+        qs += reads_from(rng, t, 15, 150, 0.02)
+        r = np.concatenate([rng.choice(ACGT, size=int(rng.integers(0, 60))), w, rng.choice(ACGT, size=int(rng.integers(0, 30)))])
+        qs.append(r if i % 2 else rc(r))
+        qs += reads_from(rng, t, 15, 150, 0.02)
+        x = spots[i % copies]
+        r = mutate(rng, t[x - 45: x + 105], 0.01)
+        qs.append(r if i % 2 else rc(r))
+    st, om = check(eng, t, qs, 20, True)
+    if left:
+        assert st["seed_left_why"][1] > 0 and st["seed_strands_left"] >= 2 * 80, st["seed_left_why"]
+    else:
+        assert st["seed_left_why"][1] == 0 and st["seed_strands_left"] <= 64, st["seed_left_why"]
+    assert len(om) > 40 * copies
+
+
 def test_satellite_fills_its_buckets(eng):
     """A tandem array (one unit 2,000 times) puts thousands of positions into the buckets of its k-mers (count 13 = more than
     fit): reads from it, and reads that merely share one window with it, are left to the index walk; the others are not."""
@@ -358,6 +390,6 @@ def test_full_size_headline_both_paths_agree_in_order(eng):
     assert torch.equal(seed_off, m.block_offsets) and torch.equal(seed_mems, m.mems[:total])
     with search_path("seed"):
         st = eng.search_stats(m, reads, offsets, 20)
-    assert st["seed_reads"] == nreads and st["seed_windows"] == 27 * nreads and st["seed_strands_left"] < 0.01 * 2 * nreads
-    assert st["survivors"] < 0.6 * st["seed_strands_left"]  # the wrong strands of the reads that were left whole die in the presence filter
+    assert st["seed_reads"] == nreads and st["seed_windows"] == 27 * nreads and st["seed_strands_left"] < 1000, st["seed_left_why"]
+    assert st["survivors"] <= st["seed_strands_left"]
     idx.close()
