@@ -109,6 +109,8 @@ struct ArenaHeader {
     uint64_t off_spill;   // uint64[spill_cap]            k-mers 13..28 of the buckets that hold that many (SeedBucket::count)
     uint32_t spill_cap;   // entries the section holds
     uint32_t spill_used;  // entries in use
+    uint64_t off_tuq;     // uint64[text_units(n)]        bit per letter: the k-mer that starts here occurs once in the text
+                          //                              (either orientation; not its own reverse complement)
 };
 // thresholds of ArenaHeader::lcp_ge
 __host__ __device__ constexpr uint32_t kLcpGe[10] = {18, 20, 25, 30, 40, 50, 75, 100, 150, 255};
@@ -121,7 +123,7 @@ static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 // around it on that diagonal -- found by comparing the strand with the text itself, 64 letters per XOR.
 //   TextPlanes u : letters 64u .. 64u+63 of the text as two bit-planes (A,C,G,T = 0..3; bit i of p0 / p1 = low / high bit of
 //                  letter 64u+i; letters that are not A,C,G,T and positions behind the text are 0 and marked in tnm / tnb)
-//   SeedBucket   : one 64-byte line: up to 12 text positions whose k-mer hashes here (ascending), a tag byte each (the low
+//   SeedBucket   : one 64-byte line: up to 12 text positions whose k-mer hashes here (by k-mer, then ascending), a tag byte each (the low
 //                  bits of the hash -- the hash is a bijection of the canonical k-mer, so bucket + tag identify it exactly --
 //                  and bit 7: the text holds the reverse complement of the canonical form), and the number of k-mers that
 //                  hash here.  More than 12: count = 13 (a strand that meets the bucket is left to the index walk), or, for
@@ -188,6 +190,7 @@ struct IndexView {
     const uint64_t* tnm;
     const uint64_t* tnb;
     const uint64_t* spill;
+    const uint64_t* tuq;
     uint32_t seed_k;
     uint32_t seed_log2;
 };

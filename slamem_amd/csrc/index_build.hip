@@ -440,39 +440,51 @@ __device__ __forceinline__ bool text_field(const TextPlanes* __restrict__ tpl, c
     f1 = (uint32_t)((a.p1 >> sh) | ((b.p1 << 1) << (63u - sh))) & m;
     return ((uint32_t)((na >> sh) | ((nb << 1) << (63u - sh))) & m) == 0u;
 }
-// sort key of text position t: its bucket above a tag byte; positions without a k-mer over A,C,G,T sort behind every bucket
+// sort key of text position t: its bucket above a byte (the tag's hash bits above the orientation bit, so that the two
+// orientations of a k-mer sort next to each other); positions without a k-mer over A,C,G,T sort behind every bucket.
+// Also the first form of the "occurs once" plane: a bit for every position that has a k-mer which is not its own reverse
+// complement (k_seed_fill clears those that occur more than once); a wave covers one 64-letter unit
 __global__ void __launch_bounds__(256) k_seed_keys(const TextPlanes* __restrict__ tpl, const uint64_t* __restrict__ tnm,
                                                    uint32_t n, uint32_t k, uint32_t log2b, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals) {
+                                                   uint32_t* __restrict__ vals, uint64_t* __restrict__ tuq, uint64_t units) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)n) return;
     uint64_t key = 1ull << (log2b + 8u);
     uint32_t f0, f1;
-    if (t + k <= (uint64_t)n && text_field(tpl, tnm, t, k, f0, f1)) {
+    bool once = false;
+    if (t < (uint64_t)n && t + k <= (uint64_t)n && text_field(tpl, tnm, t, k, f0, f1)) {
         const uint32_t x = seed_key(f0, f1, k), y = seed_key(seed_rev_field(f0, k), seed_rev_field(f1, k), k);
         const uint32_t h = seed_mix(x < y ? x : y, 2u * k), tb = 2u * k - log2b;
-        key = ((uint64_t)(h >> tb) << 8) | (uint64_t)((h & ((1u << tb) - 1u)) | (x > y ? 0x80u : 0u));
+        key = ((uint64_t)(h >> tb) << 8) | (uint64_t)(((h & ((1u << tb) - 1u)) << 1) | (x > y ? 1u : 0u));
+        once = x != y;
     }
+    const unsigned long long m = __ballot(once);
+    if ((threadIdx.x & 63u) == 0u && (t >> 6) < units) tuq[t >> 6] = m;
+    if (t >= (uint64_t)n) return;
     keys[t] = key;
     vals[t] = (uint32_t)t;
 }
+// tag byte of a bucket entry (hash bits, bit 7: orientation) from the low byte of its sort key (hash bits above the orientation bit)
+__device__ __forceinline__ uint8_t seed_tag_of_sorted(uint32_t key) { return (uint8_t)(((key >> 1) & 0x7Fu) | ((key & 1u) << 7)); }
 // the sorted positions into their buckets: a lane finds its place in its bucket's run by looking back, the first lane of a
 // run also counts it (13 = more than fit) and says how many entries of the spill list the run asks for (13 to 28 k-mers:
 // those beyond the twelfth, rounded up to four)
 __global__ void __launch_bounds__(256) k_seed_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                    uint64_t n, uint32_t log2b, SeedBucket* __restrict__ table,
-                                                   uint32_t* __restrict__ want) {
+                                                   uint32_t* __restrict__ want, unsigned long long* __restrict__ tuq) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t key = keys[i];
     uint32_t asks = 0;
     if ((key >> (log2b + 8u)) == 0ull) {
         const uint64_t b = key >> 8;
+        // the same k-mer (in either orientation) next to this one in the sorted order: it occurs more than once
+        if ((i > 0 && (keys[i - 1u] >> 1) == (key >> 1)) || (i + 1u < n && (keys[i + 1u] >> 1) == (key >> 1)))
+            atomicAnd(tuq + (vals[i] >> 6), ~(1ull << (vals[i] & 63u)));
         uint32_t r = 0;
         while (r < kSeedSlots && r < i && (keys[i - r - 1u] >> 8) == b) r++;
         if (r < kSeedSlots) {
             table[b].pos[r] = vals[i];
-            table[b].tag[r] = (uint8_t)(key & 0xFFu);
+            table[b].tag[r] = seed_tag_of_sorted((uint32_t)key);
         }
         if (r == 0u) {
             uint32_t c = 1;
@@ -500,7 +512,7 @@ __global__ void __launch_bounds__(256) k_seed_spill(const uint64_t* __restrict__
     while (c < kSeedSlots + kSeedSpillMax && i + c < n && (keys[i + c] >> 8) == b) c++;
     for (uint32_t e = 0; e < asks; e++) {
         const uint64_t j = i + kSeedSlots + e;
-        spill[at + e] = kSeedSlots + e < c ? ((uint64_t)vals[j] | ((keys[j] & 0xFFull) << 32)) : ~0ull;
+        spill[at + e] = kSeedSlots + e < c ? ((uint64_t)vals[j] | ((uint64_t)seed_tag_of_sorted((uint32_t)keys[j]) << 32)) : ~0ull;
     }
     table[b].count = kSeedSpilled | ((c - kSeedSlots) << 24) | (at >> 2);
     atomicMax(used, at + asks);
@@ -947,6 +959,7 @@ void make_view(slamem_index* idx) {
     idx->view.tnm = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tnm) : nullptr;
     idx->view.tnb = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tnb) : nullptr;
     idx->view.spill = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_spill) : nullptr;
+    idx->view.tuq = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tuq) : nullptr;
     idx->view.seed_k = h.off_seed ? h.seed_k : 0u;
     idx->view.seed_log2 = h.off_seed ? h.seed_log2 : 0u;
     idx->view.n = h.n;
@@ -1057,6 +1070,7 @@ static void plan_arena(uint32_t n, uint32_t num_n, int layout, ArenaHeader& hdr)
             hdr.off_tnb = off;  off = align_up(off + (units / 64 + 1) * 8, 256);
             hdr.spill_cap = (uint32_t)seed_spill_entries(n);
             hdr.off_spill = off; off = align_up(off + (uint64_t)hdr.spill_cap * 8, 256);
+            hdr.off_tuq = off;  off = align_up(off + units * 8, 256);
         }
     }
     hdr.total_bytes = off;
@@ -1319,18 +1333,20 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         SeedBucket* d_seed = reinterpret_cast<SeedBucket*>(base + hdr.off_seed);
         SLAMEM_HIP(hipMemsetAsync(d_tnb, 0, (units / 64 + 1) * 8, stream));
         hipLaunchKernelGGL(k_text_planes, dim3(grid_for(units + 63)), dim3(256), 0, stream, pk.as<uint64_t>(), n, units, d_tpl, d_tnm, d_tnb);
-        hipLaunchKernelGGL(k_seed_keys, dim3(grid_for(n)), dim3(256), 0, stream, (const TextPlanes*)d_tpl, (const uint64_t*)d_tnm, n,
-                           hdr.seed_k, hdr.seed_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>());
+        uint64_t* d_tuq = reinterpret_cast<uint64_t*>(base + hdr.off_tuq);
+        hipLaunchKernelGGL(k_seed_keys, dim3(grid_for(units * 64)), dim3(256), 0, stream, (const TextPlanes*)d_tpl, (const uint64_t*)d_tnm, n,
+                           hdr.seed_k, hdr.seed_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>(), d_tuq, units);
         SLAMEM_HIP(hipGetLastError());
         need = tmp_bytes;
         SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysB.as<uint64_t>(), keysA.as<uint64_t>(), valsB.as<uint32_t>(),
-                                      valsA.as<uint32_t>(), n, 8, (int)hdr.seed_log2 + 8 + 1, stream));
+                                      valsA.as<uint32_t>(), n, 0, (int)hdr.seed_log2 + 8 + 1, stream));
         SLAMEM_HIP(hipMemsetAsync(d_seed, 0, sizeof(SeedBucket) << hdr.seed_log2, stream));
         // (the sort's input buffers are free: what the runs ask of the spill list, and the places they get)
         uint32_t* d_want = valsB.as<uint32_t>();
         uint32_t* d_place = keysB.as<uint32_t>();
         hipLaunchKernelGGL(k_seed_fill, dim3(grid_for(n)), dim3(256), 0, stream, (const uint64_t*)keysA.as<uint64_t>(),
-                           (const uint32_t*)valsA.as<uint32_t>(), (uint64_t)n, hdr.seed_log2, d_seed, d_want);
+                           (const uint32_t*)valsA.as<uint32_t>(), (uint64_t)n, hdr.seed_log2, d_seed, d_want,
+                           reinterpret_cast<unsigned long long*>(d_tuq));
         SLAMEM_HIP(hipGetLastError());
         SLAMEM_HIP(exclusive_scan_u32(d_want, d_place, n, static_cast<uint32_t*>(sorttmp.p), stream));
         SLAMEM_HIP(hipMemsetAsync(d_scal + 11, 0, 4, stream));

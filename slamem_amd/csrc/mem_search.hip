@@ -187,6 +187,7 @@ struct SearchArgs {
     uint64_t query_words;       // v3: 8-byte words of the query buffer that may be read
     const uint64_t* pq;         // v3: the strands as packed letter ids (k_pack_queries), two zero words in front
     uint64_t* pq_out;           //     (the same buffer, written by k_pack_queries)
+    uint32_t seed_step;         // K8s: 0, or the stride of the windows of the first round (experiments: SLAMEM_SEED_STEP)
     const uint64_t* item_pk;    // v3: per work item, the word offset of its strand block in pq
     unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
     int32_t direct_min_depth;   // v3: a single-row match at least this deep is extended by comparing with the text (<0: off)
@@ -2491,6 +2492,9 @@ struct SeedWave {
             uint32_t mem_sig[kMems];
         };
     };
+    uint32_t bad[kSeedReads];           // the read holds a letter that is not A,C,G,T
+    unsigned long long expl[kSeedReads];  // bit per window of a read: its only occurrence in the text is accounted for (round A)
+    uint16_t ring[128];                 // window ids (read << 8 | window) waiting for a full trip
     uint32_t flags;                     // bit 2 * read + strand: the strand is left to K8
     uint32_t pad[3];
 };
@@ -2530,12 +2534,6 @@ template <bool kStats, uint32_t NW>
 __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs A, uint8_t* __restrict__ alive) {
     constexpr uint32_t kMaxLen = 64u * NW;
     __shared__ SeedWave<NW> lds[4];
-    __shared__ uint8_t lut[256];  // ASCII -> 2-bit code | 4 (one of A,C,G,T), or 8
-    {
-        const uint32_t u = threadIdx.x & 0xDFu, x = (u >> 1) & 3u;
-        lut[threadIdx.x] = (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? (uint8_t)((x ^ (x >> 1)) | 4u) : (uint8_t)8u;
-    }
-    __syncthreads();
     const IndexView& ix = A.ix;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     SeedWave<NW>& S = lds[wv];
@@ -2567,7 +2565,6 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     }
     if (lane == 0u) S.flags = 0u;
     const uint32_t plen = nwin ? len : 0u;
-    const uint8_t* qbytes = reinterpret_cast<const uint8_t*>(A.qwords);
     // The wave's reads lie next to each other in the query buffer: all their 16-byte chunks are fetched at once into LDS (a few
     // wide loads in flight together) and the letters are taken from there.  (Letter by letter from global memory, each round
     // of 64 letters waited for its own 64-byte load: the kernel spent half its time there.)  A wave whose reads span more than
@@ -2582,83 +2579,103 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         for (uint32_t c = lane; c < nchunks; c += 64u) S.raw[c] = src[c];
     }
     wave_sync();
-    const uint8_t* rawbytes = reinterpret_cast<const uint8_t*>(S.raw);
-    for (uint32_t i = 0; i < nr; i++) {
-        const uint32_t Li = (uint32_t)__builtin_amdgcn_readlane((int)plen, (int)i);
-        uint32_t keep_len = Li, keep_win = (uint32_t)__builtin_amdgcn_readlane((int)nwin, (int)i);
-        if (Li) {
-            const uint64_t base = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)i),
-                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)i));
-            uint64_t f0[NW], f1[NW];
-            unsigned long long other = 0ull;
+    // One lane per (read, 64-letter word): the lane takes its 64 bytes as 16 words and turns them into the word's two plane
+    // words with whole-word bit operations -- the letters' 2-bit codes are bits 1 and 2 of their ASCII bytes ((c >> 1) & 3 = x,
+    // code = x ^ (x >> 1): A,C,G,T = 0..3), gathered four letters at a time.  (One letter per lane and three ballots per 64
+    // letters of ONE read, the first form of this step, took 3.0 of the kernel's 6.8 ms on the headline batch.)
+    if (lane < kSeedReads) S.bad[lane] = 0u;
+    wave_sync();
+    const uint32_t* rawwords = reinterpret_cast<const uint32_t*>(S.raw);
+    const uint32_t* qw32 = reinterpret_cast<const uint32_t*>(A.qwords);
+    const uint64_t qlast32 = A.query_words * 2u - 1u;
+    constexpr uint32_t kRawLast = (kSeedReads * NW * 4u + 1u) * 4u - 1u;
+    for (uint32_t pb = 0; pb < nr * NW; pb += 64u) {
+        const uint32_t pp = pb + lane, i = pp / NW, j = pp % NW;
+        const bool on = pp < nr * NW;
+        const uint32_t Li = __shfl(plen, (int)(on ? i : 0u));
+        const uint64_t base = __shfl(off, (int)(on ? i : 0u));
+        if (on && 64u * j < Li) {
+            const uint32_t nv = Li - 64u * j < 64u ? Li - 64u * j : 64u;   // letters of this word
+            const uint64_t a = base + 64u * j;                              // its first byte in the query buffer
+            const uint32_t sh8 = (uint32_t)(a & 3u);
+            uint32_t w[17];
+            if (staged) {
+                const uint32_t i0 = (uint32_t)((a - (chunk0 << 4)) >> 2);
 #pragma unroll
-            for (uint32_t j = 0; j < NW; j++) {
-                const uint32_t x = 64u * j + lane;
-                uint32_t v = 0;
-                if (x < Li) v = lut[staged ? rawbytes[(uint32_t)(base - (chunk0 << 4)) + x] : qbytes[base + x]];
-                f0[j] = __ballot((v & 1u) != 0u);
-                f1[j] = __ballot((v & 2u) != 0u);
-                other |= __ballot((v & 8u) != 0u);
-            }
-            if (other) {  // a letter that is not A,C,G,T (N equals N in the reference, A.1): the index walk knows how
-                wflags |= 3u << (2u * i);
-                keep_len = 0; keep_win = 0;
+                for (uint32_t t = 0; t < 17u; t++) w[t] = rawwords[i0 + t < kRawLast ? i0 + t : kRawLast];
             } else {
-                // reverse strand: letter x of it is the complement (both plane bits flipped) of letter Li-1-x
-                const uint32_t sh = kMaxLen - Li, q = sh >> 6, r = sh & 63u;  // the reversed planes come down by this many letters
-                uint64_t g0[NW], g1[NW];
+                const uint64_t i0 = a >> 2;
 #pragma unroll
-                for (int pl = 0; pl < 2; pl++) {
-                    const uint64_t* f = pl ? f1 : f0;
-                    uint64_t* g = pl ? g1 : g0;
-                    // t[w] = word w of the bit-reversed planes (word 0 lowest), words behind the last are 0
-                    auto rv = [&](uint32_t w) -> uint64_t {
-                        uint64_t v = 0ull;
+                for (uint32_t t = 0; t < 17u; t++) w[t] = qw32[i0 + t < qlast32 ? i0 + t : qlast32];
+            }
+            uint32_t p0lo = 0, p0hi = 0, p1lo = 0, p1hi = 0, bad = 0;
 #pragma unroll
-                        for (uint32_t u = 0; u < NW; u++) v = (w == u) ? __brevll(f[NW - 1u - u]) : v;
-                        return v;
-                    };
+            for (uint32_t t = 0; t < 16u; t++) {
+                const uint32_t d = __builtin_amdgcn_alignbyte(w[t + 1u], w[t], sh8);  // bytes a + 4t .. a + 4t + 3
+                const uint32_t nb = nv > 4u * t ? (nv - 4u * t < 4u ? nv - 4u * t : 4u) : 0u;
+                const uint32_t M = nb >= 4u ? 0x01010101u : (0x01010101u & ((1u << (8u * nb)) - 1u));
+                const uint32_t B0 = d, B1 = d >> 1, B2 = d >> 2, B3 = d >> 3, B4 = d >> 4, B6 = d >> 6, B7 = d >> 7;
+                // one of A,C,G,T in either case: 0100 0001, 0100 0011, 0100 0111, 0101 0100 with bit 5 free
+                const uint32_t good = B6 & ~B7 & ~B3 & ((~B4 & B0 & (~B2 | B1)) | (B4 & B2 & ~B1 & ~B0));
+                bad |= ~good & M;
+                const uint32_t X = ((B1 ^ B2) & M) | ((B2 & M) << 4);
+                const uint32_t G = (X | (X >> 7) | (X >> 14) | (X >> 21)) & 0xFFu;  // plane 0 of the four letters: bits 0-3, plane 1: bits 4-7
+                if (t < 8u) { p0lo |= (G & 0xFu) << (4u * t); p1lo |= (G >> 4) << (4u * t); }
+                else { p0hi |= (G & 0xFu) << (4u * (t - 8u)); p1hi |= (G >> 4) << (4u * (t - 8u)); }
+            }
+            S.pl[i][0][0][j] = u64_of(p0lo, p0hi);
+            S.pl[i][0][1][j] = u64_of(p1lo, p1hi);
+            if (bad) S.bad[i] = 1u;
+        } else if (on) {
+            S.pl[i][0][0][j] = 0ull; S.pl[i][0][1][j] = 0ull;
+        }
+        if (on && j == 0u) { S.pl[i][0][0][NW] = 0ull; S.pl[i][0][1][NW] = 0ull; S.pl[i][1][0][NW] = 0ull; S.pl[i][1][1][NW] = 0ull; }
+    }
+    wave_sync();
+    // reverse strand: letter x of it is the complement (both plane bits flipped) of letter Li-1-x: the bit-reversed planes
+    // (word 0 lowest, words behind the last are 0) come down by 64 * NW - Li letters
+    for (uint32_t pb = 0; pb < nr * NW; pb += 64u) {
+        const uint32_t pp = pb + lane, i = pp / NW, w = pp % NW;
+        const bool on = pp < nr * NW;
+        const uint32_t Li = __shfl(plen, (int)(on ? i : 0u));
+        if (on) {
+            const uint32_t sh = kMaxLen - Li, q = sh >> 6, r = sh & 63u;
 #pragma unroll
-                    for (uint32_t w = 0; w < NW; w++)
-                        g[w] = ~funnel64(rv(w + q), rv(w + q + 1u), r) & bits_range(0, (int)Li - 64 * (int)w);
-                }
-                if (lane == 0u) {
-#pragma unroll
-                    for (uint32_t j = 0; j < NW; j++) {
-                        S.pl[i][0][0][j] = f0[j]; S.pl[i][0][1][j] = f1[j];
-                        S.pl[i][1][0][j] = g0[j]; S.pl[i][1][1][j] = g1[j];
-                    }
-                    S.pl[i][0][0][NW] = 0ull; S.pl[i][0][1][NW] = 0ull; S.pl[i][1][0][NW] = 0ull; S.pl[i][1][1][NW] = 0ull;
-                }
+            for (uint32_t pl = 0; pl < 2u; pl++) {
+                const uint64_t* f = S.pl[i][0][pl];
+                const uint64_t lo = w + q < NW ? __brevll(f[NW - 1u - (w + q)]) : 0ull, hi = w + q + 1u < NW ? __brevll(f[NW - 2u - (w + q)]) : 0ull;
+                S.pl[i][1][pl][w] = Li ? ~funnel64(lo, hi, r) & bits_range(0, (int)Li - 64 * (int)w) : 0ull;
             }
         }
-        if (lane == 0u) { S.len[i] = keep_len; S.nwin[i] = keep_win; }
-        if (keep_win == 0u && lane == i) nwin = 0;
+    }
+    {   // a letter that is not A,C,G,T (N equals N in the reference, A.1): the index walk knows how
+        const bool isbad = lane < nr && plen != 0u && S.bad[lane] != 0u;
+        uint32_t m = (uint32_t)__ballot(isbad) & 0xFFFFu;
+        m = (m | (m << 8)) & 0x00FF00FFu; m = (m | (m << 4)) & 0x0F0F0F0Fu; m = (m | (m << 2)) & 0x33333333u; m = (m | (m << 1)) & 0x55555555u;
+        wflags |= m | (m << 1);
+        if (isbad) nwin = 0;
+        if (lane < nr) { S.len[lane] = nwin ? len : 0u; S.nwin[lane] = nwin; }
     }
     if (lane == 0u)
         for (uint32_t i = nr; i < kSeedReads; i++) { S.len[i] = 0u; S.nwin[i] = 0u; }
     wave_sync();
-    // slots per read: the power of two that holds the most windows of a read of this wave
-    uint32_t slots = 0, lg_slots = 0;
-    if (__ballot(nwin > 0u)) { slots = 1; }
-#pragma unroll
-    for (uint32_t t = 1, lg = 1; t <= 32u; t <<= 1, lg++)
-        if (__ballot(nwin > t)) { slots = 2u * t; lg_slots = lg; }
-#ifdef SLAMEM_SEED_DIAG_PACK_ONLY   // (timing experiments only: wrong results)
-    slots = 0;
-#endif
-    const uint32_t rpt = slots ? 64u / slots : kSeedReads;  // reads per trip
+    // ---- which windows are looked up, and when ----------------------------------------------------------------------------
+    // Two rounds when the windows lie close (mstep > 1).  Round A looks up every mstep-th window of a read and compares its hits;
+    // a compare that finds the exact run [a, b) around its window also reads the "occurs once" plane of the text under it: a
+    // window of the other kind that lies inside [a, b) and whose k-mer occurs once in the text has its ONLY occurrence on this
+    // diagonal, where it is accounted for -- its lookup would bring that one hit and nothing else, so it is not made.  Round B
+    // looks up what is left: the windows with an error in them and the repeats (headline batch: 27 windows a read, 72 % of
+    // them free of errors: 9 lookups in round A, 5-6 in round B).  A match that holds a round-A window is reported in round A
+    // by the first of those (forward offset); one that holds none, in round B by its first window.
+    const uint32_t mstep = !ix.tuq ? 1u : A.seed_step ? A.seed_step : s <= 6u ? 3u : s <= 12u ? 2u : 1u;
+    const uint32_t lmod = mstep == 3u ? lane % 3u : mstep == 2u ? (lane & 1u) : 0u;
+    if (lane < kSeedReads) S.expl[lane] = 0ull;
+    uint32_t njobs = 0, nmems = 0;
 
-    // Phase 1 for every trip first (the trips are independent: their table lines are in flight together), then ONE pass of
-    // compares over the wave's jobs and one ranking of its MEMs -- those run with most lanes busy instead of a few per trip.
-    uint32_t njobs = 0;
-    if (slots)
-    for (uint32_t t0 = 0; t0 < nr; t0 += rpt) {
-        // ---- phase 1: one lane per window: the seed table line of its canonical form -----------------------------------
-        const uint32_t rs = t0 + (lane >> lg_slots), wi = lane & (slots - 1u);
-        const uint32_t nw = rs < kSeedReads ? S.nwin[rs] : 0u, Lr = rs < kSeedReads ? S.len[rs] : 0u;
-        const bool act = wi < nw;
-        if (__ballot(act) == 0ull) continue;
+    // ---- lookups of one trip: one lane per window (ent = read << 8 | window): the seed table line of its canonical form ----
+    auto trip = [&](uint32_t ent, bool act, uint32_t step) {
+        const uint32_t rs = ent >> 8, wi = ent & 0xFFu;
+        const uint32_t Lr = act ? S.len[rs] : 0u;
         const uint32_t o = wi * s;
         uint32_t want = 0, pal = 0;
         uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0, b3 = b0;
@@ -2696,21 +2713,24 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         // a window that is its own reverse complement lies in both strands: every hit is a compare for each
         const bool both = pal != 0u && strands == 2u;
         if (kStats && both && hits) atomicAdd(A.stats + SC_SEED_WHY + 2u, 1ull);  // (counted, no longer a reason to leave the read)
-        // Every hit is a compare -- except one whose neighbour window (the one s letters earlier in the forward strand) hit the
-        // same diagonal: the two windows overlap or touch, so they lie in the same match and that window, or one before it,
-        // reports the MEM.  (The neighbour's first two hits are looked at; a hit this misses is sorted out by its compare.)
+        // Every hit is a compare -- except one whose neighbour (the lane before: the window `step` windows earlier in the forward
+        // strand of the same read) hit the same diagonal while the two windows overlap or touch: they lie in the same match and
+        // that window, or one before it, reports the MEM.  (The neighbour's first two hits are looked at; a hit this misses is
+        // sorted out by its compare.)
         const uint32_t nm = (uint32_t)__popc(hits);
         const uint32_t e1 = nm ? (uint32_t)__ffs((int)hits) - 1u : 0u, h2 = hits & (hits - 1u), e2 = nm > 1u ? (uint32_t)__ffs((int)h2) - 1u : 0u;
         const uint32_t p1 = sel12(b0, b1, b2, e1), p2 = sel12(b0, b1, b2, e2);
         const uint32_t st1 = (rev >> e1) & 1u, st2 = (rev >> e2) & 1u;
+        const uint32_t dist = step * s;  // letters between the neighbour's window and this one
         uint32_t pn = 0, pp1 = 0, pp2 = 0, ps1 = 0, ps2 = 0;
-        if (s <= k) {
+        if (dist <= k) {
             pn = __shfl_up(nm, 1); pp1 = __shfl_up(p1, 1); pp2 = __shfl_up(p2, 1); ps1 = __shfl_up(st1, 1); ps2 = __shfl_up(st2, 1);
-            if (wi == 0u) pn = 0;
+            const uint32_t pent = __shfl_up(act ? ent : 0xFFFFFFFFu, 1);
+            if (lane == 0u || wi < step || pent != ent - step) pn = 0;
         }
         const uint32_t njobs0 = njobs;
         auto push = [&](bool hv, uint32_t p, uint32_t st) {
-            const uint32_t w = st ? p + s : p - s;
+            const uint32_t w = st ? p + dist : p - dist;
             const bool job = hv && !((pn >= 1u && ps1 == st && pp1 == w) || (pn >= 2u && ps2 == st && pp2 == w));
             const unsigned long long qb = __ballot(job);
             const uint32_t at = njobs + (uint32_t)__popcll(qb & below);
@@ -2748,18 +2768,41 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             }
         }
         if (njobs > SeedWave<NW>::kJobs) {  // (many repeated windows) every read of this trip is left to K8
-            for (uint32_t i = t0; i < t0 + rpt && i < kSeedReads; i++) wflags |= 3u << (2u * i);
+            if (act) atomicOr(&S.flags, 3u << (2u * rs));
             if (kStats && lane == 0u) atomicAdd(A.stats + SC_SEED_WHY + 3u, 1ull);
             njobs = njobs0;
         }
-    }
-    wave_sync();
-#ifdef SLAMEM_SEED_DIAG_NO_COMPARE   // (timing experiments only: wrong results)
-    njobs = 0;
-#endif
-    {
-        // ---- phase 2: one lane per compare: the strand against the text on the hit's diagonal --------------------------
-        uint32_t nmems = 0;
+    };
+    // the windows of a round, read after read, 64 to a trip (a ring of window ids in LDS takes what does not fill a trip yet)
+    auto lookups = [&](uint32_t round) {
+        const uint32_t step = round == 0u ? mstep : 1u;
+        uint32_t cnt = 0;
+        for (uint32_t r = 0; r <= nr; r++) {  // (r == nr: what is left in the ring)
+            if (r < nr) {
+                const uint32_t nw = S.nwin[r];
+                const bool pred = lane < nw && (round == 0u ? lmod == 0u : lmod != 0u && ((S.expl[r] >> lane) & 1ull) == 0ull);
+                const unsigned long long pm = __ballot(pred);
+                if (pred) S.ring[cnt + (uint32_t)__popcll(pm & below)] = (uint16_t)((r << 8) | lane);
+                cnt += (uint32_t)__popcll(pm);
+            }
+            if (cnt >= 64u || (r == nr && cnt != 0u)) {
+                wave_sync();
+                const bool act = lane < cnt;
+                const uint32_t ent = act ? S.ring[lane] : 0u;
+                const uint32_t over = lane + 64u < cnt ? S.ring[lane + 64u] : 0u;
+                wave_sync();
+                if (lane + 64u < cnt) S.ring[lane] = (uint16_t)over;
+                cnt = cnt > 64u ? cnt - 64u : 0u;
+                trip(ent, act, step);
+            }
+        }
+        wave_sync();
+    };
+
+    // ---- compares: one lane per job: the strand against the text on the hit's diagonal -------------------------------------
+    auto compares = [&](uint32_t round) {
+        const bool mark = round == 0u && mstep > 1u;
+        const uint32_t ms = mstep * s;
         for (uint32_t jb = 0; jb < njobs; jb += 64u) {
             const bool has = jb + lane < njobs;
             const uint32_t p = has ? S.job_p[jb + lane] : 0u, xx = has ? S.job_x[jb + lane] : 0u;
@@ -2779,6 +2822,13 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 uint4 tu[NU];
 #pragma unroll
                 for (int i = 0; i < NU; i++) tu[i] = T[ui[i]];
+                uint64_t uq[NU];
+#pragma unroll
+                for (int i = 0; i < NU; i++) uq[i] = 0ull;
+                if (mark) {
+#pragma unroll
+                    for (int i = 0; i < NU; i++) uq[i] = ix.tuq[ui[i]];
+                }
                 const uint64_t c0 = ix.tnb[ui[0] >> 6], c3 = ix.tnb[ui[NU - 1] >> 6];
                 uint32_t anyn = 0;
 #pragma unroll
@@ -2818,8 +2868,14 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                     const uint64_t hw = mm[w] & ~bits_range(0, (int)(os + k) - 64 * w);
                     if (hw) b = 64u * w + (uint32_t)__ffsll((unsigned long long)hw) - 1u;
                 }
-                // reported by the window with the smallest forward offset inside the match
-                const bool owner = st ? !(os + s + k <= b) : !(os >= s && os - s >= a);
+                // in forward offsets (the windows are laid out along the forward strand): the run [af, bf), the window at of
+                const uint32_t af = st ? Lj - b : a, bf = st ? Lj - a : b, of = st ? Lj - k - os : os;
+                bool owner;
+                if (round == 0u) owner = !(of >= ms && of - ms >= af);  // the first round-A window inside the run
+                else {
+                    const uint32_t oa = (af + ms - 1u) / ms * ms;       // the first round-A window at or behind af: inside?
+                    owner = !(mstep > 1u && oa + k <= bf) && !(of >= s && of - s >= af);
+                }
                 if (broken) {  // (cannot happen: the table is exact) -- leave the strand to K8
                     atomicOr(&S.flags, 1u << (2u * jr + st));
                     if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 4u, 1ull);
@@ -2841,6 +2897,21 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                         sig = kSigKnown | ((uint32_t)funnel64(l0, h0, sb) & kSigMask) | (((uint32_t)funnel64(l1, h1, sb) & kSigMask) << kSigLetters);
                     }
                 }
+                if (mark && !broken && bf >= af + k) {
+                    // the other windows inside the run whose k-mer occurs once in the text: accounted for
+                    uint64_t uqs[NW];
+#pragma unroll
+                    for (int w = 0; w < (int)NW; w++) uqs[w] = funnel64(uq[w], uq[w + 1], sh);
+                    unsigned long long done = 0ull;
+                    for (uint32_t wi = (af + s - 1u) / s, wl = (bf - k) / s; wi <= wl; wi++) {
+                        const uint32_t x = st ? Lj - k - wi * s : wi * s;  // the window's first letter in the strand
+                        uint64_t word = 0ull;
+#pragma unroll
+                        for (int w = 0; w < (int)NW; w++) word = (x >> 6) == (uint32_t)w ? uqs[w] : word;
+                        if ((word >> (x & 63u)) & 1ull) done |= 1ull << wi;
+                    }
+                    if (done) atomicOr(&S.expl[jr], done);
+                }
             }
             if (kStats) n_cmp += (uint32_t)__popcll(__ballot(has));
             const unsigned long long mb = __ballot(is_mem);
@@ -2851,8 +2922,29 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             }
             nmems += (uint32_t)__popcll(mb);
         }
-        if (nmems > SeedWave<NW>::kMems) nmems = SeedWave<NW>::kMems;
         wave_sync();
+    };
+
+#ifdef SLAMEM_SEED_DIAG_STOP   // (timing experiments only: wrong results) 0: planes only; 1: + round A lookups; 2: + its compares; 3: + round B lookups; 4: + its compares (no ranking)
+#define DIAG_OUT() do { if (lane < nr * strands) alive[r0 * strands + lane] = 0; return; } while (0)
+    if (SLAMEM_SEED_DIAG_STOP == 0) DIAG_OUT();
+    njobs = 0; lookups(0u);
+    if (SLAMEM_SEED_DIAG_STOP == 1) DIAG_OUT();
+    compares(0u);
+    if (SLAMEM_SEED_DIAG_STOP == 2) DIAG_OUT();
+    njobs = 0; lookups(1u);
+    if (SLAMEM_SEED_DIAG_STOP == 3) DIAG_OUT();
+    compares(1u);
+    if (SLAMEM_SEED_DIAG_STOP == 4) DIAG_OUT();
+#else
+    for (uint32_t round = 0; round < (mstep > 1u ? 2u : 1u); round++) {
+        njobs = 0;
+        lookups(round);
+        compares(round);
+    }
+#endif
+    {
+        if (nmems > SeedWave<NW>::kMems) nmems = SeedWave<NW>::kMems;
 
         // ---- phase 3: the strands' MEMs in the reference's emission order ------------------------------------------------
         // rank of a MEM = MEMs of its strand that come before it (greater start, or equal start and greater length; same start
@@ -3418,6 +3510,10 @@ int SearchJob::prep(hipStream_t stream) {
             }
             STEP(hipMemsetAsync(d_counts, 0, nitems * 4, stream), "memset");
             STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
+            {   // (experiments) SLAMEM_SEED_STEP=1|2|3: the stride of the first round's windows (1: one round, every window)
+                const char* v = getenv("SLAMEM_SEED_STEP");
+                A.seed_step = v && atoi(v) >= 1 && atoi(v) <= 3 ? (uint32_t)atoi(v) : 0u;
+            }
             const dim3 gs(grid_for((uint64_t)num_queries, 4 * kSeedReads));
             // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: six)
             const bool long_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLen;

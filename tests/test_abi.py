@@ -115,15 +115,16 @@ def _arena_header(n=100_000, num_n=3, with_filter=True):
     off_tnb = off; off = al(off + (units // 64 + 1) * 8)
     spill_cap = ((n // 16 + 3) & ~3) + 64
     off_spill = off; off = al(off + spill_cap * 8)
+    off_tuq = off; off = al(off + units * 8)
     fields = dict(magic_lo=0x4D414C53, magic_hi=0x58494845, version=13, seed_k=sk, seed_log2=slg, off_seed=off_seed,
-                  off_tpl=off_tpl, off_tnm=off_tnm, off_tnb=off_tnb, off_spill=off_spill, spill_cap=spill_cap, spill_used=8, layout=1, lcp_ge=0, n=n, total_bytes=off, off_fm=off_fm, off_rec=off_rec,
+                  off_tpl=off_tpl, off_tnm=off_tnm, off_tnb=off_tnb, off_spill=off_spill, spill_cap=spill_cap, spill_used=8, off_tuq=off_tuq, layout=1, lcp_ge=0, n=n, total_bytes=off, off_fm=off_fm, off_rec=off_rec,
                   off_sa=off_sa, off_nrows=off_nrows, off_kfilter=off_kf, r0=off_tg, r1=off_pr, r2=off_kj, kjump_k=kj, C=0, kbits_k=kb, z=0, off_kbits=off_kb, kfilter_log2=lg if with_filter else 0,
                   kfilter_k=k if with_filter else 0, nblocks=nblocks, dollar_row=17, num_n=num_n, max_lcp=20, sort_rounds=1)
     order = ["magic_lo", "magic_hi", "version", "n", "total_bytes", "off_fm", "off_rec", "off_sa", "off_nrows", "off_kfilter",
              "r0", "r1", "r2", "kfilter_log2", "kfilter_k", "nblocks", "dollar_row", "num_n", "max_lcp", "sort_rounds",
              "C", "C", "C", "C", "C", "C", "kjump_k", "kbits_k", "z", "off_kbits", "layout"] + ["lcp_ge"] * 10 + [
-             "seed_k", "seed_log2", "z", "off_seed", "off_tpl", "off_tnm", "off_tnb", "off_spill", "spill_cap", "spill_used"]
-    fmt = "<4I9Q7I6III" + "IQ" + "I10I" + "2II4Q" + "Q2I"
+             "seed_k", "seed_log2", "z", "off_seed", "off_tpl", "off_tnm", "off_tnb", "off_spill", "spill_cap", "spill_used", "off_tuq"]
+    fmt = "<4I9Q7I6III" + "IQ" + "I10I" + "2II4Q" + "Q2IQ"
     def pack(**over):
         f = dict(fields); f.update(over)
         return struct.pack(fmt, *[f[k] for k in order]) + b"\0" * (4096 - struct.calcsize(fmt))
@@ -143,7 +144,7 @@ def test_header_validation_rejects_corrupt_arenas(tmp_path):
     assert L.slamem_index_validate_header(pack2(), 4096, f2["total_bytes"]) == 0
     assert L.slamem_index_validate_header(good, len(good), f["total_bytes"] - 1) == ERR_FORMAT       # truncated file
     bad = [dict(magic_lo=1), dict(version=10), dict(version=12), dict(spill_cap=f["spill_cap"] + 4), dict(spill_used=f["spill_cap"] + 1),
-           dict(off_spill=f["total_bytes"] - 64), dict(off_spill=0), dict(seed_k=17), dict(seed_k=3), dict(seed_log2=f["seed_log2"] + 8),
+           dict(off_spill=f["total_bytes"] - 64), dict(off_spill=0), dict(off_tuq=0), dict(off_tuq=f["off_tuq"] + 8), dict(seed_k=17), dict(seed_k=3), dict(seed_log2=f["seed_log2"] + 8),
            dict(seed_log2=9), dict(off_seed=f["off_seed"] + 64), dict(off_tpl=f["off_tnm"]), dict(off_tnm=0), dict(off_tnb=f["total_bytes"]),
            dict(off_seed=0), dict(kbits_k=17), dict(kbits_k=f['kbits_k'] + 1), dict(off_kbits=f['off_kbits'] + 32), dict(kjump_k=13), dict(kjump_k=8), dict(r2=f['r2'] + 64), dict(r0=f['r0'] + 8), dict(r1=f['r1'] + 4096), dict(r0=0), dict(n=0), dict(nblocks=f["nblocks"] - 1), dict(nblocks=f["nblocks"] + 1),
            dict(off_fm=8192), dict(off_rec=f["off_rec"] + 64), dict(off_rec=f["off_fm"]), dict(off_sa=f["total_bytes"]),
@@ -179,7 +180,7 @@ def test_index_build_bytes_is_host_arithmetic():
     c100, pc100 = sizes(100_000_000, capi.LAYOUT_COMPACT)
     f3g, pf3g = sizes(3_100_000_000, capi.LAYOUT_FULL)
     c3g, pc3g = sizes(3_100_000_000, capi.LAYOUT_COMPACT)
-    assert abs(f100 - 8.2669e9) < 2e7 and abs(c100 - 3.2580e9) < 2e7
+    assert abs(f100 - 8.2794e9) < 2e7 and abs(c100 - 3.2580e9) < 2e7
     assert abs(f3g - 150.744e9) < 1e8 and abs(c3g - 80.864e9) < 1e8
     for arena, peak in ((f100, pf100), (c100, pc100), (f3g, pf3g), (c3g, pc3g)):
         assert arena < peak < arena + 40 * 3_100_000_001

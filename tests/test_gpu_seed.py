@@ -390,6 +390,6 @@ def test_full_size_headline_both_paths_agree_in_order(eng):
     assert torch.equal(seed_off, m.block_offsets) and torch.equal(seed_mems, m.mems[:total])
     with search_path("seed"):
         st = eng.search_stats(m, reads, offsets, 20)
-    assert st["seed_reads"] == nreads and st["seed_windows"] == 27 * nreads and st["seed_strands_left"] < 1000, st["seed_left_why"]
+    assert st["seed_reads"] == nreads and 8 * nreads <= st["seed_windows"] <= 27 * nreads and st["seed_strands_left"] < 1000, st["seed_left_why"]
     assert st["survivors"] <= st["seed_strands_left"]
     idx.close()
