@@ -2471,7 +2471,10 @@ constexpr uint32_t kSeedReads = SLAMEM_SEED_READS;     // reads of a wave (at mo
 constexpr uint32_t kSeedMaxLen = 192;   // letters of a strand the planes hold in the instantiation for reads of up to 192 letters (three words)
 constexpr uint32_t kSeedMaxLenLong = 384;  // ... and in the one for longer reads (six words: 2 x 250 bp runs; a batch takes it when its reads average more than 192)
 constexpr uint32_t kSeedJobs = 256;     // compares of one wave
-constexpr uint32_t kSeedMems = 192;     // MEMs of one wave
+#ifndef SLAMEM_SEED_MEMS
+#define SLAMEM_SEED_MEMS 192
+#endif
+constexpr uint32_t kSeedMems = SLAMEM_SEED_MEMS;     // MEMs of one wave
 constexpr uint32_t kSigLetters = 12, kSigMask = (1u << kSigLetters) - 1u, kSigKnown = 1u << 24;  // text letters kept behind a MEM (ties, phase 3)
 
 template <uint32_t NW>  // plane words of a strand (64 letters each)
@@ -2494,7 +2497,10 @@ struct SeedWave {
     };
     uint32_t bad[kSeedReads];           // the read holds a letter that is not A,C,G,T
     unsigned long long expl[kSeedReads];  // bit per window of a read: its only occurrence in the text is accounted for (round A)
-    uint16_t ring[128];                 // window ids (read << 8 | window) waiting for a full trip
+    union {
+        uint16_t ring[128];             // window ids (read << 8 | window) waiting for a full trip
+        unsigned long long smask[32];   // ... later: per strand, which MEMs of the wave's list are its own
+    };
     uint32_t flags;                     // bit 2 * read + strand: the strand is left to K8
     uint32_t pad[3];
 };
@@ -2507,12 +2513,11 @@ __device__ __forceinline__ void wave_sync() {
 // bits [sh, sh + 64) of the 128-bit value hi:lo (sh in 0..63)
 __device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t sh) { return (lo >> sh) | ((hi << 1) << (63u - sh)); }
 // the bits [lo, hi) of a word (any integers; clamped to 0..64)
-__device__ __forceinline__ uint64_t bits_range(int lo, int hi) {
-    lo = lo < 0 ? 0 : lo > 64 ? 64 : lo;
-    hi = hi < 0 ? 0 : hi > 64 ? 64 : hi;
-    const uint64_t a = hi >= 64 ? ~0ull : (1ull << hi) - 1ull, b = lo >= 64 ? ~0ull : (1ull << lo) - 1ull;
-    return a & ~b;
+__device__ __forceinline__ uint64_t bits_below(int x) {  // the bits [0, x)
+    const int c = x < 0 ? 0 : x > 64 ? 64 : x;
+    return c == 0 ? 0ull : (~0ull >> (64 - c));
 }
+__device__ __forceinline__ uint64_t bits_range(int lo, int hi) { return bits_below(hi) & ~bits_below(lo); }
 __device__ __forceinline__ uint32_t sel4(const uint4& v, uint32_t a) {
     const uint32_t lo = (a & 1u) ? v.y : v.x, hi = (a & 1u) ? v.w : v.z;
     return (a & 2u) ? hi : lo;
@@ -2715,23 +2720,22 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         if (kStats && both && hits) atomicAdd(A.stats + SC_SEED_WHY + 2u, 1ull);  // (counted, no longer a reason to leave the read)
         // Every hit is a compare -- except one whose neighbour (the lane before: the window `step` windows earlier in the forward
         // strand of the same read) hit the same diagonal while the two windows overlap or touch: they lie in the same match and
-        // that window, or one before it, reports the MEM.  (The neighbour's first two hits are looked at; a hit this misses is
+        // that window, or one before it, reports the MEM.  (The neighbour's first hit is looked at; a hit this misses is
         // sorted out by its compare.)
-        const uint32_t nm = (uint32_t)__popc(hits);
-        const uint32_t e1 = nm ? (uint32_t)__ffs((int)hits) - 1u : 0u, h2 = hits & (hits - 1u), e2 = nm > 1u ? (uint32_t)__ffs((int)h2) - 1u : 0u;
-        const uint32_t p1 = sel12(b0, b1, b2, e1), p2 = sel12(b0, b1, b2, e2);
-        const uint32_t st1 = (rev >> e1) & 1u, st2 = (rev >> e2) & 1u;
+        const uint32_t e1 = hits ? (uint32_t)__ffs((int)hits) - 1u : 0u;
+        const uint32_t p1 = sel12(b0, b1, b2, e1);
+        const uint32_t st1 = (rev >> e1) & 1u;
         const uint32_t dist = step * s;  // letters between the neighbour's window and this one
-        uint32_t pn = 0, pp1 = 0, pp2 = 0, ps1 = 0, ps2 = 0;
+        uint32_t pn = 0, pp1 = 0;  // the neighbour's first hit: (position << 1 | strand) + 1, or 0
         if (dist <= k) {
-            pn = __shfl_up(nm, 1); pp1 = __shfl_up(p1, 1); pp2 = __shfl_up(p2, 1); ps1 = __shfl_up(st1, 1); ps2 = __shfl_up(st2, 1);
+            pp1 = __shfl_up(hits ? ((p1 << 1) | st1) : 0xFFFFFFFFu, 1);
             const uint32_t pent = __shfl_up(act ? ent : 0xFFFFFFFFu, 1);
-            if (lane == 0u || wi < step || pent != ent - step) pn = 0;
+            pn = (lane == 0u || wi < step || pent != ent - step || pp1 == 0xFFFFFFFFu) ? 0u : 1u;
         }
         const uint32_t njobs0 = njobs;
         auto push = [&](bool hv, uint32_t p, uint32_t st) {
             const uint32_t w = st ? p + dist : p - dist;
-            const bool job = hv && !((pn >= 1u && ps1 == st && pp1 == w) || (pn >= 2u && ps2 == st && pp2 == w));
+            const bool job = hv && !(pn && pp1 == ((w << 1) | st));
             const unsigned long long qb = __ballot(job);
             const uint32_t at = njobs + (uint32_t)__popcll(qb & below);
             if (job && at < SeedWave<NW>::kJobs) {
@@ -2743,9 +2747,9 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         uint32_t rem = hits;
         for (uint32_t it = 0; __ballot(rem != 0u) != 0ull; it++) {
             const bool hv = rem != 0u;
-            const uint32_t e = it == 0u ? e1 : it == 1u ? e2 : hv ? (uint32_t)__ffs((int)rem) - 1u : 0u;
+            const uint32_t e = it == 0u ? e1 : hv ? (uint32_t)__ffs((int)rem) - 1u : 0u;
             rem &= rem - 1u;
-            const uint32_t p = it == 0u ? p1 : it == 1u ? p2 : sel12(b0, b1, b2, e);
+            const uint32_t p = it == 0u ? p1 : sel12(b0, b1, b2, e);
             push(hv, p, (rev >> e) & 1u);
             if (__ballot(hv && both) != 0ull) push(hv && both, p, 1u);
         }
@@ -3007,9 +3011,21 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         if (nmems <= 64u) {  // the usual case: one MEM per lane, one loop
             const bool has = lane < nmems;
             const uint32_t key = has ? S.mem_key[lane] : 0u, ref = has ? S.mem_ref[lane] : 0u, g = has ? S.mem_sig[lane] >> 25 : 0xFFFFFFFFu;
-            uint32_t rank, cnt;
-            bool tie;
-            rank_of(lane, key, g, rank, cnt, tie);
+            // the MEMs of a strand find each other through a mask per strand (a strand has a few, the wave's list some forty)
+            if (lane < 32u) S.smask[lane] = 0ull;
+            wave_sync();
+            if (has) atomicOr(&S.smask[g], 1ull << lane);
+            wave_sync();
+            const unsigned long long mine = has ? S.smask[g] : 0ull;
+            uint32_t rank = 0;
+            const uint32_t cnt = (uint32_t)__popcll(mine);
+            bool tie = false;
+            for (unsigned long long o = mine & ~(1ull << lane); __ballot(o != 0ull) != 0ull; o &= o - 1ull) {
+                if (o == 0ull) continue;
+                const uint32_t kk = S.mem_key[__ffsll(o) - 1];
+                rank += kk > key ? 1u : 0u;
+                tie = tie || kk == key;
+            }
             if (has && tie && tie_rank(lane, key, g, S.mem_sig[lane], rank)) {
                 atomicOr(&S.flags, 1u << g);
                 if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 6u, 1ull);

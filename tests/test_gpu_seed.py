@@ -339,6 +339,51 @@ def test_buckets_with_more_than_twelve_kmers(eng, copies, left):
     assert len(om) > 40 * copies
 
 
+@pytest.mark.parametrize("l", [19, 20, 23, 28])
+def test_one_round_and_two_rounds_of_lookups_agree(eng, l, monkeypatch):
+    """The windows of a read are looked up in two rounds when they lie close (every third / second window first; a window inside
+    a run that a first-round compare measured, whose k-mer occurs once in the text, not at all): the same MEMs in the same order
+    as with every window looked up in one round (SLAMEM_SEED_STEP=1), on a text with exact and diverged copies (k-mers that
+    occur once next to k-mers that do not), reads with 0-6 % substitutions, every read length from l to 192."""
+    rng = np.random.default_rng(41 + l)
+    n = 500_000  # seed_k = 12
+    t = rng.choice(ACGT, size=n)
+    for copies, length, div in [(2, 500, 0.0), (3, 300, 0.03), (6, 150, 0.01), (2, 2000, 0.002), (10, 60, 0.0)]:
+        x = int(rng.integers(0, n - length))
+        seg = t[x:x + length].copy()
+        for _ in range(copies - 1):
+            y = int(rng.integers(0, n - length))
+            t[y:y + length] = mutate(rng, seg, div) if div else seg
+    qs = []
+    for sub in (0.0, 0.02, 0.06):
+        qs += reads_from(rng, t, 700, 150, sub)
+    for length in range(l, 193, 3):
+        qs += reads_from(rng, t, 4, length, 0.02)
+    from oracle import pyoracle as po
+    q, off = pack(qs)
+    om, obc = po.OracleIndex(t.tobytes()).match_batch(q, off, l, True)
+    g = eng.Index.build(t.tobytes())
+    try:
+        assert l >= g.info.seed_k + 3
+        lookups = {}
+        for step in ("1", "2", "3", ""):
+            if step:
+                monkeypatch.setenv("SLAMEM_SEED_STEP", step)
+            else:
+                monkeypatch.delenv("SLAMEM_SEED_STEP")
+            gm, goff = g.find_mems(q, off, l, True)
+            assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64)), step
+            for f in ("ref_pos", "query_pos", "length"):
+                assert np.array_equal(gm[f], om[f]), (step, f)
+            st = seed_stats(eng, g, q, off, l, True)
+            assert st["seed_reads"] == len(qs) and st["mems"] == len(om)
+            lookups[step] = st["seed_windows"]
+        assert lookups["2"] < lookups["1"] and lookups["3"] < lookups["1"]  # (fewer lines to fetch is the point)
+        assert lookups[""] <= lookups["1"]
+    finally:
+        g.close()
+
+
 def test_satellite_fills_its_buckets(eng):
     """A tandem array (one unit 2,000 times) puts thousands of positions into the buckets of its k-mers (count 13 = more than
     fit): reads from it, and reads that merely share one window with it, are left to the index walk; the others are not."""
