@@ -142,18 +142,20 @@ typedef struct {
     uint64_t state_lane_trips[11];
     uint64_t state_wave_trips[11];
     /* K8s (ABI 4): seed-and-compare for reads */
-    uint64_t seed_windows;          /* K8s: seed-table lines fetched (one 64-byte line per window, both strands of a read share it)   */
+    uint64_t seed_windows;          /* K8s: seed-table lines fetched (one 64-byte line per window looked up; both strands share it)    */
     uint64_t seed_compares;         /* K8s: diagonals compared with the text (four 16-byte units of the text bit-planes each)         */
     uint64_t seed_letter_masks;     /* K8s: compares that also read the text's "not A,C,G,T" masks (four 8-byte words)                */
     uint64_t seed_mems;             /* K8s: MEMs it reported                                                                          */
     uint64_t seed_strands_left;     /* K8s: strands left to the index walk (K8)                                                       */
     uint64_t seed_reads;            /* K8s: reads screened                                                                            */
     uint64_t seed_query_bytes;      /* K8s: bytes of the reads it packed                                                              */
-    /* K8s: events that left a read / strand to K8: [0] reads left before any lookup (longer than the kernel's strands, a letter
-     * that is not A,C,G,T; also the reads of a wave whose compares did not fit), [1] windows whose bucket holds more k-mers than
-     * it has slots, [2] palindromic windows that hit, [3] waves whose compares did not fit, [4] inconsistent hits (never),
-     * [5] MEMs beyond the wave's list, [6] MEMs that tie with another of their strand (same start, same length)               */
+    /* K8s: events counted on the way: [0] reads left to K8 before any lookup (longer than the kernel's strands, a letter that is
+     * not A,C,G,T; also the reads of a wave whose compares did not fit), [1] windows whose bucket holds more k-mers than the
+     * table keeps (28), [2] palindromic windows that hit (compared on both strands: not left), [3] trips whose compares did not
+     * fit, [4] inconsistent hits (never), [5] MEMs beyond the wave's list, [6] MEMs whose tie with another of their strand (same
+     * start, same length) the text behind them does not decide                                                                  */
     uint64_t seed_left_why[7];
+    uint64_t seed_once_reads;       /* K8s: compares that also read the text's occurs-once plane (four 8-byte words)                 */
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

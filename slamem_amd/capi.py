@@ -90,7 +90,7 @@ class SearchStats(C.Structure):
         "enum_row_steps", "enum_levels", "enum_wave_us")] + [("state_lane_trips", C.c_uint64 * 11),
                                                                ("state_wave_trips", C.c_uint64 * 11)] + [
         (k, C.c_uint64) for k in ("seed_windows", "seed_compares", "seed_letter_masks", "seed_mems", "seed_strands_left",
-                                  "seed_reads", "seed_query_bytes")] + [("seed_left_why", C.c_uint64 * 7)]
+                                  "seed_reads", "seed_query_bytes")] + [("seed_left_why", C.c_uint64 * 7), ("seed_once_reads", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if (k.startswith("state_") or k == "seed_left_why") else int(getattr(self, k))) for k, _ in self._fields_}

@@ -187,6 +187,7 @@ struct SearchArgs {
     uint64_t query_words;       // v3: 8-byte words of the query buffer that may be read
     const uint64_t* pq;         // v3: the strands as packed letter ids (k_pack_queries), two zero words in front
     uint64_t* pq_out;           //     (the same buffer, written by k_pack_queries)
+    uint32_t implicit_items;    // v3: 1: no item tables (item_of / item_pk_of)
     uint32_t seed_step;         // K8s: 0, or the stride of the windows of the first round (experiments: SLAMEM_SEED_STEP)
     const uint64_t* item_pk;    // v3: per work item, the word offset of its strand block in pq
     unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
@@ -255,6 +256,22 @@ struct __attribute__((aligned(16))) ItemDesc {
     uint32_t len;        // its length
     uint32_t slice_rev;  // slice index | reverse strand << 31
 };
+// Implicit items (SearchArgs::implicit_items; a batch of reads on the seed path: no record is cut into slices, item g IS strand
+// block g): the descriptor and the strand's place in the packed copy come from the offsets -- the two tables of 24 bytes per
+// strand that k_item_fill writes (and the scan behind the second) are not made for the few strands K8s leaves.  The place:
+// read q's blocks start at 2 + strands * 2 * (offset / 32 + q) words -- at or behind where the blocks before it end
+// (a strand takes 2 * ceil(len / 32) words), within the pq_bytes the work space reserves.
+__device__ __forceinline__ ItemDesc item_of(const SearchArgs& A, uint64_t it) {
+    if (!A.implicit_items) return A.items[it];
+    const uint64_t q = A.strands == 2u ? it >> 1 : it;
+    const uint64_t o0 = A.offsets[q];
+    return ItemDesc{o0, (uint32_t)(A.offsets[q + 1] - o0), A.strands == 2u ? (uint32_t)(it & 1ull) << 31 : 0u};
+}
+__device__ __forceinline__ uint64_t item_pk_of(const SearchArgs& A, uint64_t it, const ItemDesc& d) {
+    if (!A.implicit_items) return A.item_pk[it];
+    const uint64_t q = A.strands == 2u ? it >> 1 : it;
+    return 2ull + (uint64_t)A.strands * 2ull * ((d.base >> 5) + q) + (uint64_t)(d.slice_rev >> 31) * 2ull * ((d.len + 31u) >> 5);
+}
 
 // Letters of one strand of a query record, read through a window of kBytes (16 or 32) held in registers: aligned
 // 16-byte loads, 5-10 per strand of 150 letters.  (With 8-byte words, a word per 8 letters, the line was fetched
@@ -1197,7 +1214,7 @@ enum : uint32_t {
     SC_WAVE_TRIPS, SC_POSITIONS, SC_ENUM_JOBS, SC_ENUM_ROW_STEPS, SC_PF_PROBES, SC_PF_QUERY_LOADS, SC_PF_ITEMS,
     SC_DIR_SA, SC_DIR_GROUPS, SC_DIR_RECS, SC_DIR_QLOADS, SC_DIR_LETTERS, SC_JUMP_LINES,
     SC_SKIP_GROUPS, SC_SKIP_QLOADS, SC_SKIP_PROBES, SC_SKIP_OK, SC_T_FIRST, SC_T_DRAIN, SC_T_LAST, SC_T_WAVE_SUM, SC_ENUM_LEVELS, SC_T_ENUM_SUM, SC_STATE_TRIPS /* 11 words: lane trips per state */, SC_STATE_WAVES = SC_STATE_TRIPS + 11 /* 11 words: wave trips in which some lane is in the state */,
-    SC_SEED_WINDOWS = SC_STATE_WAVES + 11, SC_SEED_COMPARES, SC_SEED_NMASKS, SC_SEED_MEMS, SC_SEED_LEFT, SC_SEED_READS, SC_SEED_QBYTES, SC_SEED_WHY /* 7 words: why a read / strand was left */, SC_COUNT = SC_SEED_WHY + 7
+    SC_SEED_WINDOWS = SC_STATE_WAVES + 11, SC_SEED_COMPARES, SC_SEED_NMASKS, SC_SEED_MEMS, SC_SEED_LEFT, SC_SEED_READS, SC_SEED_QBYTES, SC_SEED_WHY /* 7 words: why a read / strand was left */, SC_SEED_ONCE = SC_SEED_WHY + 7, SC_COUNT
 };
 template <bool kStats>
 __device__ __forceinline__ void stat_flush(unsigned long long* dst, uint32_t v) {
@@ -1233,11 +1250,15 @@ __global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A, bool long_on
     const uint64_t item = (!long_only && A.work_ids) ? (uint64_t)A.work_ids[e] : e;
     // the descriptor and the strand's place in the packed copy in ONE round trip (as a struct load the length came first,
     // for the test below, and the rest a round trip later: five dependent memory phases per item, now three)
-    uint4 dv = *reinterpret_cast<const uint4*>(A.items + item);
-    uint64_t pk_word = A.item_pk[item];
-    asm volatile("" : "+v"(dv.x), "+v"(dv.y), "+v"(dv.z), "+v"(dv.w), "+v"(pk_word));
     ItemDesc d;
-    d.base = u64_of(dv.x, dv.y); d.len = dv.z; d.slice_rev = dv.w;
+    uint64_t pk_word;
+    if (A.implicit_items) { d = item_of(A, item); pk_word = item_pk_of(A, item, d); }
+    else {
+        uint4 dv = *reinterpret_cast<const uint4*>(A.items + item);
+        pk_word = A.item_pk[item];
+        asm volatile("" : "+v"(dv.x), "+v"(dv.y), "+v"(dv.z), "+v"(dv.w), "+v"(pk_word));
+        d.base = u64_of(dv.x, dv.y); d.len = dv.z; d.slice_rev = dv.w;
+    }
     if (long_only != (d.len > kSliceLen)) continue;
     const uint32_t rev = d.slice_rev >> 31, sl = d.slice_rev & 0x7FFFFFFFu;
     const uint32_t a = sl * kSliceLen;
@@ -1492,8 +1513,9 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                 if (i < chunk_end) {  // descriptors -> LDS: one coalesced read per wave instead of a round trip per item
                     uint32_t id = A.work_ids ? A.work_ids[i] : (uint32_t)i;
                     lds_id[wv][lane] = id;
-                    lds_item[wv][lane] = A.items[id];
-                    lds_pk[wv][lane] = A.item_pk[id];
+                    const ItemDesc idesc = item_of(A, id);
+                    lds_item[wv][lane] = idesc;
+                    lds_pk[wv][lane] = item_pk_of(A, id, idesc);
                 }
                 // written and read by lanes of this wave only
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2434,7 +2456,7 @@ __global__ void __launch_bounds__(256) k_prefilter_list(SearchArgs A, const uint
     const uint32_t count = *list_count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         const uint32_t g = list[i];
-        const ItemDesc d = A.items[g];
+        const ItemDesc d = item_of(A, g);
         uint32_t n_probe = 0, n_qload = 0;
         if (!prefilter_item<false>(A, d, n_probe, n_qload)) alive[g] = 0;
     }
@@ -2917,7 +2939,11 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                     if (done) atomicOr(&S.expl[jr], done);
                 }
             }
-            if (kStats) n_cmp += (uint32_t)__popcll(__ballot(has));
+            if (kStats) {
+                const uint32_t nh = (uint32_t)__popcll(__ballot(has));
+                n_cmp += nh;
+                if (mark && lane == 0u) atomicAdd(A.stats + SC_SEED_ONCE, (unsigned long long)nh);
+            }
             const unsigned long long mb = __ballot(is_mem);
             if (is_mem) {
                 const uint32_t at = nmems + (uint32_t)__popcll(mb & below);
@@ -3330,6 +3356,7 @@ struct SearchJob {
     bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
     bool rawkey_marked = false;  // the overflow list already carries its "unused" marks (kChunk)
     bool deferred = false;       // this launch ran K8's kDefer instantiation: k_enum_jobs and k_defer_prefix follow
+    bool seed_path = false;  // tables(): this batch takes the seed path
     bool seeded = false;  // this batch's MEMs come from K8s (k_seed_mems); K8 scans only the strands it left
     bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
     unsigned long long scal_own[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -3428,12 +3455,20 @@ int SearchJob::tables(hipStream_t stream) {
     uint32_t slices = slices_hint;
     const bool ask = slices_hint == 0xFFFFFFFFu;
     if (ask) STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
-    {   // packed strands: offsets of the strand blocks
+    if (ask) STEP(hipStreamSynchronize(stream), "item count (sync)");
+    nitems = (uint64_t)slices * strands;
+    {   // reads (no record was cut into slices, none longer on average than the seed kernel's strands), -mem, a minimum length
+        // that leaves at least four letters between two windows: K8s finds the MEMs by seed-and-compare and leaves to K8
+        // only the strands it cannot decide (SLAMEM_SEED_SEARCH=0: the prefilter and the index walk for everything)
+        // (read per call, not once per process: the tests run both paths in one process)
+        const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
+        seed_path = use_seed && match_type == 0 && nitems == num_blocks && idx->view.seed && min_len >= idx->view.seed_k + 3u &&
+                    min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLenLong;
+    }
+    if (!seed_path) {   // packed strands: offsets of the strand blocks (a batch on the seed path: item_pk_of)
         size_t need3 = w.scan_bytes;
         STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need3, d_wps, d_wscan, (uint64_t)num_queries, stream), "scan");
     }
-    if (ask) STEP(hipStreamSynchronize(stream), "item count (sync)");
-    nitems = (uint64_t)slices * strands;
     {   // -mam: reads go through K8 (kMam); batches with a record longer than a slice through k_find_mams_sliced
         static const bool env_v3 = [] { const char* v = getenv("SLAMEM_MAM_V3"); return !(v && atoi(v) == 0); }();
         mam_v3 = match_type == 1 && nitems == num_blocks && !mam_whole_strands() && env_v3;
@@ -3461,14 +3496,19 @@ int SearchJob::tables(hipStream_t stream) {
     if (nitems && (match_type != 1 || mam_v3)) {
         uint64_t* d_itempk = reinterpret_cast<uint64_t*>(ws + w.off_itempk);
         uint64_t* d_pq = reinterpret_cast<uint64_t*>(ws + w.off_pq);
-        hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
-                           num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk,
-                           nitems != num_blocks ? reinterpret_cast<uint32_t*>(ws + w.off_itemblock) : (uint32_t*)nullptr);
-        STEP(hipGetLastError(), "k_item_fill");
+        if (seed_path) {  // no item tables: K8, its packer and the list prefilter take a strand's descriptor from the offsets
+            A.implicit_items = 1u;
+            A.items = nullptr;
+        } else {
+            hipLaunchKernelGGL(k_item_fill, dim3(grid_for(num_queries)), dim3(256), 0, stream, offsets_dev, d_first, d_wscan,
+                               num_queries, strands, reinterpret_cast<ItemDesc*>(ws + w.off_items), d_itempk,
+                               nitems != num_blocks ? reinterpret_cast<uint32_t*>(ws + w.off_itemblock) : (uint32_t*)nullptr);
+            STEP(hipGetLastError(), "k_item_fill");
+        }
         STEP(hipMemsetAsync(d_pq, 0, 16, stream), "memset");  // the two leading zero words
         A.pq = d_pq;
         A.pq_out = d_pq;
-        A.item_pk = d_itempk;
+        A.item_pk = seed_path ? nullptr : d_itempk;
         // direct extension of single-row matches: on when the index has the text-ordered sections and the class
         // threshold can discriminate (min_len >= 8); entry depth = where chance matches stop, log4(n) + 3
         static const int env_depth = [] { const char* v = getenv("SLAMEM_DIRECT_DEPTH"); return v ? atoi(v) : 0; }();
@@ -3509,13 +3549,7 @@ int SearchJob::prep(hipStream_t stream) {
     (void)hipEventRecord(ev[0], stream);
     if (nitems && (match_type != 1 || mam_v3)) {
         static const bool use_filter = [] { const char* v = getenv("SLAMEM_KFILTER"); return !(v && atoi(v) == 0); }();
-        // reads (no record was cut into slices, none longer on average than the seed kernel's strands), -mem, a minimum length
-        // that leaves at least four letters between two windows: K8s finds the MEMs by seed-and-compare and leaves to K8
-        // only the strands it cannot decide (SLAMEM_SEED_SEARCH=0: the prefilter and the index walk for everything)
-        // (read per call, not once per process: the tests run both paths in one process)
-        const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
-        seeded = use_seed && match_type == 0 && nitems == num_blocks && idx->view.seed && min_len >= idx->view.seed_k + 3u &&
-                 min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLenLong;
+        seeded = seed_path;  // (decided in tables(), which makes no item tables for such a batch)
         if (seeded) {
             uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
             // (K8's kChunk instantiation wants every place of the overflow list marked "unused" before the launch: K8s puts
@@ -3887,6 +3921,7 @@ int SearchJob::collect() {
         o.seed_mems = c[SC_SEED_MEMS]; o.seed_strands_left = c[SC_SEED_LEFT]; o.seed_reads = c[SC_SEED_READS];
         o.seed_query_bytes = c[SC_SEED_QBYTES];
         for (int q = 0; q < 7; q++) o.seed_left_why[q] = c[SC_SEED_WHY + q];
+        o.seed_once_reads = c[SC_SEED_ONCE];
         o.items = nitems;
         o.survivors = prefiltered ? nwork : nitems;
         o.mems = total;
