@@ -24,8 +24,7 @@ Rank 0 prints ONE JSON line.
   roofline      the dominant kernel (K8s k_seed_mems since round 4; K8 k_find_mems_v3 when the batch does not take the seed
                 path): `traffic` = bytes the kernel's lanes asked the memory system for, counted by the kernel's
                 diagnostic instantiation on the same batch in this run (K8s: 64 B per seed-table line = one per window looked up,
-                80 B per compare = four 16-byte units of the text bit-planes + two words of the unit mask, 32 B more
-                for a first-round compare = its words of the occurs-once plane, the reads'
+                128 B per compare = four 32-byte units of the text (bit-planes, letter mask, occurs-once plane), the reads'
                 own bytes, 12 B per MEM written, 5 B of flags / counts per strand); `achieved` = traffic / the kernel's
                 mean duration (HIP events on its stream); `frac` = achieved / 8 TB/s.  `request_rate_frac` = 64-byte
                 lines/s over a dependent-random-line ceiling measured in this process on this index arena.  The SURVEY
@@ -357,16 +356,15 @@ def main():
             # K8s: one seed-table line per window, four text units + two unit-mask words per compare (+ four letter-mask words for
             # the few whose units hold a letter that is not A,C,G,T), the reads' bytes once, 12 B per MEM and 5 B per strand out
             s_s = r["seed_ms"] * 1e-3
-            s_bytes = (64 * st["seed_windows"] + 80 * st["seed_compares"] + 32 * st["seed_letter_masks"] + 32 * st.get("seed_once_reads", 0)
-                       + st["seed_query_bytes"] + 12 * st["seed_mems"] + 5 * st["items"])
-            s_lines = st["seed_windows"] + st["seed_compares"] + st.get("seed_once_reads", 0) + st["seed_query_bytes"] // 64
+            s_bytes = (64 * st["seed_windows"] + 128 * st["seed_compares"] + st["seed_query_bytes"] + 12 * st["seed_mems"] + 5 * st["items"])
+            s_lines = st["seed_windows"] + 2 * st["seed_compares"] + st["seed_query_bytes"] // 64
             achieved = s_bytes / s_s / 1e9
             out["roofline"] = {
                 "bound": "hbm", "kernel": "k_seed_mems", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": s_bytes,
                 "traffic_source": "counters of the kernel's diagnostic instantiation on this batch (this run): 64 B per window looked "
-                                  "up (seed-table line), 80 B per compare (text bit-planes) + 32 B for a first-round compare "
-                                  "(occurs-once plane), the reads' bytes, 12 B per MEM, 5 B per strand; cross-check against "
+                                  "up (seed-table line), 128 B per compare (four 32-byte text units: planes, letter mask, "
+                                  "occurs-once plane), the reads' bytes, 12 B per MEM, 5 B per strand; cross-check against "
                                   "rocprofv3 FETCH_SIZE + WRITE_SIZE in profiles/",
                 "bound_note": "the kernel is bound by vector-instruction issue and by the fabric's line-request rate at once "
                               "(profiles/: SQ_INSTS_VALU x 4 cycles / 1,024 SIMDs and TCC_EA0_RDREQ / time); frac is bytes over the "

@@ -71,7 +71,7 @@ typedef struct {
 /* Index layouts (no reference counterpart: the reference has one layout of 3.3 B per letter made for CPU caches,
  * bwtindex.c:33-37 + lcparray.c:46-57; here HBM is spent to cut dependent random reads).
  *   FULL     every section: ~37.5 B per text letter + 16-32 B of presence filter, and for texts below 2^28 letters 16-32 B of
- *            seed table + the text's bit-planes (the seed-and-compare search of reads, ABI 4): 8.2 GB at 100 Mbp, 151 GB at 3.1 Gbp
+ *            seed table (+ spill list) + the text's bit-planes and occurs-once plane (the seed-and-compare search of reads, ABI 4): 8.3 GB at 100 Mbp, 151 GB at 3.1 Gbp
  *   COMPACT  no text-ordered sections (the search walks the index where it would have compared with the text) and a
  *            presence filter of half the size: ~21.5 B per letter + 8-16 B (3.3 GB at 100 Mbp, 81 GB at 3.1 Gbp); same
  *            results, slower search (DESIGN.md 2 has the measured cost)
@@ -143,8 +143,8 @@ typedef struct {
     uint64_t state_wave_trips[11];
     /* K8s (ABI 4): seed-and-compare for reads */
     uint64_t seed_windows;          /* K8s: seed-table lines fetched (one 64-byte line per window looked up; both strands share it)    */
-    uint64_t seed_compares;         /* K8s: diagonals compared with the text (four 16-byte units of the text bit-planes each)         */
-    uint64_t seed_letter_masks;     /* K8s: compares that also read the text's "not A,C,G,T" masks (four 8-byte words)                */
+    uint64_t seed_compares;         /* K8s: diagonals compared with the text (four 32-byte units of the text each: 128 bytes)          */
+    uint64_t seed_letter_masks;     /* K8s: compares whose text units hold a letter that is not A,C,G,T                               */
     uint64_t seed_mems;             /* K8s: MEMs it reported                                                                          */
     uint64_t seed_strands_left;     /* K8s: strands left to the index walk (K8)                                                       */
     uint64_t seed_reads;            /* K8s: reads screened                                                                            */
@@ -155,7 +155,7 @@ typedef struct {
      * fit, [4] inconsistent hits (never), [5] MEMs beyond the wave's list, [6] MEMs whose tie with another of their strand (same
      * start, same length) the text behind them does not decide                                                                  */
     uint64_t seed_left_why[7];
-    uint64_t seed_once_reads;       /* K8s: compares that also read the text's occurs-once plane (four 8-byte words)                 */
+    uint64_t seed_once_reads;       /* K8s: compares of the first round (they also look at the occurs-once plane of their units)    */
 } slamem_search_stats;
 
 /* ---- library ---------------------------------------------------------- */

@@ -101,18 +101,16 @@ static int header_ok(const ArenaHeader& h, uint64_t bytes) {
         if (!bad && (h.kbits_k < 8 || h.kbits_k > 16)) bad = "occurrence bitmap k";
         if (!bad) section(h.off_kbits, (1ull << (2u * h.kbits_k)) >> 3, "occurrence bitmap");
     }
-    if (h.off_seed || h.off_tpl || h.off_tnm || h.off_tnb || h.off_spill || h.off_tuq) {
+    if (h.off_seed || h.off_tpl || h.off_spill) {
         const uint64_t units = text_units(h.n);
         if (!bad && (h.seed_k < 4 || h.seed_k > 16 || h.seed_log2 < 10 || h.seed_log2 > 30 || 2u * h.seed_k < h.seed_log2 ||
                      2u * h.seed_k - h.seed_log2 > 7u)) bad = "seed table parameters";
         if (!bad) section(h.off_seed, sizeof(SeedBucket) << h.seed_log2, "seed table");
-        section(h.off_tpl, units * sizeof(TextPlanes), "text bit-planes");
-        section(h.off_tnm, units * 8, "text letter mask");
-        section(h.off_tnb, (units / 64 + 1) * 8, "text unit mask");
+        section(h.off_tpl, units * sizeof(TextPlanes), "text units");
         if (!bad && (h.spill_cap != seed_spill_entries(h.n) || h.spill_used > h.spill_cap)) bad = "seed spill list size";
         section(h.off_spill, (uint64_t)h.spill_cap * 8, "seed spill list");
-        section(h.off_tuq, units * 8, "text occurs-once plane");
     }
+    if (!bad && (h.off_tnm || h.off_tnb || h.off_tuq)) bad = "reserved section offsets";
     if (!bad && h.dollar_row > h.n) bad = "'$' row";
     if (bad) {
         set_error("index arena is corrupt or truncated: bad %s", bad);

@@ -102,15 +102,14 @@ struct ArenaHeader {
     uint32_t seed_k;      // letters of a seed (<= 16)
     uint32_t seed_log2;   // log2 of the number of buckets of the seed table
     uint64_t off_seed;    // SeedBucket[1 << seed_log2]   every k-mer of the text over A,C,G,T by its canonical form
-    uint64_t off_tpl;     // TextPlanes[text_units(n)]    the text as two bit-planes, 64 letters per 16 bytes
-    uint64_t off_tnm;     // uint64[text_units(n)]        bit per letter: not one of A,C,G,T
-    uint64_t off_tnb;     // uint64[text_units(n)/64 + 1] bit per 64-letter unit: it holds such a letter
+    uint64_t off_tpl;     // TextPlanes[text_units(n)]    the text in units of 64 letters: two bit-planes, the letter mask, the occurs-once plane
+    uint64_t off_tnm;     // 0 (version 12 kept the letter mask here; it lies in the units now)
+    uint64_t off_tnb;     // 0 (version 12: a bit per unit "holds a letter that is not A,C,G,T")
     // (version 13)
     uint64_t off_spill;   // uint64[spill_cap]            k-mers 13..28 of the buckets that hold that many (SeedBucket::count)
     uint32_t spill_cap;   // entries the section holds
     uint32_t spill_used;  // entries in use
-    uint64_t off_tuq;     // uint64[text_units(n)]        bit per letter: the k-mer that starts here occurs once in the text
-                          //                              (either orientation; not its own reverse complement)
+    uint64_t off_tuq;     // 0 (the occurs-once plane lies in the units)
 };
 // thresholds of ArenaHeader::lcp_ge
 __host__ __device__ constexpr uint32_t kLcpGe[10] = {18, 20, 25, 30, 40, 50, 75, 100, 150, 255};
@@ -121,15 +120,17 @@ static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 // (slamem.c:114-199).  A MEM of at least L letters contains a k-letter window that starts at a multiple of s = L - k + 1 of
 // the strand; the seed table gives every text position of that window, and the MEM is then the run of agreeing letters
 // around it on that diagonal -- found by comparing the strand with the text itself, 64 letters per XOR.
-//   TextPlanes u : letters 64u .. 64u+63 of the text as two bit-planes (A,C,G,T = 0..3; bit i of p0 / p1 = low / high bit of
-//                  letter 64u+i; letters that are not A,C,G,T and positions behind the text are 0 and marked in tnm / tnb)
+//   TextPlanes u : letters 64u .. 64u+63 of the text: two bit-planes (A,C,G,T = 0..3; bit i of p0 / p1 = low / high bit of
+//                  letter 64u+i; letters that are not A,C,G,T and positions behind the text are 0), nm: bit per letter "not one
+//                  of A,C,G,T", uq: bit per letter "the k-mer that starts here occurs once in the text" (either orientation; not
+//                  its own reverse complement).  32 bytes: what a compare needs of the text under a strand is 128 contiguous bytes
 //   SeedBucket   : one 64-byte line: up to 12 text positions whose k-mer hashes here (by k-mer, then ascending), a tag byte each (the low
 //                  bits of the hash -- the hash is a bijection of the canonical k-mer, so bucket + tag identify it exactly --
 //                  and bit 7: the text holds the reverse complement of the canonical form), and the number of k-mers that
 //                  hash here.  More than 12: count = 13 (a strand that meets the bucket is left to the index walk), or, for
 //                  up to 28, bit 31 + the number beyond 12 in bits 24-28 + their place in the spill list (in units of four
 //                  entries, bits 0-23): entry = position | tag << 32, runs padded to four entries with ~0
-struct __attribute__((aligned(16))) TextPlanes { uint64_t p0, p1; };
+struct __attribute__((aligned(32))) TextPlanes { uint64_t p0, p1, nm, uq; };
 constexpr uint32_t kSeedSlots = 12;
 constexpr uint32_t kSeedSpillMax = 16;            // k-mers of a bucket beyond its slots that the spill list takes
 constexpr uint32_t kSeedSpilled = 0x80000000u;    // SeedBucket::count of such a bucket
@@ -139,7 +140,7 @@ struct __attribute__((aligned(64))) SeedBucket {
     uint8_t tag[kSeedSlots];
     uint32_t count;
 };
-static_assert(sizeof(SeedBucket) == 64 && sizeof(TextPlanes) == 16, "seed bucket = one line, text unit = 16 bytes");
+static_assert(sizeof(SeedBucket) == 64 && sizeof(TextPlanes) == 32, "seed bucket = one line, text unit = 32 bytes");
 __host__ __device__ inline uint64_t text_units(uint64_t n) { return (n + 63) / 64 + 4; }  // (a compare reads four units from the one its diagonal starts in)
 // k letters as two k-bit plane fields (bit i = letter i) -> the 2k-bit key
 __host__ __device__ inline uint32_t seed_key(uint32_t p0, uint32_t p1, uint32_t k) { return p0 | (p1 << k); }
@@ -187,10 +188,7 @@ struct IndexView {
     uint32_t kfilter_levels;  // 2 or 3
     const SeedBucket* seed;   // nullptr when the index has no seed sections
     const TextPlanes* tpl;
-    const uint64_t* tnm;
-    const uint64_t* tnb;
     const uint64_t* spill;
-    const uint64_t* tuq;
     uint32_t seed_k;
     uint32_t seed_log2;
 };

@@ -404,10 +404,9 @@ __device__ __forceinline__ uint32_t even_bits16(uint32_t x) {
     x = (x | (x >> 8)) & 0x0000FFFFu;
     return x;
 }
-// one lane per unit of 64 letters; a wave covers 64 consecutive units and writes their word of the coarse bitmap
+// one lane per unit of 64 letters (the occurs-once word is filled in by the seed build)
 __global__ void __launch_bounds__(256) k_text_planes(const uint64_t* __restrict__ pk, uint32_t n, uint64_t units,
-                                                     TextPlanes* __restrict__ tpl, uint64_t* __restrict__ tnm,
-                                                     uint64_t* __restrict__ tnb) {
+                                                     TextPlanes* __restrict__ tpl) {
     const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t p0 = 0, p1 = 0, nm = 0;
     if (u < units && u * 64 < (uint64_t)n) {
@@ -423,18 +422,16 @@ __global__ void __launch_bounds__(256) k_text_planes(const uint64_t* __restrict_
         const uint64_t left = (uint64_t)n - u * 64;  // letters of the text in this unit
         if (left < 64) nm &= (1ull << left) - 1ull;  // positions behind the text are not marked (the compare bounds them)
     }
-    if (u < units) { tpl[u] = TextPlanes{p0, p1}; tnm[u] = nm; }
-    const unsigned long long any = __ballot(nm != 0ull);
-    if ((threadIdx.x & 63u) == 0u && (u >> 6) < units / 64 + 1) tnb[u >> 6] = any;
+    if (u < units) tpl[u] = TextPlanes{p0, p1, nm, 0ull};
 }
 
 // k letters of the text from position t as plane fields; false: a letter is not A,C,G,T
-__device__ __forceinline__ bool text_field(const TextPlanes* __restrict__ tpl, const uint64_t* __restrict__ tnm, uint64_t t,
+__device__ __forceinline__ bool text_field(const TextPlanes* __restrict__ tpl, uint64_t t,
                                            uint32_t k, uint32_t& f0, uint32_t& f1) {
     const uint64_t u = t >> 6;
     const uint32_t sh = (uint32_t)t & 63u;
     const TextPlanes a = tpl[u], b = tpl[u + 1];
-    const uint64_t na = tnm[u], nb = tnm[u + 1];
+    const uint64_t na = a.nm, nb = b.nm;
     const uint32_t m = (k >= 32u) ? 0xFFFFFFFFu : (1u << k) - 1u;
     f0 = (uint32_t)((a.p0 >> sh) | ((b.p0 << 1) << (63u - sh))) & m;
     f1 = (uint32_t)((a.p1 >> sh) | ((b.p1 << 1) << (63u - sh))) & m;
@@ -444,21 +441,21 @@ __device__ __forceinline__ bool text_field(const TextPlanes* __restrict__ tpl, c
 // orientations of a k-mer sort next to each other); positions without a k-mer over A,C,G,T sort behind every bucket.
 // Also the first form of the "occurs once" plane: a bit for every position that has a k-mer which is not its own reverse
 // complement (k_seed_fill clears those that occur more than once); a wave covers one 64-letter unit
-__global__ void __launch_bounds__(256) k_seed_keys(const TextPlanes* __restrict__ tpl, const uint64_t* __restrict__ tnm,
+__global__ void __launch_bounds__(256) k_seed_keys(TextPlanes* __restrict__ tpl,
                                                    uint32_t n, uint32_t k, uint32_t log2b, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals, uint64_t* __restrict__ tuq, uint64_t units) {
+                                                   uint32_t* __restrict__ vals, uint64_t units) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t key = 1ull << (log2b + 8u);
     uint32_t f0, f1;
     bool once = false;
-    if (t < (uint64_t)n && t + k <= (uint64_t)n && text_field(tpl, tnm, t, k, f0, f1)) {
+    if (t < (uint64_t)n && t + k <= (uint64_t)n && text_field(tpl, t, k, f0, f1)) {
         const uint32_t x = seed_key(f0, f1, k), y = seed_key(seed_rev_field(f0, k), seed_rev_field(f1, k), k);
         const uint32_t h = seed_mix(x < y ? x : y, 2u * k), tb = 2u * k - log2b;
         key = ((uint64_t)(h >> tb) << 8) | (uint64_t)(((h & ((1u << tb) - 1u)) << 1) | (x > y ? 1u : 0u));
         once = x != y;
     }
     const unsigned long long m = __ballot(once);
-    if ((threadIdx.x & 63u) == 0u && (t >> 6) < units) tuq[t >> 6] = m;
+    if ((threadIdx.x & 63u) == 0u && (t >> 6) < units) tpl[t >> 6].uq = m;  // (every lane of the grid has read its planes: a lane reads units t >> 6 and the next, the word written is neither's p0 / p1 / nm)
     if (t >= (uint64_t)n) return;
     keys[t] = key;
     vals[t] = (uint32_t)t;
@@ -470,7 +467,7 @@ __device__ __forceinline__ uint8_t seed_tag_of_sorted(uint32_t key) { return (ui
 // those beyond the twelfth, rounded up to four)
 __global__ void __launch_bounds__(256) k_seed_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                    uint64_t n, uint32_t log2b, SeedBucket* __restrict__ table,
-                                                   uint32_t* __restrict__ want, unsigned long long* __restrict__ tuq) {
+                                                   uint32_t* __restrict__ want, TextPlanes* __restrict__ tpl) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t key = keys[i];
@@ -479,7 +476,7 @@ __global__ void __launch_bounds__(256) k_seed_fill(const uint64_t* __restrict__ 
         const uint64_t b = key >> 8;
         // the same k-mer (in either orientation) next to this one in the sorted order: it occurs more than once
         if ((i > 0 && (keys[i - 1u] >> 1) == (key >> 1)) || (i + 1u < n && (keys[i + 1u] >> 1) == (key >> 1)))
-            atomicAnd(tuq + (vals[i] >> 6), ~(1ull << (vals[i] & 63u)));
+            atomicAnd(reinterpret_cast<unsigned long long*>(&tpl[vals[i] >> 6].uq), ~(1ull << (vals[i] & 63u)));
         uint32_t r = 0;
         while (r < kSeedSlots && r < i && (keys[i - r - 1u] >> 8) == b) r++;
         if (r < kSeedSlots) {
@@ -956,10 +953,7 @@ void make_view(slamem_index* idx) {
     idx->view.kfilter_levels = h.kfilter_levels == 2u ? 2u : 3u;
     idx->view.seed = h.off_seed ? reinterpret_cast<const SeedBucket*>(base + h.off_seed) : nullptr;
     idx->view.tpl = h.off_seed ? reinterpret_cast<const TextPlanes*>(base + h.off_tpl) : nullptr;
-    idx->view.tnm = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tnm) : nullptr;
-    idx->view.tnb = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tnb) : nullptr;
     idx->view.spill = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_spill) : nullptr;
-    idx->view.tuq = h.off_seed ? reinterpret_cast<const uint64_t*>(base + h.off_tuq) : nullptr;
     idx->view.seed_k = h.off_seed ? h.seed_k : 0u;
     idx->view.seed_log2 = h.off_seed ? h.seed_log2 : 0u;
     idx->view.n = h.n;
@@ -1066,11 +1060,8 @@ static void plan_arena(uint32_t n, uint32_t num_n, int layout, ArenaHeader& hdr)
             const uint64_t units = text_units(n);
             hdr.off_seed = off; off = align_up(off + (sizeof(SeedBucket) << lg), 256);
             hdr.off_tpl = off;  off = align_up(off + units * sizeof(TextPlanes), 256);
-            hdr.off_tnm = off;  off = align_up(off + units * 8, 256);
-            hdr.off_tnb = off;  off = align_up(off + (units / 64 + 1) * 8, 256);
             hdr.spill_cap = (uint32_t)seed_spill_entries(n);
             hdr.off_spill = off; off = align_up(off + (uint64_t)hdr.spill_cap * 8, 256);
-            hdr.off_tuq = off;  off = align_up(off + units * 8, 256);
         }
     }
     hdr.total_bytes = off;
@@ -1328,14 +1319,10 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
                          // BEFORE the presence filter is built: the B buffers may lie in the filter's region
         const uint64_t units = text_units(n);
         TextPlanes* d_tpl = reinterpret_cast<TextPlanes*>(base + hdr.off_tpl);
-        uint64_t* d_tnm = reinterpret_cast<uint64_t*>(base + hdr.off_tnm);
-        uint64_t* d_tnb = reinterpret_cast<uint64_t*>(base + hdr.off_tnb);
         SeedBucket* d_seed = reinterpret_cast<SeedBucket*>(base + hdr.off_seed);
-        SLAMEM_HIP(hipMemsetAsync(d_tnb, 0, (units / 64 + 1) * 8, stream));
-        hipLaunchKernelGGL(k_text_planes, dim3(grid_for(units + 63)), dim3(256), 0, stream, pk.as<uint64_t>(), n, units, d_tpl, d_tnm, d_tnb);
-        uint64_t* d_tuq = reinterpret_cast<uint64_t*>(base + hdr.off_tuq);
-        hipLaunchKernelGGL(k_seed_keys, dim3(grid_for(units * 64)), dim3(256), 0, stream, (const TextPlanes*)d_tpl, (const uint64_t*)d_tnm, n,
-                           hdr.seed_k, hdr.seed_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>(), d_tuq, units);
+        hipLaunchKernelGGL(k_text_planes, dim3(grid_for(units)), dim3(256), 0, stream, pk.as<uint64_t>(), n, units, d_tpl);
+        hipLaunchKernelGGL(k_seed_keys, dim3(grid_for(units * 64)), dim3(256), 0, stream, d_tpl, n,
+                           hdr.seed_k, hdr.seed_log2, keysB.as<uint64_t>(), valsB.as<uint32_t>(), units);
         SLAMEM_HIP(hipGetLastError());
         need = tmp_bytes;
         SLAMEM_HIP(sort_pairs_u64_u32(sorttmp.p, need, keysB.as<uint64_t>(), keysA.as<uint64_t>(), valsB.as<uint32_t>(),
@@ -1346,7 +1333,7 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
         uint32_t* d_place = keysB.as<uint32_t>();
         hipLaunchKernelGGL(k_seed_fill, dim3(grid_for(n)), dim3(256), 0, stream, (const uint64_t*)keysA.as<uint64_t>(),
                            (const uint32_t*)valsA.as<uint32_t>(), (uint64_t)n, hdr.seed_log2, d_seed, d_want,
-                           reinterpret_cast<unsigned long long*>(d_tuq));
+                           d_tpl);
         SLAMEM_HIP(hipGetLastError());
         SLAMEM_HIP(exclusive_scan_u32(d_want, d_place, n, static_cast<uint32_t*>(sorttmp.p), stream));
         SLAMEM_HIP(hipMemsetAsync(d_scal + 11, 0, 4, stream));

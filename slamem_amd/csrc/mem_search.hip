@@ -176,7 +176,9 @@ struct SearchArgs {
     RawKey* raw_key;
     slamem_mem* raw_mem;
     uint32_t* block_counts;    // [num_blocks + 1]
-    struct RawRow* inline_rows; // v3: kInlineMems slots per work item, addressed directly (no atomics)
+    struct RawRow* inline_rows; // v3: kInlineMems slots per work item, addressed directly (no atomics): slot kk of item g at
+                                //     [kk * inline_stride + g] (slot-major: K9 reads every item's first slot, rarely another)
+    uint64_t inline_stride;
     const struct ItemDesc* items; // v3: work items in emission order
     uint64_t num_items;
     uint8_t* item_attempt;      // v3: attempt whose records are the valid ones
@@ -188,6 +190,8 @@ struct SearchArgs {
     const uint64_t* pq;         // v3: the strands as packed letter ids (k_pack_queries), two zero words in front
     uint64_t* pq_out;           //     (the same buffer, written by k_pack_queries)
     uint32_t implicit_items;    // v3: 1: no item tables (item_of / item_pk_of)
+    uint32_t* seed_left_ids;    // K8s: the strands it leaves to K8 (K8's work list) ...
+    unsigned int* seed_left_count;  // ... and their number
     uint32_t seed_step;         // K8s: 0, or the stride of the windows of the first round (experiments: SLAMEM_SEED_STEP)
     const uint64_t* item_pk;    // v3: per work item, the word offset of its strand block in pq
     unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
@@ -207,6 +211,7 @@ struct SearchArgs {
     // launch takes those lanes in first (carry_in) and lets them write to the PREVIOUS batch's output side (prev).
     struct OutCtx {
         struct RawRow* inline_rows;
+        uint64_t inline_stride;
         RawKey* raw_key;
         slamem_mem* raw_mem;
         unsigned long long* total;
@@ -768,7 +773,7 @@ __global__ void __launch_bounds__(256) k_mam_check(SearchArgs A, MamPass P, uint
 __device__ __forceinline__ void emit3_at(const SearchArgs& A, uint32_t g, uint32_t kk, uint32_t tag, uint32_t row,
                                          uint32_t pos, uint32_t len) {
     if (kk < kInlineMems) {
-        A.inline_rows[(uint64_t)g * kInlineMems + kk] = RawRow{row, pos, len};
+        A.inline_rows[(uint64_t)kk * A.inline_stride + g] = RawRow{row, pos, len};
     } else {
         if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(A.total) + 9, 1u);  // the ordinal would run into the tag: reported as an error
         unsigned long long slot = atomicAdd(A.total, 1ull);
@@ -806,7 +811,7 @@ __device__ __forceinline__ void emit3_sel(const SearchArgs& A, bool old, uint32_
     if (!kCarry) { emit3_at(A, g, kk, tag, row, pos, len); return; }
     if (kk < kInlineMems) {
         RawRow* ir = old ? A.prev.inline_rows : A.inline_rows;
-        ir[(uint64_t)g * kInlineMems + kk] = RawRow{row, pos, len};
+        ir[(uint64_t)kk * (old ? A.prev.inline_stride : A.inline_stride) + g] = RawRow{row, pos, len};
     } else {
         unsigned long long* tot = old ? A.prev.total : A.total;
         if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(tot) + 9, 1u);
@@ -857,7 +862,7 @@ __device__ __forceinline__ uint32_t wave_emit_step(const SearchArgs& A, bool old
     const unsigned long long mo = __ballot(ok && !inl);
     if (inl) {
         RawRow* ir = (kCarry && old) ? A.prev.inline_rows : A.inline_rows;
-        ir[(uint64_t)g * kInlineMems + kk] = RawRow{row, pos, len};
+        ir[(uint64_t)kk * ((kCarry && old) ? A.prev.inline_stride : A.inline_stride) + g] = RawRow{row, pos, len};
     }
     if (mo != 0ull) {
         unsigned long long* tot = (kCarry && old) ? A.prev.total : A.total;
@@ -1252,7 +1257,10 @@ __global__ void __launch_bounds__(256) k_pack_queries(SearchArgs A, bool long_on
     // for the test below, and the rest a round trip later: five dependent memory phases per item, now three)
     ItemDesc d;
     uint64_t pk_word;
-    if (A.implicit_items) { d = item_of(A, item); pk_word = item_pk_of(A, item, d); }
+    if (A.implicit_items) {
+        if (!long_only && A.item_alive && A.item_alive[item] == 0) continue;  // (proved empty by the presence filter: K8 passes over it)
+        d = item_of(A, item); pk_word = item_pk_of(A, item, d);
+    }
     else {
         uint4 dv = *reinterpret_cast<const uint4*>(A.items + item);
         pk_word = A.item_pk[item];
@@ -1513,7 +1521,8 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
                 if (i < chunk_end) {  // descriptors -> LDS: one coalesced read per wave instead of a round trip per item
                     uint32_t id = A.work_ids ? A.work_ids[i] : (uint32_t)i;
                     lds_id[wv][lane] = id;
-                    const ItemDesc idesc = item_of(A, id);
+                    ItemDesc idesc = item_of(A, id);
+                    if (A.implicit_items && A.item_alive && A.item_alive[id] == 0) idesc.len = 0;  // (the list K8s wrote, less what the presence filter proved empty)
                     lds_item[wv][lane] = idesc;
                     lds_pk[wv][lane] = item_pk_of(A, id, idesc);
                 }
@@ -2694,7 +2703,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     // looks up what is left: the windows with an error in them and the repeats (headline batch: 27 windows a read, 72 % of
     // them free of errors: 9 lookups in round A, 5-6 in round B).  A match that holds a round-A window is reported in round A
     // by the first of those (forward offset); one that holds none, in round B by its first window.
-    const uint32_t mstep = !ix.tuq ? 1u : A.seed_step ? A.seed_step : s <= 6u ? 3u : s <= 12u ? 2u : 1u;
+    const uint32_t mstep = A.seed_step ? A.seed_step : s <= 6u ? 3u : s <= 12u ? 2u : 1u;
     const uint32_t lmod = mstep == 3u ? lane % 3u : mstep == 2u ? (lane & 1u) : 0u;
     if (lane < kSeedReads) S.expl[lane] = 0ull;
     uint32_t njobs = 0, nmems = 0;
@@ -2844,29 +2853,16 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 int64_t ui[NU];
 #pragma unroll
                 for (int i = 0; i < NU; i++) { const int64_t u = u0 + i; ui[i] = u < 0 ? 0 : u > ulast ? ulast : u; }
+                // (a unit is 32 bytes: planes, letter mask, occurs-once plane -- the units of a compare are 128 contiguous bytes)
                 const uint4* T = reinterpret_cast<const uint4*>(ix.tpl);
-                uint4 tu[NU];
+                uint4 tu[NU], tx[NU];
 #pragma unroll
-                for (int i = 0; i < NU; i++) tu[i] = T[ui[i]];
-                uint64_t uq[NU];
-#pragma unroll
-                for (int i = 0; i < NU; i++) uq[i] = 0ull;
-                if (mark) {
-#pragma unroll
-                    for (int i = 0; i < NU; i++) uq[i] = ix.tuq[ui[i]];
-                }
-                const uint64_t c0 = ix.tnb[ui[0] >> 6], c3 = ix.tnb[ui[NU - 1] >> 6];
+                for (int i = 0; i < NU; i++) { tu[i] = T[2 * ui[i]]; tx[i] = T[2 * ui[i] + 1]; }
+                uint64_t uq[NU], nu[NU];
                 uint32_t anyn = 0;
 #pragma unroll
-                for (int i = 0; i < NU; i++) anyn |= (uint32_t)((((ui[i] >> 6) == (ui[0] >> 6) ? c0 : c3) >> (ui[i] & 63)) & 1ull);
-                uint64_t nu[NU];
-#pragma unroll
-                for (int i = 0; i < NU; i++) nu[i] = 0ull;
-                if (anyn) {  // (rare) some unit holds a letter that is not A,C,G,T: it disagrees with every letter of a strand that has none
-#pragma unroll
-                    for (int i = 0; i < NU; i++) nu[i] = ix.tnm[ui[i]];
-                    if (kStats) n_nm++;
-                }
+                for (int i = 0; i < NU; i++) { nu[i] = u64_of(tx[i].x, tx[i].y); uq[i] = u64_of(tx[i].z, tx[i].w); anyn |= (tx[i].x | tx[i].y); }
+                if (kStats && anyn) n_nm++;
                 const uint64_t* R0 = S.pl[jr][st][0];
                 const uint64_t* R1 = S.pl[jr][st][1];
                 uint64_t mm[NW];
@@ -3078,7 +3074,18 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     }
     wave_sync();
     const uint32_t fl = S.flags | wflags;
-    if (lane < nr * strands) alive[r0 * strands + lane] = (uint8_t)((fl >> (strands == 2u ? lane : 2u * lane)) & 1u);
+    {   // the strands left to K8: their flags, and their numbers appended to K8's work list (the list's order is the order the
+        // waves end in: it decides which lane scans a strand, never what is reported for it)
+        const bool isleft = lane < nr * strands && ((fl >> (strands == 2u ? lane : 2u * lane)) & 1u) != 0u;
+        if (lane < nr * strands) alive[r0 * strands + lane] = isleft ? 1 : 0;
+        const unsigned long long lm = __ballot(isleft);
+        if (lm != 0ull) {
+            unsigned int at = 0;
+            if (lane == 0u) at = atomicAdd(A.seed_left_count, (unsigned int)__popcll(lm));
+            at = (unsigned int)__builtin_amdgcn_readfirstlane((int)at);
+            if (isleft) A.seed_left_ids[at + (uint32_t)__popcll(lm & below)] = (uint32_t)(r0 * strands + lane);
+        }
+    }
     if (kStats) {
         stat_flush<kStats>(A.stats + SC_SEED_NMASKS, n_nm);
         stat_flush<kStats>(A.stats + SC_SEED_MEMS, n_mem);
@@ -3096,7 +3103,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
 }
 
 // K9 for v3: inline slots and overflow records -> grouped output, BWT rows resolved to text positions here
-__global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__ inl, const uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__ inl, uint64_t stride, const uint32_t* __restrict__ counts,
                                                       const uint64_t* __restrict__ item_off, uint64_t nitems,
                                                       const uint32_t* __restrict__ sa, uint64_t capacity,
                                                       slamem_mem* __restrict__ out, const uint8_t* __restrict__ inline_valid) {
@@ -3111,12 +3118,12 @@ __global__ void __launch_bounds__(256) k_place_inline(const RawRow* __restrict__
     if (iv && cnt > iv - 1u) cnt = iv - 1u;
     if (cnt == 0u) return;
     static_assert(kInlineMems == 4, "k_place_inline is written for four inline slots");
-    const RawRow* in = inl + g * kInlineMems;
+    const RawRow* in = inl + g;
     const RawRow none = {0u, 0u, 0x80000000u};  // (bit 31: no suffix-array read)
     RawRow r0 = in[0], r1 = none, r2 = none, r3 = none;
-    if (cnt > 1u) r1 = in[1];
-    if (cnt > 2u) r2 = in[2];
-    if (cnt > 3u) r3 = in[3];
+    if (cnt > 1u) r1 = in[stride];
+    if (cnt > 2u) r2 = in[2u * stride];
+    if (cnt > 3u) r3 = in[3u * stride];
     asm volatile("" : "+v"(r0.row), "+v"(r0.pos), "+v"(r0.len), "+v"(r1.row), "+v"(r1.pos), "+v"(r1.len));
     asm volatile("" : "+v"(r2.row), "+v"(r2.pos), "+v"(r2.len), "+v"(r3.row), "+v"(r3.pos), "+v"(r3.len));
     // bit 31 of the length: `row` already is the text position (a MEM emitted from a direct run)
@@ -3165,9 +3172,9 @@ __global__ void __launch_bounds__(256) k_place_overflow(const RawKey* __restrict
 // slices per strand of every record (>= 1 so that empty records still own an (empty) output block)
 // (and the 64-bit words one strand of the record occupies in the packed copy: a multiple of two, i.e. 16-byte blocks)
 __global__ void __launch_bounds__(256) k_item_counts(const uint64_t* __restrict__ offsets, uint32_t nq, uint32_t slice_len,
-                                                     uint32_t* __restrict__ cnt, uint32_t* __restrict__ wps) {
+                                                     uint32_t* __restrict__ cnt, uint32_t* __restrict__ wps,
+                                                     unsigned int* __restrict__ most) {
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > nq) return;
     uint32_t c = 0, w = 0;
     if (q < nq) {
         uint64_t len = offsets[q + 1] - offsets[q];
@@ -3175,6 +3182,10 @@ __global__ void __launch_bounds__(256) k_item_counts(const uint64_t* __restrict_
         if (c == 0) c = 1;
         w = 2u * (uint32_t)((len + 31u) >> 5);
     }
+    // the most items any record has (1: no record is cut into slices -- item g is strand block g, and a batch on the seed
+    // path needs no scan of these counts)
+    if (c > 1u) atomicMax(most, c);
+    if (q > nq) return;
     cnt[q] = c;  // cnt[nq] = 0: the scan of nq+1 values leaves the total in first[nq]
     wps[q] = w;
 }
@@ -3448,23 +3459,42 @@ int SearchJob::tables(hipStream_t stream) {
     // ---- work items: one per strand, long records cut into slices ----------------------------------------------
     uint32_t* d_wps = reinterpret_cast<uint32_t*>(ws + w.off_wps);
     uint64_t* d_wscan = reinterpret_cast<uint64_t*>(ws + w.off_wscan);
-    hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
-                       num_queries, (match_type == 1 && mam_whole_strands()) ? 0u : kSliceLen, d_cnt, d_wps);
-    STEP(hipGetLastError(), "k_item_counts");
-    STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
+    // reads (no record was cut into slices, none longer on average than the seed kernel's strands), -mem, a minimum length
+    // that leaves at least four letters between two windows: K8s finds the MEMs by seed-and-compare and leaves to K8
+    // only the strands it cannot decide (SLAMEM_SEED_SEARCH=0: the prefilter and the index walk for everything)
+    // (read per call, not once per process: the tests run both paths in one process)
+    const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
+    const bool seed_ok = use_seed && match_type == 0 && idx->view.seed && min_len >= idx->view.seed_k + 3u &&
+                         min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLenLong;
     uint32_t slices = slices_hint;
     const bool ask = slices_hint == 0xFFFFFFFFu;
-    if (ask) STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
-    if (ask) STEP(hipStreamSynchronize(stream), "item count (sync)");
-    nitems = (uint64_t)slices * strands;
-    {   // reads (no record was cut into slices, none longer on average than the seed kernel's strands), -mem, a minimum length
-        // that leaves at least four letters between two windows: K8s finds the MEMs by seed-and-compare and leaves to K8
-        // only the strands it cannot decide (SLAMEM_SEED_SEARCH=0: the prefilter and the index walk for everything)
-        // (read per call, not once per process: the tests run both paths in one process)
-        const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
-        seed_path = use_seed && match_type == 0 && nitems == num_blocks && idx->view.seed && min_len >= idx->view.seed_k + 3u &&
-                    min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLenLong;
+    // a batch on the seed path takes its items from the offsets (item_of): no counts, no scans, no tables -- when the caller
+    // says that no record is longer than a slice; when it does not, one pass over the lengths says so
+    bool counted = false, scanned = false;
+    unsigned int* d_most = reinterpret_cast<unsigned int*>(d_total) + 2;  // a word of the zeroed scalar block
+    if (!(seed_ok && !ask && slices == num_queries)) {
+        hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
+                           num_queries, (match_type == 1 && mam_whole_strands()) ? 0u : kSliceLen, d_cnt, d_wps, d_most);
+        STEP(hipGetLastError(), "k_item_counts");
+        counted = true;
+        if (ask) {
+            unsigned int most = 0;
+            STEP(hipMemcpyAsync(&most, d_most, 4, hipMemcpyDeviceToHost, stream), "memcpy");
+            STEP(hipStreamSynchronize(stream), "item count (sync)");
+            if (most <= 1u) slices = num_queries;
+        }
     }
+    seed_path = seed_ok && slices == num_queries;
+    if (counted && !seed_path) {
+        STEP(exclusive_scan_u32(d_cnt, d_first, (uint64_t)num_queries + 1, reinterpret_cast<uint32_t*>(ws + w.off_scan32), stream), "scan");
+        scanned = true;
+        if (slices == 0xFFFFFFFFu) {
+            STEP(hipMemcpyAsync(&slices, d_first + num_queries, 4, hipMemcpyDeviceToHost, stream), "memcpy");
+            STEP(hipStreamSynchronize(stream), "item count (sync)");
+        }
+    }
+    (void)scanned;
+    nitems = (uint64_t)slices * strands;
     if (!seed_path) {   // packed strands: offsets of the strand blocks (a batch on the seed path: item_pk_of)
         size_t need3 = w.scan_bytes;
         STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need3, d_wps, d_wscan, (uint64_t)num_queries, stream), "scan");
@@ -3488,6 +3518,7 @@ int SearchJob::tables(hipStream_t stream) {
     A.raw_mem = reinterpret_cast<slamem_mem*>(ws + w.off_rawmem);
     A.block_counts = d_counts;
     A.inline_rows = reinterpret_cast<RawRow*>(ws + w.off_inline);
+    A.inline_stride = w.max_items;
     A.items = reinterpret_cast<const ItemDesc*>(ws + w.off_items);
     A.num_items = nitems;
     A.item_attempt = reinterpret_cast<uint8_t*>(ws + w.off_attempt);
@@ -3564,6 +3595,11 @@ int SearchJob::prep(hipStream_t stream) {
                 const char* v = getenv("SLAMEM_SEED_STEP");
                 A.seed_step = v && atoi(v) >= 1 && atoi(v) <= 3 ? (uint32_t)atoi(v) : 0u;
             }
+            // K8s writes K8's work list itself (no pass over 20 M flags for the handful it leaves)
+            uint32_t* d_ids = reinterpret_cast<uint32_t*>(ws + w.off_workids);
+            uint32_t* d_nwork = reinterpret_cast<uint32_t*>(d_total) + 8;  // a word of the zeroed scalar block
+            A.seed_left_ids = d_ids;
+            A.seed_left_count = d_nwork;
             const dim3 gs(grid_for((uint64_t)num_queries, 4 * kSeedReads));
             // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: six)
             const bool long_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLen;
@@ -3578,19 +3614,13 @@ int SearchJob::prep(hipStream_t stream) {
             (void)hipEventRecord(ev[3], stream);
             prefiltered = true;
             A.item_alive = d_alive;
-            uint32_t* d_ids = reinterpret_cast<uint32_t*>(ws + w.off_workids);
-            uint32_t* d_nwork = reinterpret_cast<uint32_t*>(d_total) + 8;  // a word of the zeroed scalar block
-            size_t need2 = w.select_bytes;
-            STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
             A.work_ids = d_ids;
             A.work_count = d_nwork;
             if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
-                // the strands K8s left, through the presence filter (the wrong strand of a read that was left whole dies here),
-                // and the list again from what is left of alive[]
+                // the strands K8s left, through the presence filter (the wrong strand of a read that was left whole dies here:
+                // alive[] = 0; K8 and its packer pass over those entries of the list)
                 hipLaunchKernelGGL(k_prefilter_list, dim3(512), dim3(256), 0, stream, A, (const uint32_t*)d_ids, (const uint32_t*)d_nwork, d_alive);
                 STEP(hipGetLastError(), "k_prefilter_list");
-                need2 = w.select_bytes;
-                STEP(select_indices_u32(ws + w.off_select, need2, d_alive, d_ids, d_nwork, nitems, stream), "select");
             }
         } else if (use_filter && idx->view.kfilter && min_len >= idx->view.kfilter_k) {
             uint8_t* d_alive = reinterpret_cast<uint8_t*>(ws + w.off_alive);
@@ -3661,7 +3691,7 @@ bool SearchJob::can_carry_into(const SearchJob& next) const {
 }
 
 static void fill_prev_ctx(SearchArgs& A, const SearchJob& from) {
-    A.prev.inline_rows = from.A.inline_rows; A.prev.raw_key = from.A.raw_key; A.prev.raw_mem = from.A.raw_mem;
+    A.prev.inline_rows = from.A.inline_rows; A.prev.inline_stride = from.A.inline_stride; A.prev.raw_key = from.A.raw_key; A.prev.raw_mem = from.A.raw_mem;
     A.prev.total = from.A.total; A.prev.capacity = from.A.capacity; A.prev.block_counts = from.A.block_counts;
     A.prev.item_attempt = from.A.item_attempt;
     char* pws = static_cast<char*>(from.workspace_dev);
@@ -3861,14 +3891,19 @@ int SearchJob::place(hipStream_t stream) {
     // and every store is bounds-checked against the capacity (a batch that does not fit is reported by collect()).
     uint32_t* d_first = reinterpret_cast<uint32_t*>(ws + w.off_first);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(ws + w.off_counts);
-    uint64_t* d_itemoff = reinterpret_cast<uint64_t*>(ws + w.off_itemoff);
+    // (no record cut into slices: item g is strand block g and the items' offsets ARE the blocks' -- scanned straight into the
+    //  caller's array; otherwise a block starts where its first item does)
+    const bool blocks_are_items = nitems == num_blocks;
+    uint64_t* d_itemoff = blocks_are_items ? block_offsets_dev : reinterpret_cast<uint64_t*>(ws + w.off_itemoff);
     size_t need = w.scan_bytes;
     STEP(scan_sum_exclusive_u32_u64(ws + w.off_scan, need, d_counts, d_itemoff, nitems, stream), "scan");
-    hipLaunchKernelGGL(k_block_offsets, dim3(grid_for(num_blocks + 1)), dim3(256), 0, stream, d_first, d_itemoff,
-                       num_queries, strands, nitems, block_offsets_dev);
-    STEP(hipGetLastError(), "k_block_offsets");
+    if (!blocks_are_items) {
+        hipLaunchKernelGGL(k_block_offsets, dim3(grid_for(num_blocks + 1)), dim3(256), 0, stream, d_first, d_itemoff,
+                           num_queries, strands, nitems, block_offsets_dev);
+        STEP(hipGetLastError(), "k_block_offsets");
+    }
     if (nitems && mems_capacity) {
-        hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, d_counts,
+        hipLaunchKernelGGL(k_place_inline, dim3(grid_for(nitems)), dim3(256), 0, stream, A.inline_rows, A.inline_stride, d_counts,
                            d_itemoff, nitems, idx->view.sa, mems_capacity, mems_dev, deferred ? (const uint8_t*)A.defer.inline_valid : (const uint8_t*)nullptr);
         STEP(hipGetLastError(), "k_place_inline");
         const uint64_t ob = (mems_capacity + 255) / 256;

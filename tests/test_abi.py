@@ -110,12 +110,11 @@ def _arena_header(n=100_000, num_n=3, with_filter=True):
     sk, slg = 11, 15
     units = (n + 63) // 64 + 4
     off_seed = off; off = al(off + (64 << slg))
-    off_tpl = off; off = al(off + units * 16)
-    off_tnm = off; off = al(off + units * 8)
-    off_tnb = off; off = al(off + (units // 64 + 1) * 8)
+    off_tpl = off; off = al(off + units * 32)
+    off_tnm = off_tnb = 0
     spill_cap = ((n // 16 + 3) & ~3) + 64
     off_spill = off; off = al(off + spill_cap * 8)
-    off_tuq = off; off = al(off + units * 8)
+    off_tuq = 0
     fields = dict(magic_lo=0x4D414C53, magic_hi=0x58494845, version=13, seed_k=sk, seed_log2=slg, off_seed=off_seed,
                   off_tpl=off_tpl, off_tnm=off_tnm, off_tnb=off_tnb, off_spill=off_spill, spill_cap=spill_cap, spill_used=8, off_tuq=off_tuq, layout=1, lcp_ge=0, n=n, total_bytes=off, off_fm=off_fm, off_rec=off_rec,
                   off_sa=off_sa, off_nrows=off_nrows, off_kfilter=off_kf, r0=off_tg, r1=off_pr, r2=off_kj, kjump_k=kj, C=0, kbits_k=kb, z=0, off_kbits=off_kb, kfilter_log2=lg if with_filter else 0,
@@ -144,8 +143,8 @@ def test_header_validation_rejects_corrupt_arenas(tmp_path):
     assert L.slamem_index_validate_header(pack2(), 4096, f2["total_bytes"]) == 0
     assert L.slamem_index_validate_header(good, len(good), f["total_bytes"] - 1) == ERR_FORMAT       # truncated file
     bad = [dict(magic_lo=1), dict(version=10), dict(version=12), dict(spill_cap=f["spill_cap"] + 4), dict(spill_used=f["spill_cap"] + 1),
-           dict(off_spill=f["total_bytes"] - 64), dict(off_spill=0), dict(off_tuq=0), dict(off_tuq=f["off_tuq"] + 8), dict(seed_k=17), dict(seed_k=3), dict(seed_log2=f["seed_log2"] + 8),
-           dict(seed_log2=9), dict(off_seed=f["off_seed"] + 64), dict(off_tpl=f["off_tnm"]), dict(off_tnm=0), dict(off_tnb=f["total_bytes"]),
+           dict(off_spill=f["total_bytes"] - 64), dict(off_spill=0), dict(off_tuq=4096), dict(seed_k=17), dict(seed_k=3), dict(seed_log2=f["seed_log2"] + 8),
+           dict(seed_log2=9), dict(off_seed=f["off_seed"] + 64), dict(off_tpl=f["off_spill"]), dict(off_tnm=256), dict(off_tnb=f["total_bytes"]),
            dict(off_seed=0), dict(kbits_k=17), dict(kbits_k=f['kbits_k'] + 1), dict(off_kbits=f['off_kbits'] + 32), dict(kjump_k=13), dict(kjump_k=8), dict(r2=f['r2'] + 64), dict(r0=f['r0'] + 8), dict(r1=f['r1'] + 4096), dict(r0=0), dict(n=0), dict(nblocks=f["nblocks"] - 1), dict(nblocks=f["nblocks"] + 1),
            dict(off_fm=8192), dict(off_rec=f["off_rec"] + 64), dict(off_rec=f["off_fm"]), dict(off_sa=f["total_bytes"]),
            dict(off_sa=f["off_rec"] + 256), dict(off_nrows=f["off_sa"]), dict(off_kfilter=f["total_bytes"] - 256),

@@ -298,6 +298,15 @@ def test_config5_grch38_sized_full_size_properties(eng):
     first = rows[rows[:, 0] < 200_000]
     assert digest_rows(first) == {k: ref100k[k] for k in DIGEST_KEYS}
     assert int((first[:, 1].astype(np.int64) > (1 << 31)).sum()) == ref100k["rows_beyond_2p31"]
+    # a second, disjoint pin by the REAL reference (round 4): reads 7,000,000 .. 7,099,999 of the same share
+    ref7m = KNOWN.get("config5_reads_7M")
+    if ref7m is not None:
+        assert ref7m["reference_completed"] and ref7m["reference_valid"]
+        lo = 2 * 7_000_000
+        part = rows[(rows[:, 0] >= lo) & (rows[:, 0] < lo + 200_000)].copy()
+        part[:, 0] -= lo  # (the reference numbered its 100,000 queries from 0)
+        assert digest_rows(part) == {k: ref7m[k] for k in DIGEST_KEYS}
+        assert int((part[:, 1].astype(np.int64) > (1 << 31)).sum()) == ref7m["rows_beyond_2p31"]
     # completeness beyond 2^31 rows: the definitional MEM set (every maximal match >= l, from the text and the reads alone,
     # no index) of 2,600 sampled reads -- 1,500 random, 600 drawn from beyond position 2^31, 500 from planted repeats --
     # equals the engine's output for those reads as a set
