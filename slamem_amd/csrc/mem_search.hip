@@ -2496,27 +2496,32 @@ __global__ void __launch_bounds__(256) k_prefilter_list(SearchArgs A, const uint
 // two MEMs of a strand with the same start and length (their order is the order of their BWT rows).  Nothing here is
 // approximate: a strand is either reported completely by this kernel or completely by K8.
 #ifndef SLAMEM_SEED_READS
-#define SLAMEM_SEED_READS 16
+#define SLAMEM_SEED_READS 21
 #endif
-constexpr uint32_t kSeedReads = SLAMEM_SEED_READS;     // reads of a wave (at most 16: a flag word holds two bits per read)
+// reads of a wave in the instantiation for reads of up to 192 letters: 21 x 3 plane words are 63 lanes of work in the planes
+// step, 21 x 9 first-round windows three full trips (at most 32: a flag word holds a bit per read); the long-read form takes 16
+constexpr uint32_t kSeedReads = SLAMEM_SEED_READS, kSeedReadsLong = 16;
 constexpr uint32_t kSeedMaxLen = 192;   // letters of a strand the planes hold in the instantiation for reads of up to 192 letters (three words)
 constexpr uint32_t kSeedMaxLenLong = 384;  // ... and in the one for longer reads (six words: 2 x 250 bp runs; a batch takes it when its reads average more than 192)
-constexpr uint32_t kSeedJobs = 256;     // compares of one wave
-#ifndef SLAMEM_SEED_MEMS
-#define SLAMEM_SEED_MEMS 192
+#ifndef SLAMEM_SEED_JOBS
+#define SLAMEM_SEED_JOBS 16
 #endif
-constexpr uint32_t kSeedMems = SLAMEM_SEED_MEMS;     // MEMs of one wave
+constexpr uint32_t kSeedJobs = SLAMEM_SEED_JOBS;      // compares of one wave: this many per read
+#ifndef SLAMEM_SEED_MEMS
+#define SLAMEM_SEED_MEMS 12
+#endif
+constexpr uint32_t kSeedMems = SLAMEM_SEED_MEMS;     // MEMs of one wave: this many per read
 constexpr uint32_t kSigLetters = 12, kSigMask = (1u << kSigLetters) - 1u, kSigKnown = 1u << 24;  // text letters kept behind a MEM (ties, phase 3)
 
-template <uint32_t NW>  // plane words of a strand (64 letters each)
+template <uint32_t NW, uint32_t R>
 struct SeedWave {
-    static constexpr uint32_t kJobs = kSeedJobs * (NW / 3u), kMems = kSeedMems * (NW / 3u);  // (longer strands: more windows, more MEMs)
-    uint64_t pl[kSeedReads][2][2][NW + 1];   // [read][strand][plane][word]; the last word stays 0 (a window's second word)
-    uint32_t len[kSeedReads];           // letters (0: the read takes no part)
-    uint32_t nwin[kSeedReads];          // windows
+    static constexpr uint32_t kJobs = kSeedJobs * R * (NW / 3u), kMems = kSeedMems * R * (NW / 3u);  // (longer strands: more windows, more MEMs)
+    uint64_t pl[R][2][2][NW + 1];       // [read][strand][plane][word]; the last word stays 0 (a window's second word)
+    uint32_t len[R];                    // letters (0: the read takes no part)
+    uint32_t nwin[R];                   // windows
     union {
         // first the wave's reads as they are (their bytes, 16-byte chunks of the query buffer), while the planes are made ...
-        uint4 raw[kSeedReads * NW * 4 + 1];
+        uint4 raw[R * NW * 4 + 1];
         // ... then the compares and the MEMs
         struct {
             uint32_t job_p[kJobs], job_x[kJobs];
@@ -2526,13 +2531,13 @@ struct SeedWave {
             uint32_t mem_sig[kMems];
         };
     };
-    uint32_t bad[kSeedReads];           // the read holds a letter that is not A,C,G,T
-    unsigned long long expl[kSeedReads];  // bit per window of a read: its only occurrence in the text is accounted for (round A)
+    uint32_t bad[R];                    // the read holds a letter that is not A,C,G,T
+    unsigned long long expl[R];         // bit per window of a read: its only occurrence in the text is accounted for (round A)
     union {
         uint16_t ring[128];             // window ids (read << 8 | window) waiting for a full trip
-        unsigned long long smask[32];   // ... later: per strand, which MEMs of the wave's list are its own
+        unsigned long long smask[2 * R];  // ... later: per strand, which MEMs of the wave's list are its own
     };
-    uint32_t flags;                     // bit 2 * read + strand: the strand is left to K8
+    uint32_t flags;                     // bit per read: it is left to K8 (both strands)
     uint32_t pad[3];
 };
 
@@ -2566,18 +2571,19 @@ __device__ __forceinline__ uint32_t byte_tops(uint32_t m) {
 #ifndef SLAMEM_SEED_WAVES
 #define SLAMEM_SEED_WAVES 1
 #endif
-template <bool kStats, uint32_t NW>
+template <bool kStats, uint32_t NW, uint32_t R>
 __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs A, uint8_t* __restrict__ alive) {
     constexpr uint32_t kMaxLen = 64u * NW;
-    __shared__ SeedWave<NW> lds[4];
+    static_assert(R <= 32u && R * NW <= 128u, "a flag word holds a bit per read; the planes step runs in at most two passes");
+    __shared__ SeedWave<NW, R> lds[4];
     const IndexView& ix = A.ix;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    SeedWave<NW>& S = lds[wv];
+    SeedWave<NW, R>& S = lds[wv];
     const uint32_t strands = A.strands, k = ix.seed_k, L = A.min_len, s = L - k + 1u;
     const uint32_t kmask = (1u << k) - 1u, tb = 2u * k - ix.seed_log2, tagmask = (1u << tb) - 1u;
-    const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wv) * kSeedReads;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wv) * R;
     if (r0 >= (uint64_t)A.num_queries) return;
-    const uint32_t nr = (uint64_t)A.num_queries - r0 < kSeedReads ? (uint32_t)((uint64_t)A.num_queries - r0) : kSeedReads;
+    const uint32_t nr = (uint64_t)A.num_queries - r0 < R ? (uint32_t)((uint64_t)A.num_queries - r0) : R;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int64_t ulast = (int64_t)text_units(ix.n) - 1;
     uint32_t n_win = 0, n_cmp = 0, n_nm = 0, n_mem = 0;
@@ -2593,12 +2599,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         if (len >= L) nwin = (len - k) / s + 1u;
         if (nwin > 64u) { left = true; nwin = 0; }
     }
-    uint32_t wflags = 0;  // wave-uniform part of the flags
-    {
-        uint32_t m = (uint32_t)__ballot(left) & 0xFFFFu;
-        m = (m | (m << 8)) & 0x00FF00FFu; m = (m | (m << 4)) & 0x0F0F0F0Fu; m = (m | (m << 2)) & 0x33333333u; m = (m | (m << 1)) & 0x55555555u;
-        wflags = m | (m << 1);
-    }
+    uint32_t wflags = (uint32_t)__ballot(left);  // wave-uniform part of the flags (a bit per read)
     if (lane == 0u) S.flags = 0u;
     const uint32_t plen = nwin ? len : 0u;
     // The wave's reads lie next to each other in the query buffer: all their 16-byte chunks are fetched at once into LDS (a few
@@ -2609,7 +2610,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     const uint64_t span1 = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)nr), (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)nr));
     const uint64_t chunk0 = span0 >> 4;
     const uint32_t nchunks = span1 > span0 ? (uint32_t)(((span1 - 1u) >> 4) - chunk0 + 1u) : 0u;
-    const bool staged = nchunks <= kSeedReads * NW * 4u + 1u;
+    const bool staged = nchunks <= R * NW * 4u + 1u;
     if (staged) {
         const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + chunk0;
         for (uint32_t c = lane; c < nchunks; c += 64u) S.raw[c] = src[c];
@@ -2619,12 +2620,12 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     // words with whole-word bit operations -- the letters' 2-bit codes are bits 1 and 2 of their ASCII bytes ((c >> 1) & 3 = x,
     // code = x ^ (x >> 1): A,C,G,T = 0..3), gathered four letters at a time.  (One letter per lane and three ballots per 64
     // letters of ONE read, the first form of this step, took 3.0 of the kernel's 6.8 ms on the headline batch.)
-    if (lane < kSeedReads) S.bad[lane] = 0u;
+    if (lane < R) S.bad[lane] = 0u;
     wave_sync();
     const uint32_t* rawwords = reinterpret_cast<const uint32_t*>(S.raw);
     const uint32_t* qw32 = reinterpret_cast<const uint32_t*>(A.qwords);
     const uint64_t qlast32 = A.query_words * 2u - 1u;
-    constexpr uint32_t kRawLast = (kSeedReads * NW * 4u + 1u) * 4u - 1u;
+    constexpr uint32_t kRawLast = (R * NW * 4u + 1u) * 4u - 1u;
     for (uint32_t pb = 0; pb < nr * NW; pb += 64u) {
         const uint32_t pp = pb + lane, i = pp / NW, j = pp % NW;
         const bool on = pp < nr * NW;
@@ -2686,14 +2687,12 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     }
     {   // a letter that is not A,C,G,T (N equals N in the reference, A.1): the index walk knows how
         const bool isbad = lane < nr && plen != 0u && S.bad[lane] != 0u;
-        uint32_t m = (uint32_t)__ballot(isbad) & 0xFFFFu;
-        m = (m | (m << 8)) & 0x00FF00FFu; m = (m | (m << 4)) & 0x0F0F0F0Fu; m = (m | (m << 2)) & 0x33333333u; m = (m | (m << 1)) & 0x55555555u;
-        wflags |= m | (m << 1);
+        wflags |= (uint32_t)__ballot(isbad);
         if (isbad) nwin = 0;
         if (lane < nr) { S.len[lane] = nwin ? len : 0u; S.nwin[lane] = nwin; }
     }
     if (lane == 0u)
-        for (uint32_t i = nr; i < kSeedReads; i++) { S.len[i] = 0u; S.nwin[i] = 0u; }
+        for (uint32_t i = nr; i < R; i++) { S.len[i] = 0u; S.nwin[i] = 0u; }
     wave_sync();
     // ---- which windows are looked up, and when ----------------------------------------------------------------------------
     // Two rounds when the windows lie close (mstep > 1).  Round A looks up every mstep-th window of a read and compares its hits;
@@ -2705,7 +2704,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     // by the first of those (forward offset); one that holds none, in round B by its first window.
     const uint32_t mstep = A.seed_step ? A.seed_step : s <= 6u ? 3u : s <= 12u ? 2u : 1u;
     const uint32_t lmod = mstep == 3u ? lane % 3u : mstep == 2u ? (lane & 1u) : 0u;
-    if (lane < kSeedReads) S.expl[lane] = 0ull;
+    if (lane < R) S.expl[lane] = 0ull;
     uint32_t njobs = 0, nmems = 0;
 
     // ---- lookups of one trip: one lane per window (ent = read << 8 | window): the seed table line of its canonical form ----
@@ -2742,7 +2741,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         // more than twelve k-mers in the bucket: up to sixteen more in the spill list (looked at behind the twelve)
         const uint32_t xn = act && (count & kSeedSpilled) ? (count >> 24) & 0x1Fu : 0u, xo = (count & 0xFFFFFFu) << 2;
         if (act && count > kSeedSlots && !(count & kSeedSpilled)) {
-            atomicOr(&S.flags, 3u << (2u * rs));
+            atomicOr(&S.flags, 1u << rs);
             if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 1u, 1ull);
             hits = 0;
         }
@@ -2769,7 +2768,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             const bool job = hv && !(pn && pp1 == ((w << 1) | st));
             const unsigned long long qb = __ballot(job);
             const uint32_t at = njobs + (uint32_t)__popcll(qb & below);
-            if (job && at < SeedWave<NW>::kJobs) {
+            if (job && at < SeedWave<NW, R>::kJobs) {
                 S.job_p[at] = p;
                 S.job_x[at] = (st ? Lr - k - o : o) | (st << 15) | (rs << 16);
             }
@@ -2802,8 +2801,8 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 if (__ballot(hv && both) != 0ull) push(hv && both, p, 1u);
             }
         }
-        if (njobs > SeedWave<NW>::kJobs) {  // (many repeated windows) every read of this trip is left to K8
-            if (act) atomicOr(&S.flags, 3u << (2u * rs));
+        if (njobs > SeedWave<NW, R>::kJobs) {  // (many repeated windows) every read of this trip is left to K8
+            if (act) atomicOr(&S.flags, 1u << rs);
             if (kStats && lane == 0u) atomicAdd(A.stats + SC_SEED_WHY + 3u, 1ull);
             njobs = njobs0;
         }
@@ -2899,7 +2898,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                     owner = !(mstep > 1u && oa + k <= bf) && !(of >= s && of - s >= af);
                 }
                 if (broken) {  // (cannot happen: the table is exact) -- leave the strand to K8
-                    atomicOr(&S.flags, 1u << (2u * jr + st));
+                    atomicOr(&S.flags, 1u << jr);
                     if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 4u, 1ull);
                 }
                 else if (owner && b - a >= L) {
@@ -2943,8 +2942,8 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             const unsigned long long mb = __ballot(is_mem);
             if (is_mem) {
                 const uint32_t at = nmems + (uint32_t)__popcll(mb & below);
-                if (at < SeedWave<NW>::kMems) { S.mem_key[at] = key; S.mem_ref[at] = ref; S.mem_sig[at] = sig | ((2u * jr + st) << 25); }
-                else { atomicOr(&S.flags, 1u << (2u * jr + st)); if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 5u, 1ull); }
+                if (at < SeedWave<NW, R>::kMems) { S.mem_key[at] = key; S.mem_ref[at] = ref; S.mem_sig[at] = sig | ((2u * jr + st) << 25); }
+                else { atomicOr(&S.flags, 1u << jr); if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 5u, 1ull); }
             }
             nmems += (uint32_t)__popcll(mb);
         }
@@ -2970,7 +2969,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     }
 #endif
     {
-        if (nmems > SeedWave<NW>::kMems) nmems = SeedWave<NW>::kMems;
+        if (nmems > SeedWave<NW, R>::kMems) nmems = SeedWave<NW, R>::kMems;
 
         // ---- phase 3: the strands' MEMs in the reference's emission order ------------------------------------------------
         // rank of a MEM = MEMs of its strand that come before it (greater start, or equal start and greater length; same start
@@ -3024,7 +3023,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             return bad;
         };
         auto emit_mem = [&](uint32_t fl, uint32_t key, uint32_t ref, uint32_t gb, uint32_t rank, uint32_t cnt) {
-            if ((fl >> gb) & 1u) return;
+            if ((fl >> (gb >> 1)) & 1u) return;
             const uint32_t g = g0 + (strands == 2u ? gb : gb >> 1);
             emit3_at(A, g, rank, 0u, ref, key >> 16, (key & 0xFFFFu) | 0x80000000u);  // bit 31: ref_pos is the text position (K9)
             if (rank == 0u) A.block_counts[g] = cnt;
@@ -3034,7 +3033,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             const bool has = lane < nmems;
             const uint32_t key = has ? S.mem_key[lane] : 0u, ref = has ? S.mem_ref[lane] : 0u, g = has ? S.mem_sig[lane] >> 25 : 0xFFFFFFFFu;
             // the MEMs of a strand find each other through a mask per strand (a strand has a few, the wave's list some forty)
-            if (lane < 32u) S.smask[lane] = 0ull;
+            if (lane < 2u * R) S.smask[lane] = 0ull;
             wave_sync();
             if (has) atomicOr(&S.smask[g], 1ull << lane);
             wave_sync();
@@ -3049,7 +3048,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 tie = tie || kk == key;
             }
             if (has && tie && tie_rank(lane, key, g, S.mem_sig[lane], rank)) {
-                atomicOr(&S.flags, 1u << g);
+                atomicOr(&S.flags, 1u << (g >> 1));
                 if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 6u, 1ull);
             }
             wave_sync();
@@ -3065,7 +3064,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                     bool tie;
                     rank_of(mi, key, g, rank, cnt, tie);
                     const bool bad = has && tie && tie_rank(mi, key, g, S.mem_sig[mi], rank);
-                    if (!pass) { if (bad) atomicOr(&S.flags, 1u << g); }
+                    if (!pass) { if (bad) atomicOr(&S.flags, 1u << (g >> 1)); }
                     else if (has) emit_mem(fl, key, ref, g, rank, cnt);
                 }
                 wave_sync();
@@ -3076,7 +3075,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     const uint32_t fl = S.flags | wflags;
     {   // the strands left to K8: their flags, and their numbers appended to K8's work list (the list's order is the order the
         // waves end in: it decides which lane scans a strand, never what is reported for it)
-        const bool isleft = lane < nr * strands && ((fl >> (strands == 2u ? lane : 2u * lane)) & 1u) != 0u;
+        const bool isleft = lane < nr * strands && ((fl >> (strands == 2u ? lane >> 1 : lane)) & 1u) != 0u;
         if (lane < nr * strands) alive[r0 * strands + lane] = isleft ? 1 : 0;
         const unsigned long long lm = __ballot(isleft);
         if (lm != 0ull) {
@@ -3094,10 +3093,8 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             atomicAdd(A.stats + SC_SEED_COMPARES, (unsigned long long)n_cmp);
             atomicAdd(A.stats + SC_SEED_READS, (unsigned long long)nr);
             atomicAdd(A.stats + SC_SEED_QBYTES, (unsigned long long)(__builtin_amdgcn_readlane((int)(uint32_t)off, (int)nr) - __builtin_amdgcn_readlane((int)(uint32_t)off, 0)));
-            uint32_t lf = 0;
-            for (uint32_t i = 0; i < nr * strands; i++) lf += (fl >> (strands == 2u ? i : 2u * i)) & 1u;
-            atomicAdd(A.stats + SC_SEED_LEFT, (unsigned long long)lf);
-            atomicAdd(A.stats + SC_SEED_WHY + 0u, (unsigned long long)__popc(wflags & 0x55555555u));  // reads left before any lookup: too long, or a letter that is not A,C,G,T (and trips whose compares did not fit)
+            atomicAdd(A.stats + SC_SEED_LEFT, (unsigned long long)(strands * (uint32_t)__popc(fl)));
+            atomicAdd(A.stats + SC_SEED_WHY + 0u, (unsigned long long)__popc(wflags));  // reads left before any lookup: too long, or a letter that is not A,C,G,T (and trips whose compares did not fit)
         }
     }
 }
@@ -3600,15 +3597,15 @@ int SearchJob::prep(hipStream_t stream) {
             uint32_t* d_nwork = reinterpret_cast<uint32_t*>(d_total) + 8;  // a word of the zeroed scalar block
             A.seed_left_ids = d_ids;
             A.seed_left_count = d_nwork;
-            const dim3 gs(grid_for((uint64_t)num_queries, 4 * kSeedReads));
-            // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: six)
             const bool long_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLen;
+            const dim3 gs(grid_for((uint64_t)num_queries, 4 * (long_reads ? kSeedReadsLong : kSeedReads)));
+            // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: six)
             if (long_reads) {
-                if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 6>), gs, dim3(256), 0, stream, A, d_alive);
-                else hipLaunchKernelGGL((k_seed_mems<false, 6>), gs, dim3(256), 0, stream, A, d_alive);
+                if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 6, kSeedReadsLong>), gs, dim3(256), 0, stream, A, d_alive);
+                else hipLaunchKernelGGL((k_seed_mems<false, 6, kSeedReadsLong>), gs, dim3(256), 0, stream, A, d_alive);
             } else {
-                if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 3>), gs, dim3(256), 0, stream, A, d_alive);
-                else hipLaunchKernelGGL((k_seed_mems<false, 3>), gs, dim3(256), 0, stream, A, d_alive);
+                if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 3, kSeedReads>), gs, dim3(256), 0, stream, A, d_alive);
+                else hipLaunchKernelGGL((k_seed_mems<false, 3, kSeedReads>), gs, dim3(256), 0, stream, A, d_alive);
             }
             STEP(hipGetLastError(), "k_seed_mems");
             (void)hipEventRecord(ev[3], stream);
