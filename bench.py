@@ -371,6 +371,9 @@ def main():
                               "HBM peak as the contract defines it",
                 "kernel_ms": r["seed_ms"], "lines_64B": s_lines, "lines_per_s": s_lines / s_s,
                 "random_line_ceiling_per_s": ceiling, "request_rate_frac": (s_lines / s_s / ceiling) if ceiling else None,
+                "request_rate_note": "lines the lanes ask for (two per compare: many of those are served by L2 / Infinity Cache -- "
+                                     "the text units are 50 MB) over the probed ceiling of dependent random lines from HBM: at "
+                                     "or above 1 the kernel is at that ceiling; the fabric's own count is TCC_EA0_RDREQ in profiles/",
                 "lines_per_query_base": s_lines / bases, "windows_per_read": st["seed_windows"] / max(1, st["seed_reads"]),
                 "compares_per_read": st["seed_compares"] / max(1, st["seed_reads"]),
                 "strands_left_to_index_walk": st["seed_strands_left"], "index_walk": walk, "counters": st,

@@ -2813,7 +2813,9 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         uint32_t cnt = 0;
         for (uint32_t r = 0; r <= nr; r++) {  // (r == nr: what is left in the ring)
             if (r < nr) {
-                const uint32_t nw = S.nwin[r];
+                // (a read that is left to K8 already -- a bucket beyond the spill list, lists that ran over: repeat families do
+                //  that -- asks for nothing more)
+                const uint32_t nw = ((S.flags >> r) & 1u) ? 0u : S.nwin[r];
                 const bool pred = lane < nw && (round == 0u ? lmod == 0u : lmod != 0u && ((S.expl[r] >> lane) & 1ull) == 0ull);
                 const unsigned long long pm = __ballot(pred);
                 if (pred) S.ring[cnt + (uint32_t)__popcll(pm & below)] = (uint16_t)((r << 8) | lane);
@@ -2837,10 +2839,12 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     auto compares = [&](uint32_t round) {
         const bool mark = round == 0u && mstep > 1u;
         const uint32_t ms = mstep * s;
+        const uint32_t gone = S.flags;  // reads that are left to K8 already: their compares are not made
         for (uint32_t jb = 0; jb < njobs; jb += 64u) {
-            const bool has = jb + lane < njobs;
-            const uint32_t p = has ? S.job_p[jb + lane] : 0u, xx = has ? S.job_x[jb + lane] : 0u;
+            const bool listed = jb + lane < njobs;
+            const uint32_t p = listed ? S.job_p[jb + lane] : 0u, xx = listed ? S.job_x[jb + lane] : 0u;
             const uint32_t os = xx & 0x7FFFu, st = (xx >> 15) & 1u, jr = xx >> 16;
+            const bool has = listed && ((gone >> jr) & 1u) == 0u;
             const uint32_t Lj = S.len[jr];
             const int64_t d = (int64_t)p - (int64_t)os;   // text position of the strand's first letter
             const int64_t u0 = d >> 6;

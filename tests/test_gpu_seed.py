@@ -384,6 +384,26 @@ def test_one_round_and_two_rounds_of_lookups_agree(eng, l, monkeypatch):
         g.close()
 
 
+def test_spill_list_runs_full(eng):
+    """The spill list holds n/16 + 64 entries: 40 words of 60 letters in 14 copies each ask for more (some 1,900 buckets of 14+
+    k-mers, four entries each).  The buckets that still fit are read from the list, the others count as "more than fit" and
+    their strands go to the index walk: same MEMs either way."""
+    rng = np.random.default_rng(59)
+    n = 100_000
+    t = rng.choice(ACGT, size=n)
+    words = [rng.choice(ACGT, size=60) for _ in range(40)]
+    spots = rng.choice(np.arange(100, n - 100, 70), size=40 * 14, replace=False)
+    for i, x in enumerate(spots):
+        t[int(x):int(x) + 60] = words[i // 14]
+    qs = reads_from(rng, t, 600, 150, 0.02)
+    for i, w in enumerate(words):
+        r = np.concatenate([rng.choice(ACGT, size=30), w, rng.choice(ACGT, size=40)])
+        qs.insert(15 * i, r if i % 2 else rc(r))
+    st, om = check(eng, t, qs, 20, True)
+    assert st["seed_left_why"][1] > 0 and 0 < st["seed_strands_left"] < st["items"], st["seed_left_why"]
+    assert len(om) > 40 * 14
+
+
 def test_satellite_fills_its_buckets(eng):
     """A tandem array (one unit 2,000 times) puts thousands of positions into the buckets of its k-mers (count 13 = more than
     fit): reads from it, and reads that merely share one window with it, are left to the index walk; the others are not."""
