@@ -2995,7 +2995,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         // A deeper interval exists iff another match of the strand covers [a, b] and more to the right; a row lies above it iff
         // its text letter behind the match is smaller than the strand's; rows compare as the text behind their matches does.
         // Adds the tied MEMs that come before this one to rank; true: not decidable from kSigLetters letters (the strand is left to K8)
-        auto tie_rank = [&](uint32_t mi, uint32_t key, uint32_t g, uint32_t sig, uint32_t& rank) -> bool {
+        auto tie_rank = [&](uint32_t mi, uint32_t key, uint32_t myref, uint32_t g, uint32_t sig, uint32_t& rank) -> bool {
             const uint32_t a = key >> 16, b = a + (key & 0xFFFFu);
             bool child = false;
             for (uint32_t t2 = 0; t2 < nmems; t2++) {
@@ -3006,20 +3006,27 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             uint32_t qb = 0;
             if (child) qb = (uint32_t)((S.pl[jr][st][0][b >> 6] >> (b & 63u)) & 1ull) | ((uint32_t)((S.pl[jr][st][1][b >> 6] >> (b & 63u)) & 1ull) << 1);
             auto letter = [&](uint32_t sg, uint32_t t) { return ((sg >> t) & 1u) | (((sg >> (t + kSigLetters)) & 1u) << 1); };
+            // copies that go on alike for all the letters kept (long repeats): the rows themselves, from the text-ordered records
+            // (the full layout has them: TextRec::row of a text position is the row of the suffix that starts there)
+            const bool rows = ix.prec != nullptr;
             const uint32_t my_side = child && letter(sig, 0u) > qb ? 1u : 0u;
-            bool bad = (sig & kSigKnown) == 0u;
+            bool bad = (sig & kSigKnown) == 0u && (child || !rows);  // (which side of the child interval: the letter behind the match says)
             for (uint32_t t2 = 0; t2 < nmems; t2++) {
                 const uint32_t so = S.mem_sig[t2];
                 if (t2 == mi || (so >> 25) != g || S.mem_key[t2] != key) continue;
-                if ((so & kSigKnown) == 0u) { bad = true; continue; }
+                const bool known = (so & sig & kSigKnown) != 0u;
+                if (!known && (child || !rows)) { bad = true; continue; }
                 const uint32_t o_side = child && letter(so, 0u) > qb ? 1u : 0u;
                 bool before;
                 if (o_side != my_side) before = o_side == 0u;
                 else {
-                    const uint32_t x = sig ^ so, diff = (x | (x >> kSigLetters)) & kSigMask;
-                    if (diff == 0u) { bad = true; continue; }
-                    const uint32_t t = (uint32_t)__ffs((int)diff) - 1u;
-                    const bool smaller = letter(so, t) < letter(sig, t);
+                    const uint32_t x = sig ^ so, diff = known ? (x | (x >> kSigLetters)) & kSigMask : 0u;
+                    bool smaller;
+                    if (diff != 0u) {
+                        const uint32_t t = (uint32_t)__ffs((int)diff) - 1u;
+                        smaller = letter(so, t) < letter(sig, t);
+                    } else if (rows) smaller = ix.prec[S.mem_ref[t2]].row < ix.prec[myref].row;
+                    else { bad = true; continue; }
                     before = my_side == 0u ? smaller : !smaller;
                 }
                 rank += before ? 1u : 0u;
@@ -3051,7 +3058,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 rank += kk > key ? 1u : 0u;
                 tie = tie || kk == key;
             }
-            if (has && tie && tie_rank(lane, key, g, S.mem_sig[lane], rank)) {
+            if (has && tie && tie_rank(lane, key, ref, g, S.mem_sig[lane], rank)) {
                 atomicOr(&S.flags, 1u << (g >> 1));
                 if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 6u, 1ull);
             }
@@ -3067,7 +3074,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                     uint32_t rank, cnt;
                     bool tie;
                     rank_of(mi, key, g, rank, cnt, tie);
-                    const bool bad = has && tie && tie_rank(mi, key, g, S.mem_sig[mi], rank);
+                    const bool bad = has && tie && tie_rank(mi, key, ref, g, S.mem_sig[mi], rank);
                     if (!pass) { if (bad) atomicOr(&S.flags, 1u << (g >> 1)); }
                     else if (has) emit_mem(fl, key, ref, g, rank, cnt);
                 }

@@ -194,8 +194,9 @@ def test_letters_that_are_not_acgt(eng):
 
 def test_windows_that_occur_several_times_and_ties(eng):
     """Segments of the text in 2, 3, 5, 13 and 40 exact copies and reads from them: every copy is a hit of every window (up to
-    12 per bucket; beyond, the strand is left to the index walk), equal-length MEMs with equal starts tie and need the suffix
-    order (left to the index walk), nested repeats give MEMs with equal starts and different lengths (ranked here)."""
+    12 per bucket + the spill list; beyond, the strand is left to the index walk), equal-length MEMs with equal starts tie and
+    need the suffix order (from the text behind them, or the rows of the text-ordered records when the copies go on alike),
+    nested repeats give MEMs with equal starts and different lengths."""
     rng = np.random.default_rng(17)
     n = 300_000
     t = rng.choice(ACGT, size=n)
@@ -216,8 +217,9 @@ def test_windows_that_occur_several_times_and_ties(eng):
             a = int(rng.integers(0, len(seg) - 100))
             r = mutate(rng, seg[a:a + 100 + int(rng.integers(0, min(50, len(seg) - a - 100) + 1))], 0.01)
             qs.append(rc(r) if rng.random() < 0.5 else r)
-    st, _ = check(eng, t, qs, 20, True, min_left=20)
-    assert st["seed_mems"] > 1500 and st["seed_left_why"][6] > 0  # copies that go on alike behind the match: not decided here
+    st, _ = check(eng, t, qs, 20, True)
+    # (copies that go on alike behind the match for more letters than a compare keeps: ordered by their rows, TextRec::row)
+    assert st["seed_mems"] > 1500 and st["seed_left_why"][6] == 0, st["seed_left_why"]
 
 
 def test_ties_are_ordered_as_the_rows_of_the_suffix_array(eng):
