@@ -20,6 +20,7 @@
 #include "prims.h"
 
 #include <atomic>
+#include <type_traits>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
@@ -2531,7 +2532,9 @@ struct SeedWave {
             uint32_t mem_sig[kMems];
         };
     };
-    uint32_t bad[R];                    // the read holds a letter that is not A,C,G,T
+    uint32_t bad[R];                    // the read holds a letter that is not A,C,G,T (and the text holds such letters too)
+    uint64_t pn[R][NW + 1];             // forward strand, bit per letter: not A,C,G,T (a text without such letters: it agrees with nothing)
+    uint32_t hasn;                      // some read of the wave has such a letter
     unsigned long long expl[R];         // bit per window of a read: its only occurrence in the text is accounted for (round A)
     union {
         uint16_t ring[128];             // window ids (read << 8 | window) waiting for a full trip
@@ -2621,6 +2624,11 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     // code = x ^ (x >> 1): A,C,G,T = 0..3), gathered four letters at a time.  (One letter per lane and three ballots per 64
     // letters of ONE read, the first form of this step, took 3.0 of the kernel's 6.8 ms on the headline batch.)
     if (lane < R) S.bad[lane] = 0u;
+    if (lane == 0u) S.hasn = 0u;
+    // a text without a letter that is not A,C,G,T (ArenaHeader::num_n = 0): such a letter of a READ agrees with nothing (N equals
+    // only N, A.1), so no MEM holds it -- its windows are not looked up, its positions disagree in every compare, and the read
+    // stays here; with such letters in the text a MEM may span one (N against N), and the read goes to the index walk
+    const bool text_pure = ix.num_n == 0u;
     wave_sync();
     const uint32_t* rawwords = reinterpret_cast<const uint32_t*>(S.raw);
     const uint32_t* qw32 = reinterpret_cast<const uint32_t*>(A.qwords);
@@ -2662,11 +2670,25 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             }
             S.pl[i][0][0][j] = u64_of(p0lo, p0hi);
             S.pl[i][0][1][j] = u64_of(p1lo, p1hi);
-            if (bad) S.bad[i] = 1u;
+            uint32_t nlo = 0, nhi = 0;
+            if (bad && text_pure) {  // (rare) which letters: the same gather over the "not one of A,C,G,T" bits
+#pragma unroll
+                for (uint32_t t = 0; t < 16u; t++) {
+                    const uint32_t d = __builtin_amdgcn_alignbyte(w[t + 1u], w[t], sh8);
+                    const uint32_t nb = nv > 4u * t ? (nv - 4u * t < 4u ? nv - 4u * t : 4u) : 0u;
+                    const uint32_t M = nb >= 4u ? 0x01010101u : (0x01010101u & ((1u << (8u * nb)) - 1u));
+                    const uint32_t B0 = d, B1 = d >> 1, B2 = d >> 2, B3 = d >> 3, B4 = d >> 4, B6 = d >> 6, B7 = d >> 7;
+                    const uint32_t X = ~(B6 & ~B7 & ~B3 & ((~B4 & B0 & (~B2 | B1)) | (B4 & B2 & ~B1 & ~B0))) & M;
+                    const uint32_t G = (X | (X >> 7) | (X >> 14) | (X >> 21)) & 0xFu;
+                    if (t < 8u) nlo |= G << (4u * t); else nhi |= G << (4u * (t - 8u));
+                }
+                S.hasn = 1u;
+            } else if (bad) S.bad[i] = 1u;
+            S.pn[i][j] = u64_of(nlo, nhi);
         } else if (on) {
-            S.pl[i][0][0][j] = 0ull; S.pl[i][0][1][j] = 0ull;
+            S.pl[i][0][0][j] = 0ull; S.pl[i][0][1][j] = 0ull; S.pn[i][j] = 0ull;
         }
-        if (on && j == 0u) { S.pl[i][0][0][NW] = 0ull; S.pl[i][0][1][NW] = 0ull; S.pl[i][1][0][NW] = 0ull; S.pl[i][1][1][NW] = 0ull; }
+        if (on && j == 0u) { S.pl[i][0][0][NW] = 0ull; S.pl[i][0][1][NW] = 0ull; S.pl[i][1][0][NW] = 0ull; S.pl[i][1][1][NW] = 0ull; S.pn[i][NW] = 0ull; }
     }
     wave_sync();
     // reverse strand: letter x of it is the complement (both plane bits flipped) of letter Li-1-x: the bit-reversed planes
@@ -2704,9 +2726,14 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     // by the first of those (forward offset); one that holds none, in round B by its first window.
     const uint32_t mstep = A.seed_step ? A.seed_step : s <= 6u ? 3u : s <= 12u ? 2u : 1u;
     const uint32_t lmod = mstep == 3u ? lane % 3u : mstep == 2u ? (lane & 1u) : 0u;
+    const bool wave_hasn = __builtin_amdgcn_readfirstlane((int)S.hasn) != 0;
     if (lane < R) S.expl[lane] = 0ull;
     uint32_t njobs = 0, nmems = 0;
 
+    // (the lookups and the compares in two forms, chosen per wave: with the code for reads that hold a letter which is not
+    //  A,C,G,T, and without it -- merely compiling that code into the one form cost the headline batch 3.7 %)
+    auto search = [&](auto with_n) {
+    constexpr bool hasn = decltype(with_n)::value;
     // ---- lookups of one trip: one lane per window (ent = read << 8 | window): the seed table line of its canonical form ----
     auto trip = [&](uint32_t ent, bool act, uint32_t step) {
         const uint32_t rs = ent >> 8, wi = ent & 0xFFu;
@@ -2714,6 +2741,10 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         const uint32_t o = wi * s;
         uint32_t want = 0, pal = 0;
         uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0, b3 = b0;
+        if (hasn && act) {  // a window that holds a letter which is not A,C,G,T occurs nowhere in the text: no lookup
+            const uint64_t* PN = S.pn[rs];
+            if (((uint32_t)funnel64(PN[o >> 6], PN[(o >> 6) + 1u], o & 63u) & kmask) != 0u) act = false;
+        }
         if (act) {
             const uint32_t q = o >> 6, sh = o & 63u;
             const uint64_t* P0 = S.pl[rs][0][0];
@@ -2873,6 +2904,21 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 for (int w = 0; w < (int)NW; w++)
                     mm[w] = (funnel64(u64_of(tu[w].x, tu[w].y), u64_of(tu[w + 1].x, tu[w + 1].y), sh) ^ R0[w]) |
                             (funnel64(u64_of(tu[w].z, tu[w].w), u64_of(tu[w + 1].z, tu[w + 1].w), sh) ^ R1[w]) | funnel64(nu[w], nu[w + 1], sh);
+                if (hasn) {  // the strand's letters that are not A,C,G,T disagree with whatever they face
+                    const uint64_t* PN = S.pn[jr];
+                    if (st == 0u) {
+#pragma unroll
+                        for (int w = 0; w < (int)NW; w++) mm[w] |= PN[w];
+                    } else {  // (the reverse strand: the forward plane bit-reversed, come down by 64 * NW - length letters)
+                        const uint32_t shn = kMaxLen - Lj, qn = shn >> 6, rn = shn & 63u;
+#pragma unroll
+                        for (int w = 0; w < (int)NW; w++) {
+                            const uint32_t x = (uint32_t)w + qn;
+                            const uint64_t lo64 = x < NW ? __brevll(PN[NW - 1u - x]) : 0ull, hi64 = x + 1u < NW ? __brevll(PN[NW - 2u - x]) : 0ull;
+                            mm[w] |= funnel64(lo64, hi64, rn);
+                        }
+                    }
+                }
                 // letters that face no text letter, or lie behind the strand, disagree
                 const int lo = d < 0 ? (int)(-d) : 0;
                 const int64_t room = (int64_t)ix.n - d;
@@ -2954,24 +3000,13 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         wave_sync();
     };
 
-#ifdef SLAMEM_SEED_DIAG_STOP   // (timing experiments only: wrong results) 0: planes only; 1: + round A lookups; 2: + its compares; 3: + round B lookups; 4: + its compares (no ranking)
-#define DIAG_OUT() do { if (lane < nr * strands) alive[r0 * strands + lane] = 0; return; } while (0)
-    if (SLAMEM_SEED_DIAG_STOP == 0) DIAG_OUT();
-    njobs = 0; lookups(0u);
-    if (SLAMEM_SEED_DIAG_STOP == 1) DIAG_OUT();
-    compares(0u);
-    if (SLAMEM_SEED_DIAG_STOP == 2) DIAG_OUT();
-    njobs = 0; lookups(1u);
-    if (SLAMEM_SEED_DIAG_STOP == 3) DIAG_OUT();
-    compares(1u);
-    if (SLAMEM_SEED_DIAG_STOP == 4) DIAG_OUT();
-#else
     for (uint32_t round = 0; round < (mstep > 1u ? 2u : 1u); round++) {
         njobs = 0;
         lookups(round);
         compares(round);
     }
-#endif
+    };
+    if (wave_hasn) search(std::true_type{}); else search(std::false_type{});
     {
         if (nmems > SeedWave<NW, R>::kMems) nmems = SeedWave<NW, R>::kMems;
 

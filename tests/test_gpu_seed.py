@@ -192,6 +192,33 @@ def test_letters_that_are_not_acgt(eng):
     assert st["seed_letter_masks"] > 0 and st["seed_strands_left"] >= 2 * (len(qs) // 9)
 
 
+@pytest.mark.parametrize("length,l,both", [(150, 20, True), (150, 20, False), (250, 25, True), (36, 18, True)])
+def test_letters_that_are_not_acgt_in_reads_on_a_text_without_them(eng, length, l, both):
+    """A text of A,C,G,T only: N (and every other letter the loader turns into N) in a READ agrees with nothing, so no MEM holds
+    it -- the seed path keeps the read (windows with such a letter are not looked up, its positions disagree in every compare, on
+    both strands), where a text WITH such letters sends it to the index walk.  One to many such letters per read, at the ends, in
+    runs, next to matches that are barely long enough; lower case beside them."""
+    rng = np.random.default_rng(71 + length)
+    n = 150_000
+    t = rng.choice(ACGT, size=n)
+    qs = reads_from(rng, t, 1200, length, 0.02)
+    for i in range(0, len(qs), 3):
+        q = qs[i].copy()
+        for _ in range(int(rng.integers(1, 5))):
+            x = int(rng.integers(0, length))
+            q[x:x + int(rng.integers(1, 4))] = ord("NRYKMnrwSBDHV"[int(rng.integers(0, 13))])
+        if i % 9 == 0:
+            q[0] = ord("N")
+        if i % 12 == 0:
+            q[-1] = ord("n")
+        qs[i] = q
+    for i in range(1, len(qs), 40):
+        qs[i] = np.frombuffer(qs[i].tobytes().lower(), dtype=np.uint8)
+    st, om = check(eng, t, qs, l, both)
+    assert st["seed_strands_left"] == 0 and st["seed_left_why"][0] == 0, st["seed_left_why"]
+    assert len(om) > len(qs) // 2
+
+
 def test_windows_that_occur_several_times_and_ties(eng):
     """Segments of the text in 2, 3, 5, 13 and 40 exact copies and reads from them: every copy is a hit of every window (up to
     12 per bucket + the spill list; beyond, the strand is left to the index walk), equal-length MEMs with equal starts tie and
