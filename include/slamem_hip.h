@@ -70,8 +70,9 @@ typedef struct {
 
 /* Index layouts (no reference counterpart: the reference has one layout of 3.3 B per letter made for CPU caches,
  * bwtindex.c:33-37 + lcparray.c:46-57; here HBM is spent to cut dependent random reads).
- *   FULL     every section: ~37.5 B per text letter + 16-32 B of presence filter, and for texts below 2^28 letters 16-32 B of
- *            seed table (+ spill list) + the text's bit-planes and occurs-once plane (the seed-and-compare search of reads, ABI 4): 8.3 GB at 100 Mbp, 151 GB at 3.1 Gbp
+ *   FULL     every section: ~37.5 B per text letter + 16-32 B of presence filter + the seed-and-compare sections of the search of
+ *            reads (ABI 4: seed table 16-32 B per letter, 8-16 B for texts of 2^28 letters and more -- there only when the build
+ *            still fits the free HBM with it --, spill list, the text in 32-byte units): 8.3 GB at 100 Mbp, 188 GB at 3.1 Gbp
  *   COMPACT  no text-ordered sections (the search walks the index where it would have compared with the text) and a
  *            presence filter of half the size: ~21.5 B per letter + 8-16 B (3.3 GB at 100 Mbp, 81 GB at 3.1 Gbp); same
  *            results, slower search (DESIGN.md 2 has the measured cost)

@@ -103,7 +103,7 @@ static int header_ok(const ArenaHeader& h, uint64_t bytes) {
     }
     if (h.off_seed || h.off_tpl || h.off_spill) {
         const uint64_t units = text_units(h.n);
-        if (!bad && (h.seed_k < 4 || h.seed_k > 16 || h.seed_log2 < 10 || h.seed_log2 > 30 || 2u * h.seed_k < h.seed_log2 ||
+        if (!bad && (h.seed_k < 4 || h.seed_k > kSeedMaxK || h.seed_log2 < 10 || h.seed_log2 > 30 || 2u * h.seed_k < h.seed_log2 ||
                      2u * h.seed_k - h.seed_log2 > 7u)) bad = "seed table parameters";
         if (!bad) section(h.off_seed, sizeof(SeedBucket) << h.seed_log2, "seed table");
         section(h.off_tpl, units * sizeof(TextPlanes), "text units");

@@ -99,7 +99,7 @@ struct ArenaHeader {
     uint32_t layout;      // 1 = full, 2 = compact (no text-ordered sections, half-size presence filter); 0 in arenas of older builds = full
     uint32_t lcp_ge[10];  // rows whose LCP is >= kLcpGe[i]: how repeat-rich the text is at a given minimum length (all 0 in arenas of older builds: unknown)
     // seed-and-compare sections (version 12; all 0: the index has none)
-    uint32_t seed_k;      // letters of a seed (<= 16)
+    uint32_t seed_k;      // letters of a seed (<= 18; 17 and 18: texts of 2^29 letters and more)
     uint32_t seed_log2;   // log2 of the number of buckets of the seed table
     uint64_t off_seed;    // SeedBucket[1 << seed_log2]   every k-mer of the text over A,C,G,T by its canonical form
     uint64_t off_tpl;     // TextPlanes[text_units(n)]    the text in units of 64 letters: two bit-planes, the letter mask, the occurs-once plane
@@ -164,6 +164,33 @@ __host__ __device__ inline uint32_t seed_mix(uint32_t key, uint32_t bits) {
     x ^= x >> ((bits >> 1) + 1u);
     x = (x * 0xC2B2AE35u) & mask;
     return x;
+}
+// the same for keys of 33 to 36 bits (seeds of 17 and 18 letters: texts of 2^29 letters and more)
+__host__ __device__ inline uint64_t seed_mix64(uint64_t key, uint32_t bits) {
+    const uint64_t mask = (1ull << bits) - 1ull;
+    uint64_t x = key;
+    x = (x * 0x9E3779B97F4A7C15ull) & mask;
+    x ^= x >> (bits >> 1);
+    x = (x * 0xC2B2AE3D27D4EB4Full) & mask;
+    x ^= x >> ((bits >> 1) + 1u);
+    x = (x * 0x165667B19E3779F9ull) & mask;
+    return x;
+}
+constexpr uint32_t kSeedMaxK = 18;
+// A window's k letters (two plane fields) -> its bucket, the tag's hash bits, which of the two forms it is (1: the reverse
+// complement is the canonical one) and whether it is its own reverse complement.  log2b = log2 of the number of buckets.
+__host__ __device__ inline void seed_place(uint32_t f0, uint32_t f1, uint32_t k, uint32_t log2b, uint32_t& bucket, uint32_t& tagbits,
+                                           uint32_t& orient, uint32_t& pal) {
+    const uint32_t r0 = seed_rev_field(f0, k), r1 = seed_rev_field(f1, k), tb = 2u * k - log2b;
+    if (k <= 16u) {
+        const uint32_t x = seed_key(f0, f1, k), y = seed_key(r0, r1, k);
+        const uint32_t h = seed_mix(x < y ? x : y, 2u * k);
+        bucket = h >> tb; tagbits = h & ((1u << tb) - 1u); orient = x > y ? 1u : 0u; pal = x == y ? 1u : 0u;
+    } else {
+        const uint64_t x = (uint64_t)f0 | ((uint64_t)f1 << k), y = (uint64_t)r0 | ((uint64_t)r1 << k);
+        const uint64_t h = seed_mix64(x < y ? x : y, 2u * k);
+        bucket = (uint32_t)(h >> tb); tagbits = (uint32_t)h & ((1u << tb) - 1u); orient = x > y ? 1u : 0u; pal = x == y ? 1u : 0u;
+    }
 }
 
 // What the kernels see (passed by value).

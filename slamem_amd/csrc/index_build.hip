@@ -449,10 +449,10 @@ __global__ void __launch_bounds__(256) k_seed_keys(TextPlanes* __restrict__ tpl,
     uint32_t f0, f1;
     bool once = false;
     if (t < (uint64_t)n && t + k <= (uint64_t)n && text_field(tpl, t, k, f0, f1)) {
-        const uint32_t x = seed_key(f0, f1, k), y = seed_key(seed_rev_field(f0, k), seed_rev_field(f1, k), k);
-        const uint32_t h = seed_mix(x < y ? x : y, 2u * k), tb = 2u * k - log2b;
-        key = ((uint64_t)(h >> tb) << 8) | (uint64_t)(((h & ((1u << tb) - 1u)) << 1) | (x > y ? 1u : 0u));
-        once = x != y;
+        uint32_t bucket, tagbits, orient, pal;
+        seed_place(f0, f1, k, log2b, bucket, tagbits, orient, pal);
+        key = ((uint64_t)bucket << 8) | (uint64_t)((tagbits << 1) | orient);
+        once = pal == 0u;
     }
     const unsigned long long m = __ballot(once);
     if ((threadIdx.x & 63u) == 0u && (t >> 6) < units) tpl[t >> 6].uq = m;  // (every lane of the grid has read its planes: a lane reads units t >> 6 and the next, the word written is neither's p0 / p1 / nm)
@@ -967,6 +967,8 @@ void make_view(slamem_index* idx) {
 //   layout 2 (compact): no text-ordered sections (K8 walks the index where it would have compared with the text) and a
 //                       presence filter of half the size (no (k+2)-mers): ~21.5 B per letter + 8-16 B of filter
 // Environment switches (experiments): SLAMEM_KFILTER=0, SLAMEM_TEXT_SECTIONS=0, SLAMEM_KJUMP=<K>, SLAMEM_KBITS / SLAMEM_SKIP.
+// (build_index_device: 0 when the seed table of a text of 2^28 letters or more does not fit the free HBM beside the build)
+static thread_local int tl_big_seed = 1;
 static void plan_arena(uint32_t n, uint32_t num_n, int layout, ArenaHeader& hdr) {
     const uint64_t R = (uint64_t)n + 1;
     const uint32_t nblocks = (uint32_t)((R + 1 + kFmRows - 1) >> kFmRowsLog2);  // occ(c, <= n) reads offset n+1
@@ -1044,17 +1046,23 @@ static void plan_arena(uint32_t n, uint32_t num_n, int layout, ArenaHeader& hdr)
             hdr.off_kbits = off; off = align_up(off + ((1ull << (2u * k)) >> 3), 256);
         }
     }
-    {   // seed table + text bit-planes (the seed-and-compare path for reads): full layout, texts below 2^28 letters (a seed
-        // is at most 16 letters: beyond, chance occurrences swamp the table); SLAMEM_SEED=0 builds without.  Two to four
-        // k-mers per 12-slot bucket (more than 12 in one bucket: 3e-4 of the buckets at four); k so that the tag fits 7 bits
+    {   // seed table + text units (the seed-and-compare path for reads): full layout; SLAMEM_SEED=0 builds without.  Two to four
+        // k-mers per 12-slot bucket for texts below 2^28 letters (more than 12 in one bucket: 3e-4 of the buckets at four), k so
+        // that the tag fits 7 bits: k = 10 .. 16.  Texts of 2^28 letters and more (round 4: configs[4]'s 3.1 Gbp): four to eight
+        // per bucket (34 GB of table at 3.1 Gbp instead of 69; 0.6 % of the buckets use the spill list) and seeds of 16 to 18
+        // letters -- keys of up to 36 bits -- unless the caller found that the table does not fit beside the build (g_big_seed)
         const char* se = getenv("SLAMEM_SEED");
-        if (!compact && !(se && atoi(se) == 0) && n >= 64u && n < (1u << 28)) {
+        const char* sk = getenv("SLAMEM_SEED_K");  // (tests: seeds of 17 / 18 letters on a small text: as many buckets as the tag needs)
+        const bool big = n >= (1u << 28);
+        if (!compact && !(se && atoi(se) == 0) && n >= 64u && (!big || tl_big_seed)) {
             uint32_t lg = 10;
-            while ((4ull << lg) < (uint64_t)n) lg++;
+            while (((big ? 8ull : 4ull) << lg) < (uint64_t)n) lg++;
             uint32_t k = (lg + 7u) / 2u;
-            if (k > 16u) k = 16u;
-            // (experiments: SLAMEM_SEED_K=<k> asks for shorter seeds -- fewer windows per read, more chance occurrences)
+            if (k > kSeedMaxK) k = kSeedMaxK;
+            if (!big && k > 16u) k = 16u;
+            // (experiments: SLAMEM_SEED=<k> asks for shorter seeds -- fewer windows per read, more chance occurrences)
             if (se && atoi(se) >= 8 && (uint32_t)atoi(se) < k && 2u * (uint32_t)atoi(se) >= lg) k = (uint32_t)atoi(se);
+            if (sk && (atoi(sk) == 17 || atoi(sk) == 18)) { k = (uint32_t)atoi(sk); if (lg < 2u * k - 7u) lg = 2u * k - 7u; }
             hdr.seed_k = k;
             hdr.seed_log2 = lg;
             const uint64_t units = text_units(n);
@@ -1132,6 +1140,20 @@ int build_index_device(const void* text_dev, uint32_t n, int device, hipStream_t
     }
     SLAMEM_HIP(hipSetDevice(device));
     int layout = 0;
+    struct BigSeedReset { ~BigSeedReset() { tl_big_seed = 1; } } big_seed_reset;  // (the estimate calls of other threads' callers see the default)
+    tl_big_seed = 1;
+    if (n >= (1u << 28)) {
+        // the seed table of a text this long (34 GB at 3.1 Gbp) is built only when the full layout's build peak still fits the
+        // free HBM with it (SLAMEM_HBM_BUDGET_GB caps what counts as free; SLAMEM_SEED_BIG=0: never)
+        size_t free_b = 0, total_b = 0;
+        SLAMEM_HIP(hipMemGetInfo(&free_b, &total_b));
+        uint64_t budget = free_b, arena = 0, peak = 0;
+        const char* env = getenv("SLAMEM_HBM_BUDGET_GB");
+        if (env && atof(env) > 0 && (uint64_t)(atof(env) * 1073741824.0) < budget) budget = (uint64_t)(atof(env) * 1073741824.0);
+        estimate_build_bytes(n, 1, &arena, &peak);
+        const char* sb = getenv("SLAMEM_SEED_BIG");
+        if ((sb && atoi(sb) == 0) || peak + (2048ull << 20) > budget) tl_big_seed = 0;
+    }
     {
         int rc = choose_layout(n, layout_arg, &layout);
         if (rc != SLAMEM_OK) return rc;

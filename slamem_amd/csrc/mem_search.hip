@@ -265,7 +265,7 @@ struct __attribute__((aligned(16))) ItemDesc {
 // Implicit items (SearchArgs::implicit_items; a batch of reads on the seed path: no record is cut into slices, item g IS strand
 // block g): the descriptor and the strand's place in the packed copy come from the offsets -- the two tables of 24 bytes per
 // strand that k_item_fill writes (and the scan behind the second) are not made for the few strands K8s leaves.  The place:
-// read q's blocks start at 2 + strands * 2 * (offset / 32 + q) words -- at or behind where the blocks before it end
+// read q's blocks start at 2 + strands * 2 * (offset within the batch / 32 + q) words -- at or behind where the blocks before it end
 // (a strand takes 2 * ceil(len / 32) words), within the pq_bytes the work space reserves.
 __device__ __forceinline__ ItemDesc item_of(const SearchArgs& A, uint64_t it) {
     if (!A.implicit_items) return A.items[it];
@@ -276,7 +276,8 @@ __device__ __forceinline__ ItemDesc item_of(const SearchArgs& A, uint64_t it) {
 __device__ __forceinline__ uint64_t item_pk_of(const SearchArgs& A, uint64_t it, const ItemDesc& d) {
     if (!A.implicit_items) return A.item_pk[it];
     const uint64_t q = A.strands == 2u ? it >> 1 : it;
-    return 2ull + (uint64_t)A.strands * 2ull * ((d.base >> 5) + q) + (uint64_t)(d.slice_rev >> 31) * 2ull * ((d.len + 31u) >> 5);
+    const uint64_t rel = d.base - A.offsets[0];  // (a caller's offsets may start anywhere: slamem_stream_* hands over windows of one array)
+    return 2ull + (uint64_t)A.strands * 2ull * ((rel >> 5) + q) + (uint64_t)(d.slice_rev >> 31) * 2ull * ((d.len + 31u) >> 5);
 }
 
 // Letters of one strand of a query record, read through a window of kBytes (16 or 32) held in registers: aligned
@@ -2583,7 +2584,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     SeedWave<NW, R>& S = lds[wv];
     const uint32_t strands = A.strands, k = ix.seed_k, L = A.min_len, s = L - k + 1u;
-    const uint32_t kmask = (1u << k) - 1u, tb = 2u * k - ix.seed_log2, tagmask = (1u << tb) - 1u;
+    const uint32_t kmask = (1u << k) - 1u;
     const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wv) * R;
     if (r0 >= (uint64_t)A.num_queries) return;
     const uint32_t nr = (uint64_t)A.num_queries - r0 < R ? (uint32_t)((uint64_t)A.num_queries - r0) : R;
@@ -2632,7 +2633,9 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     wave_sync();
     const uint32_t* rawwords = reinterpret_cast<const uint32_t*>(S.raw);
     const uint32_t* qw32 = reinterpret_cast<const uint32_t*>(A.qwords);
-    const uint64_t qlast32 = A.query_words * 2u - 1u;
+    // (the last 4-byte word that may be read: the 8-byte word that holds the batch's last letter ends with it; the offsets may
+    //  start anywhere -- slamem_stream_* hands over windows of one array -- so the batch's end, not its size, says where)
+    const uint64_t qlast32 = ((A.offsets[A.num_queries] + 7ull) >> 3) * 2ull - 1ull;
     constexpr uint32_t kRawLast = (R * NW * 4u + 1u) * 4u - 1u;
     for (uint32_t pb = 0; pb < nr * NW; pb += 64u) {
         const uint32_t pp = pb + lane, i = pp / NW, j = pp % NW;
@@ -2750,11 +2753,10 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
             const uint64_t* P0 = S.pl[rs][0][0];
             const uint64_t* P1 = S.pl[rs][0][1];
             const uint32_t f0 = (uint32_t)funnel64(P0[q], P0[q + 1u], sh) & kmask, f1 = (uint32_t)funnel64(P1[q], P1[q + 1u], sh) & kmask;
-            const uint32_t x = seed_key(f0, f1, k), y = seed_key(seed_rev_field(f0, k), seed_rev_field(f1, k), k);
-            const uint32_t h = seed_mix(x < y ? x : y, 2u * k);
-            want = (h & tagmask) | (x > y ? 0x80u : 0u);
-            pal = x == y ? 1u : 0u;
-            const uint4* B = reinterpret_cast<const uint4*>(ix.seed + (h >> tb));
+            uint32_t bucket, tagbits, orient;
+            seed_place(f0, f1, k, ix.seed_log2, bucket, tagbits, orient, pal);  // (seeds of 17 / 18 letters: 64-bit keys, a wave-uniform branch)
+            want = tagbits | (orient << 7);
+            const uint4* B = reinterpret_cast<const uint4*>(ix.seed + bucket);
             b0 = B[0]; b1 = B[1]; b2 = B[2]; b3 = B[3];
         }
         if (kStats) n_win += (uint32_t)__popcll(__ballot(act));
@@ -2787,16 +2789,17 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         const uint32_t p1 = sel12(b0, b1, b2, e1);
         const uint32_t st1 = (rev >> e1) & 1u;
         const uint32_t dist = step * s;  // letters between the neighbour's window and this one
-        uint32_t pn = 0, pp1 = 0;  // the neighbour's first hit: (position << 1 | strand) + 1, or 0
+        uint32_t pn = 0, pp1 = 0, ps1 = 0;  // the neighbour's first hit: position and strand (positions take all 32 bits at 3.1 Gbp)
         if (dist <= k) {
-            pp1 = __shfl_up(hits ? ((p1 << 1) | st1) : 0xFFFFFFFFu, 1);
+            pp1 = __shfl_up(p1, 1);
+            ps1 = __shfl_up(hits ? st1 : 2u, 1);
             const uint32_t pent = __shfl_up(act ? ent : 0xFFFFFFFFu, 1);
-            pn = (lane == 0u || wi < step || pent != ent - step || pp1 == 0xFFFFFFFFu) ? 0u : 1u;
+            pn = (lane == 0u || wi < step || pent != ent - step || ps1 == 2u) ? 0u : 1u;
         }
         const uint32_t njobs0 = njobs;
         auto push = [&](bool hv, uint32_t p, uint32_t st) {
             const uint32_t w = st ? p + dist : p - dist;
-            const bool job = hv && !(pn && pp1 == ((w << 1) | st));
+            const bool job = hv && !(pn && pp1 == w && ps1 == st);
             const unsigned long long qb = __ballot(job);
             const uint32_t at = njobs + (uint32_t)__popcll(qb & below);
             if (job && at < SeedWave<NW, R>::kJobs) {
@@ -3507,7 +3510,8 @@ int SearchJob::tables(hipStream_t stream) {
     // only the strands it cannot decide (SLAMEM_SEED_SEARCH=0: the prefilter and the index walk for everything)
     // (read per call, not once per process: the tests run both paths in one process)
     const bool use_seed = [] { const char* v = getenv("SLAMEM_SEED_SEARCH"); return !(v && atoi(v) == 0); }();
-    const bool seed_ok = use_seed && match_type == 0 && idx->view.seed && min_len >= idx->view.seed_k + 3u &&
+    // (min_len >= k + 2: at least three letters between two windows -- 59 windows in a strand of 192 letters)
+    const bool seed_ok = use_seed && match_type == 0 && idx->view.seed && min_len >= idx->view.seed_k + 2u &&
                          min_len < 0x8000u && query_bytes <= (uint64_t)num_queries * kSeedMaxLenLong;
     uint32_t slices = slices_hint;
     const bool ask = slices_hint == 0xFFFFFFFFu;

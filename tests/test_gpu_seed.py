@@ -79,7 +79,7 @@ def check(eng, text, qs, l, both, expect_seed=True, max_left_frac=None, min_left
         st = seed_stats(eng, g, q, off, l, both)
         assert st["mems"] == len(om)
         if expect_seed:
-            assert g.info.seed_k >= 4 and l >= g.info.seed_k + 3
+            assert g.info.seed_k >= 4 and l >= g.info.seed_k + 2
             assert st["seed_reads"] == len(qs), "the seed path did not take this batch"
             assert st["survivors"] <= st["seed_strands_left"]  # (what K8 scans: the strands left, less those the presence filter proves empty)
             if max_left_frac is not None:
@@ -393,7 +393,7 @@ def test_one_round_and_two_rounds_of_lookups_agree(eng, l, monkeypatch):
     om, obc = po.OracleIndex(t.tobytes()).match_batch(q, off, l, True)
     g = eng.Index.build(t.tobytes())
     try:
-        assert l >= g.info.seed_k + 3
+        assert l >= g.info.seed_k + 2
         lookups = {}
         for step in ("1", "2", "3", ""):
             if step:
@@ -411,6 +411,77 @@ def test_one_round_and_two_rounds_of_lookups_agree(eng, l, monkeypatch):
         assert lookups[""] <= lookups["1"]
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("k,l", [(17, 19), (17, 24), (18, 20), (18, 31)])
+def test_seeds_of_17_and_18_letters(eng, k, l, monkeypatch):
+    """Texts of 2^29 letters and more take seeds of 17 / 18 letters: keys of 34 / 36 bits, hashed with 64-bit arithmetic (a
+    second form of seed_place), text positions that use all 32 bits.  SLAMEM_SEED_K forces such seeds on a small text (the
+    table then has as many buckets as the 7-bit tag needs: 8.6 / 34 GB of mostly empty lines); minimum lengths from k + 2
+    (three letters between two windows); repeats, palindromes and ties as in the other cases."""
+    monkeypatch.setenv("SLAMEM_SEED_K", str(k))
+    rng = np.random.default_rng(300 + k + l)
+    n = 400_000
+    t = rng.choice(ACGT, size=n)
+    for copies, length, div in [(3, 400, 0.0), (5, 200, 0.02), (12, 80, 0.0)]:
+        x = int(rng.integers(0, n - length))
+        seg = t[x:x + length].copy()
+        for _ in range(copies - 1):
+            y = int(rng.integers(0, n - length))
+            t[y:y + length] = mutate(rng, seg, div) if div else seg
+    for i in range(20):
+        half = rng.choice(ACGT, size=k // 2 + 2)
+        pal = np.concatenate([half, rc(half)])
+        y = int(rng.integers(0, n - 60))
+        t[y:y + len(pal)] = pal
+    qs = reads_from(rng, t, 1500, 150, 0.02) + reads_from(rng, t, 300, 60, 0.0) + reads_from(rng, t, 100, 192, 0.05)
+    st, om = check(eng, t, qs, l, True)
+    assert st["seed_k"] == k and st["seed_strands_left"] <= 64, st["seed_left_why"]
+    assert len(om) > 1500
+
+
+def test_windows_of_one_offset_array_and_waves_that_do_not_fit_the_staging_buffer(eng):
+    """slamem_stream_submit hands the search windows of ONE offsets array (a batch's offsets start anywhere, its letters lie
+    behind the same base pointer), and a wave whose 21 reads are longer together than the staging buffer reads its letters from
+    global memory: the last word it may touch is the batch's last, wherever the batch starts.  Reads of 30-384 letters mixed so
+    that many waves are of that kind, four batches, both the letters and the bit-planes form of the upload."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(83)
+    n = 200_000
+    t = rng.choice(ACGT, size=n)
+    qs = []
+    for i in range(1200):
+        qs += reads_from(rng, t, 1, int(rng.integers(30, 385)) if i % 3 else 150, 0.02)
+    q, off = pack(qs)
+    chars = np.frombuffer(q, dtype=np.uint8) if not isinstance(q, np.ndarray) else q
+    o = po.OracleIndex(t.tobytes())
+    idx = eng.Index.build(t.tobytes())
+    per = 300
+    st = eng.Stream(idx, 3, 1 << 18, per, True)
+    keep = []
+    try:
+        for packed in (False, True):
+            for b in range(len(qs) // per):
+                w = off[b * per: (b + 1) * per + 1]
+                if packed:
+                    units = int(((np.diff(w) + 63) // 64).sum())
+                    pl = eng.PinnedBuffer(units * 16 + 64)
+                    ot = np.zeros(units + 1, dtype=np.uint64)
+                    assert eng.pack_reads(chars, w, pl.array, ot, threads=2) == units
+                    keep.append(pl)
+                    st.submit_packed(pl.array, None, w, 20, units=units)
+                else:
+                    st.submit(chars, w, 20)
+                m, boff, _ = st.next()
+                om, obc = o.match_batch(chars[int(w[0]): int(w[-1])], w - w[0], 20, True)
+                assert np.array_equal(np.diff(boff.astype(np.int64)), obc.astype(np.int64)), (packed, b)
+                for f in ("ref_pos", "query_pos", "length"):
+                    assert np.array_equal(m[f], om[f]), (packed, b, f)
+    finally:
+        st.close()
+        for pl in keep:
+            pl.close()
+        idx.close()
 
 
 def test_spill_list_runs_full(eng):

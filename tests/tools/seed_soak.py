@@ -3,7 +3,8 @@ diverged copies of short and long segments, tandem arrays, reverse-complement co
 A,C,G,T in the text or only in the reads, read lengths (fixed or mixed, up to 384), substitution rate, minimum length, one or
 both strands -- the engine's answer on the default path (K8s, K8 for what it leaves) must equal, row for row in order, its
 answer with SLAMEM_SEED_SEARCH=0 (the prefilter and the index walk, which the test suites pin to the oracle), and the oracle's
-own answer on the smaller cases (checker only).  Prints one JSON line per case and a summary; exits 1 on the first difference.
+own answer on the smaller cases (checker only); in a third of the cases the reads also go through slamem_stream_submit in
+windows of the one offsets array, batch by batch.  Prints one JSON line per case and a summary; exits 1 on the first difference.
 
     python tests/tools/seed_soak.py [seconds] [first_seed]
 """
@@ -119,7 +120,7 @@ def one(seed):
     g = engine.Index.build(t.tobytes())
     try:
         k = int(g.info.seed_k)
-        lo = k + 3 if k else 12
+        lo = k + 2 if k else 12
         l = int(rng.integers(lo, lo + 12)) if rng.random() < 0.7 else int(rng.integers(lo, 70))
         step = os.environ.get("SLAMEM_SEED_STEP")
         if rng.random() < 0.25:
@@ -137,6 +138,25 @@ def one(seed):
         else:
             os.environ["SLAMEM_SEED_STEP"] = step
         ok = np.array_equal(so, wo) and all(np.array_equal(sm[f], wm[f]) for f in ("ref_pos", "query_pos", "length"))
+        streamed = False
+        if ok and rng.random() < 0.3 and len(qs) >= 8:
+            # the same reads through slamem_stream_submit in windows of the one offsets array (offsets that do not start at 0)
+            streamed = True
+            strands = 2 if both else 1
+            cuts = sorted(set([0, len(qs)] + [int(x) for x in rng.integers(1, len(qs), size=int(rng.integers(1, 4)))]))
+            maxq = max(int(off[cuts[i + 1]] - off[cuts[i]]) for i in range(len(cuts) - 1))
+            stx = engine.Stream(g, 2, maxq + 64, max(cuts[i + 1] - cuts[i] for i in range(len(cuts) - 1)), both)
+            try:
+                wcnt = np.diff(wo.astype(np.int64))
+                for i in range(len(cuts) - 1):
+                    w = np.ascontiguousarray(off[cuts[i]: cuts[i + 1] + 1])
+                    stx.submit(q, w, l)
+                    m2, b2, _ = stx.next()
+                    lo, hi = int(wo[cuts[i] * strands]), int(wo[cuts[i + 1] * strands])
+                    ok = ok and np.array_equal(np.diff(b2.astype(np.int64)), wcnt[cuts[i] * strands: cuts[i + 1] * strands]) and all(
+                        np.array_equal(m2[f], wm[f][lo:hi]) for f in ("ref_pos", "query_pos", "length"))
+            finally:
+                stx.close()
         checked_oracle = False
         if ok and n <= 300_000 and len(qs) <= 2500:
             u = np.frombuffer(q.tobytes().upper(), dtype=np.uint8).copy()
@@ -147,7 +167,7 @@ def one(seed):
             checked_oracle = True
         rec = {"seed": seed, "n": n, "kinds": kinds, "text_n": bool(text_n), "reads": nreads, "fixed_len": fixed, "long": bool(long_reads),
                "sub": sub, "reads_n": bool(reads_n), "both": bool(both), "l": l, "seed_k": k, "step": forced, "mems": int(len(sm)),
-               "oracle": checked_oracle, "ok": bool(ok)}
+               "oracle": checked_oracle, "stream": streamed, "ok": bool(ok)}
         print(json.dumps(rec), flush=True)
         return ok, len(sm)
     finally:
