@@ -2727,8 +2727,11 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     // looks up what is left: the windows with an error in them and the repeats (headline batch: 27 windows a read, 72 % of
     // them free of errors: 9 lookups in round A, 5-6 in round B).  A match that holds a round-A window is reported in round A
     // by the first of those (forward offset); one that holds none, in round B by its first window.
-    const uint32_t mstep = A.seed_step ? A.seed_step : s <= 6u ? 3u : s <= 12u ? 2u : 1u;
-    const uint32_t lmod = mstep == 3u ? lane % 3u : mstep == 2u ? (lane & 1u) : 0u;
+    // (as many windows apart as still overlap or touch, k / s -- 3 on the headline, 6 for 18-letter seeds at -l 20 -- and at
+    //  least every second one while the windows lie within 12 letters of each other)
+    const uint32_t mfit = k / s > 6u ? 6u : k / s;
+    const uint32_t mstep = A.seed_step ? A.seed_step : mfit >= 3u ? mfit : s <= 12u ? 2u : 1u;
+    const uint32_t lmod = lane - mstep * ((lane * (65536u / mstep + 1u)) >> 16);  // lane % mstep (lane < 64, mstep <= 6)
     const bool wave_hasn = __builtin_amdgcn_readfirstlane((int)S.hasn) != 0;
     if (lane < R) S.expl[lane] = 0ull;
     uint32_t njobs = 0, nmems = 0;
@@ -3638,9 +3641,9 @@ int SearchJob::prep(hipStream_t stream) {
             }
             STEP(hipMemsetAsync(d_counts, 0, nitems * 4, stream), "memset");
             STEP(hipMemsetAsync(A.item_attempt, 0, nitems, stream), "memset");
-            {   // (experiments) SLAMEM_SEED_STEP=1|2|3: the stride of the first round's windows (1: one round, every window)
+            {   // (experiments) SLAMEM_SEED_STEP=1..6: the stride of the first round's windows (1: one round, every window)
                 const char* v = getenv("SLAMEM_SEED_STEP");
-                A.seed_step = v && atoi(v) >= 1 && atoi(v) <= 3 ? (uint32_t)atoi(v) : 0u;
+                A.seed_step = v && atoi(v) >= 1 && atoi(v) <= 6 ? (uint32_t)atoi(v) : 0u;
             }
             // K8s writes K8's work list itself (no pass over 20 M flags for the handful it leaves)
             uint32_t* d_ids = reinterpret_cast<uint32_t*>(ws + w.off_workids);

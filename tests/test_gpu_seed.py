@@ -395,7 +395,7 @@ def test_one_round_and_two_rounds_of_lookups_agree(eng, l, monkeypatch):
     try:
         assert l >= g.info.seed_k + 2
         lookups = {}
-        for step in ("1", "2", "3", ""):
+        for step in ("1", "2", "3", "4", "6", ""):
             if step:
                 monkeypatch.setenv("SLAMEM_SEED_STEP", step)
             else:
@@ -407,7 +407,7 @@ def test_one_round_and_two_rounds_of_lookups_agree(eng, l, monkeypatch):
             st = seed_stats(eng, g, q, off, l, True)
             assert st["seed_reads"] == len(qs) and st["mems"] == len(om)
             lookups[step] = st["seed_windows"]
-        assert lookups["2"] < lookups["1"] and lookups["3"] < lookups["1"]  # (fewer lines to fetch is the point)
+        assert max(lookups[x] for x in ("2", "3", "4", "6")) < lookups["1"]  # (fewer lines to fetch is the point)
         assert lookups[""] <= lookups["1"]
     finally:
         g.close()

@@ -124,7 +124,7 @@ def one(seed):
         l = int(rng.integers(lo, lo + 12)) if rng.random() < 0.7 else int(rng.integers(lo, 70))
         step = os.environ.get("SLAMEM_SEED_STEP")
         if rng.random() < 0.25:
-            os.environ["SLAMEM_SEED_STEP"] = str(int(rng.integers(1, 4)))
+            os.environ["SLAMEM_SEED_STEP"] = str(int(rng.integers(1, 7)))
         else:
             os.environ.pop("SLAMEM_SEED_STEP", None)
         forced = os.environ.get("SLAMEM_SEED_STEP", "")
