@@ -211,8 +211,8 @@ def test_cli_n_gpu_schedule_on_logical_gpus(tmp_path):
 
 def test_cli_back_to_back_large_runs(tmp_path):
     """Two large jobs in a row on one GPU.  The first runs with SLAMEM_DETACH_TEARDOWN=1 (returns when its results are
-    written; its worker still holds the 135 GB index, here for 12 more seconds: SLAMEM_TEST_LINGER_MS); the second starts
-    at once, needs a 197 GB build peak on the 288 GiB (309 GB) device, and must WAIT for the memory instead of failing
+    written; its worker still holds the 164 GB index, here for 7 more seconds: SLAMEM_TEST_LINGER_MS); the second starts
+    at once, needs a 225 GB build peak (197 without the seed table) on the 288 GiB (309 GB) device, and must WAIT for the memory instead of failing
     (wait_for_hbm in host/main.c; the reference frees before it reports, slamem.c:208-216).  Both exit 0 with identical
     output files.  2.7 Gbp text, 100,000 reads, -b -l 20."""
     import time
@@ -235,7 +235,7 @@ def test_cli_back_to_back_large_runs(tmp_path):
     cmd = lambda o: [exe, "-b", "-l", "20", "-o", os.path.join(d, o), os.path.join(d, "ref.fa"), os.path.join(d, "qry.fa")]
     t0 = time.time()
     r1 = subprocess.run(cmd("o1.txt"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
-                        env=dict(os.environ, SLAMEM_DETACH_TEARDOWN="1", SLAMEM_TEST_LINGER_MS="12000"))
+                        env=dict(os.environ, SLAMEM_DETACH_TEARDOWN="1", SLAMEM_TEST_LINGER_MS="7000"))
     t1 = time.time()
     r2 = subprocess.run(cmd("o2.txt"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     t2 = time.time()
@@ -247,7 +247,7 @@ def test_cli_back_to_back_large_runs(tmp_path):
     assert os.path.getsize(os.path.join(d, "o1.txt")) > 1_000_000
     try:
         with open(os.path.join(hostlib.ROOT, "gpurun_out", "back_to_back.txt"), "a") as f:
-            f.write(f"2.7 Gbp, 100k reads: first run (detached teardown, worker lingers 12 s) returned after {t1 - t0:.2f} s; "
+            f.write(f"2.7 Gbp, 100k reads: first run (detached teardown, worker lingers 7 s) returned after {t1 - t0:.2f} s; "
                     f"second run (default: returns when its memory is back) {t2 - t1:.2f} s; stderr of the second: "
                     f"{r2.stderr.decode(errors='replace').strip()}\n")
     except OSError:
