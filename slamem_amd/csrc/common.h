@@ -112,7 +112,7 @@ struct ArenaHeader {
     uint64_t off_tuq;     // 0 (the occurs-once plane lies in the units)
 };
 // thresholds of ArenaHeader::lcp_ge
-__host__ __device__ constexpr uint32_t kLcpGe[10] = {18, 20, 25, 30, 40, 50, 75, 100, 150, 255};
+constexpr uint32_t kLcpGe[10] = {18, 20, 25, 30, 40, 50, 75, 100, 150, 255};
 static_assert(sizeof(ArenaHeader) <= kHeaderBytes, "header too large");
 
 // ---- seed-and-compare sections (no reference counterpart) ---------------------------------------------------------

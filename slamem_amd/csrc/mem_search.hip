@@ -851,7 +851,6 @@ __device__ __forceinline__ void emit_provisional(const SearchArgs& A, uint32_t g
 // keep the mark the whole list is filled with before the launch (block 0xFFFFFFFF), K9 skips them.  It is a separate
 // instantiation because the headline kernel's register allocation does not survive the extra code (+2.4 ms of 20.9).
 constexpr uint32_t kOvfChunk = 128;
-constexpr uint32_t kOvfHole = 0xFFFFFFFFu;
 template <bool kCarry, bool kChunk>
 __device__ __forceinline__ uint32_t wave_emit_step(const SearchArgs& A, bool old, uint32_t lane, uint32_t g, uint32_t k, uint32_t tag,
                                                    bool ok, uint32_t row, uint32_t pos, uint32_t len,
@@ -1001,39 +1000,6 @@ __device__ __forceinline__ uint32_t wave_enumerate_merged(const SearchArgs& A, b
 }
 
 // ---- K8e: the queue of deferred enumeration jobs (kDefer) -------------------------------------------------------------------
-// One step of a queued job: the rows the wave reports go to the list (never to inline slots: the strand's MEM numbers are
-// provisional), places reserved kOvfChunk at a time as in wave_emit_step<*, true>
-__device__ __forceinline__ uint32_t wave_emit_queued(const SearchArgs& A, uint32_t lane, uint32_t g, uint32_t k, bool ok, uint32_t row,
-                                                     uint32_t pos, uint32_t len, uint32_t segabs, unsigned long long& ovf_base,
-                                                     uint32_t& ovf_left) {
-    const unsigned long long m = __ballot(ok);
-    if (m == 0ull) return k;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const uint32_t need = (uint32_t)__popcll(m);
-    if (ovf_left < need) {  // (wave-uniform) a new chunk; what is left of the old one stays marked as unused
-        const uint32_t chunk = need > kOvfChunk ? need : kOvfChunk;
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned long long base = 0ull;
-        if ((int)lane == leader) base = atomicAdd(A.total, (unsigned long long)chunk);
-        ovf_base = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader),
-                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader));
-        ovf_left = chunk;
-    }
-    if (ok) {
-        const uint32_t kk = k + (uint32_t)__popcll(m & below);
-        if (kk >> 28) atomicOr(reinterpret_cast<unsigned int*>(A.total) + 9, 1u);
-        const unsigned long long slot = ovf_base + (unsigned long long)__popcll(m & below);
-        if (slot < A.capacity) {
-            A.raw_key[slot] = RawKey{g, kk};
-            A.raw_mem[slot] = slamem_mem{row, pos, len};  // ref_pos holds the ROW until K9
-            A.defer.raw_seg[slot] = segabs;
-        }
-    }
-    ovf_base += need;
-    ovf_left -= need;
-    return k + need;
-}
-
 // Every wave of the chip takes jobs from the queue, FOUR at a time: a group of 16 lanes per job.  A job is a chain of levels (the
 // interval, then its ancestors down to min_len: one memory round trip each), and on a repeat-rich text most rows of a level
 // are NOT reported -- the copies of a family mostly agree on the letter to the left -- so the rows are not looked at one per
