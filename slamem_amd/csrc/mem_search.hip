@@ -2697,8 +2697,15 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     //  least every second one while the windows lie within 12 letters of each other)
     const uint32_t mfit = k / s > 6u ? 6u : k / s;
     const uint32_t mstep = A.seed_step ? A.seed_step : mfit >= 3u ? mfit : s <= 12u ? 2u : 1u;
-    const uint32_t lmod = lane - mstep * ((lane * (65536u / mstep + 1u)) >> 16);  // lane % mstep (lane < 64, mstep <= 6)
+
     const bool wave_hasn = __builtin_amdgcn_readfirstlane((int)S.hasn) != 0;
+    uint32_t lg_slots = 0;  // lanes a read takes in the queueing of its windows: the power of two that holds the most windows of a read of the wave
+    {
+        const uint32_t nwl = lane < nr ? S.nwin[lane] : 0u;
+#pragma unroll
+        for (uint32_t t = 1, lg = 1; t <= 32u; t <<= 1, lg++)
+            if (__ballot(nwl > t) != 0ull) lg_slots = lg;
+    }
     if (lane < R) S.expl[lane] = 0ull;
     uint32_t njobs = 0, nmems = 0;
 
@@ -2814,17 +2821,23 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     auto lookups = [&](uint32_t round) {
         const uint32_t step = round == 0u ? mstep : 1u;
         uint32_t cnt = 0;
-        for (uint32_t r = 0; r <= nr; r++) {  // (r == nr: what is left in the ring)
+        // (as many reads an iteration as fit the wave with a power of two of lanes each: two of the headline's, 27 windows a read,
+        //  sixteen at -l 50, 4 windows a read)
+        const uint32_t per = 64u >> lg_slots, wi = lane & ((1u << lg_slots) - 1u);
+        const uint32_t wmod = wi - mstep * ((wi * (65536u / mstep + 1u)) >> 16);  // wi % mstep (wi < 64, mstep <= 6)
+        for (uint32_t r = 0;; r += per) {
             if (r < nr) {
+                const uint32_t rr = r + (lane >> lg_slots);
                 // (a read that is left to K8 already -- a bucket beyond the spill list, lists that ran over: repeat families do
                 //  that -- asks for nothing more)
-                const uint32_t nw = ((S.flags >> r) & 1u) ? 0u : S.nwin[r];
-                const bool pred = lane < nw && (round == 0u ? lmod == 0u : lmod != 0u && ((S.expl[r] >> lane) & 1ull) == 0ull);
+                const uint32_t nw = (rr >= nr || ((S.flags >> rr) & 1u)) ? 0u : S.nwin[rr];
+                const bool pred = wi < nw && (round == 0u ? wmod == 0u : wmod != 0u && ((S.expl[rr] >> wi) & 1ull) == 0ull);
                 const unsigned long long pm = __ballot(pred);
-                if (pred) S.ring[cnt + (uint32_t)__popcll(pm & below)] = (uint16_t)((r << 8) | lane);
+                if (pred) S.ring[cnt + (uint32_t)__popcll(pm & below)] = (uint16_t)((rr << 8) | wi);
                 cnt += (uint32_t)__popcll(pm);
             }
-            if (cnt >= 64u || (r == nr && cnt != 0u)) {
+            const bool last = r >= nr;  // (what is left in the ring)
+            if (cnt >= 64u || (last && cnt != 0u)) {
                 wave_sync();
                 const bool act = lane < cnt;
                 const uint32_t ent = act ? S.ring[lane] : 0u;
@@ -2834,6 +2847,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 cnt = cnt > 64u ? cnt - 64u : 0u;
                 trip(ent, act, step);
             }
+            if (last) break;
         }
         wave_sync();
     };
