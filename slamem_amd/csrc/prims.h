@@ -24,6 +24,8 @@ hipError_t scan_max_inclusive_u32(void* tmp, size_t& tmp_bytes, const uint32_t* 
 // out[i] = sum_{j<i} in[j]  (u32 in, u64 out); out has n+1 entries, out[n] = total.
 hipError_t scan_sum_exclusive_u32_u64(void* tmp, size_t& tmp_bytes, const uint32_t* in, uint64_t* out, size_t n,
                                       hipStream_t stream);
+// The same with u64 in: out has n+1 entries, the caller keeps in[n] = 0, out[n] = total.
+hipError_t scan_sum_exclusive_u64(void* tmp, size_t& tmp_bytes, const uint64_t* in, uint64_t* out, size_t n, hipStream_t stream);
 // Four independent exclusive sums over uint4 lanes (FM block rank samples).
 hipError_t scan_sum_exclusive_uint4(void* tmp, size_t& tmp_bytes, const uint4* in, uint4* out, size_t n,
                                     hipStream_t stream);

@@ -207,6 +207,10 @@ hipError_t scan_sum_exclusive_u32_u64(void* tmp, size_t& tmp_bytes, const uint32
     return scan_impl<SumU64, LoadU32As64, LoadU64, false>(tmp, tmp_bytes, LoadU32As64{in}, out, n + 1, stream);
 }
 
+hipError_t scan_sum_exclusive_u64(void* tmp, size_t& tmp_bytes, const uint64_t* in, uint64_t* out, size_t n, hipStream_t stream) {
+    return scan_impl<SumU64, LoadU64, LoadU64, false>(tmp, tmp_bytes, LoadU64{in}, out, n + 1, stream);
+}
+
 hipError_t scan_sum_exclusive_uint4(void* tmp, size_t& tmp_bytes, const uint4* in, uint4* out, size_t n, hipStream_t stream) {
     return scan_impl<SumU4, LoadU4, LoadU4, false>(tmp, tmp_bytes, LoadU4{in}, out, n, stream);
 }
