@@ -1373,6 +1373,9 @@ __global__ void __launch_bounds__(256, (kSkip || kMam || kCarry || kChunk) ? 4 :
     // busy until the list is empty whatever its strands cost -- with a fixed share per wave, lanes idled at the end
     // of every share (measured: 58 % lane use once the direct extension made strand costs uneven).
     const uint32_t nitems = A.work_ids ? *A.work_count : (uint32_t)A.num_items;  // (the host refuses batches near 2^32 items)
+    // (an empty list -- K8s left no strand: every batch of plain reads -- and no lanes to take in: 4,096 waves have nothing to
+    //  queue up for at the cursor's one address)
+    if (!kCarry && !kStats && nitems == 0u) return;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t next = 0, chunk_first = 0, chunk_end = 0;  // wave-uniform: the piece being handed out
     uint32_t seen = 0;                                  // wave-uniform: how far this wave has seen the cursor get
