@@ -193,6 +193,7 @@ struct SearchArgs {
     uint32_t implicit_items;    // v3: 1: no item tables (item_of / item_pk_of)
     uint32_t* seed_left_ids;    // K8s: the strands it leaves to K8 (K8's work list) ...
     unsigned int* seed_left_count;  // ... and their number
+    unsigned int* seed_long_flag;   // K8s sets it when a record is longer than a slice (a call that took the seed path without asking starts again)
     uint32_t seed_step;         // K8s: 0, or the stride of the windows of the first round (experiments: SLAMEM_SEED_STEP)
     const uint64_t* item_pk;    // v3: per work item, the word offset of its strand block in pq
     unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
@@ -2568,6 +2569,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     bool left = false;  // both strands of the read are left to K8
     if (lane < nr) {
         const uint64_t l64 = offn - off;
+        if (l64 > kSliceLen) atomicOr(A.seed_long_flag, 1u);  // (such a record needs slices: what the caller assumed does not hold)
         if (l64 > kMaxLen) left = l64 >= L; else len = (uint32_t)l64;
         if (len >= L) nwin = (len - k) / s + 1u;
         if (nwin > 64u) { left = true; nwin = 0; }
@@ -3458,6 +3460,8 @@ struct SearchJob {
     bool want_stats = false, prefiltered = false, timed_k8 = false, launched = false;
     bool rawkey_marked = false;  // the overflow list already carries its "unused" marks (kChunk)
     bool deferred = false;       // this launch ran K8's kDefer instantiation: k_enum_jobs and k_defer_prefix follow
+    bool speculate = false;  // the caller starts again when a record turns out longer than a slice (saw_long)
+    bool speculated = false, saw_long = false;
     bool seed_path = false;  // tables(): this batch takes the seed path
     bool seeded = false;  // this batch's MEMs come from K8s (k_seed_mems); K8 scans only the strands it left
     bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
@@ -3564,12 +3568,19 @@ int SearchJob::tables(hipStream_t stream) {
     // says that no record is longer than a slice; when it does not, one pass over the lengths says so
     bool counted = false, scanned = false;
     unsigned int* d_most = reinterpret_cast<unsigned int*>(d_total) + 2;  // a word of the zeroed scalar block
-    if (!(seed_ok && !ask && slices == num_queries)) {
+    speculated = false;
+    if (seed_ok && ask && speculate) {
+        // slamem_find_mems_device: take the seed path without asking the device for the longest record first (a kernel and a
+        // round trip in front of every call); K8s says at the end whether some record was longer than a slice, and the call
+        // then starts again the careful way (collect(): saw_long)
+        slices = num_queries;
+        speculated = true;
+    } else if (!(seed_ok && !ask && slices == num_queries)) {
         hipLaunchKernelGGL(k_item_counts, dim3(grid_for((uint64_t)num_queries + 1)), dim3(256), 0, stream, offsets_dev,
                            num_queries, (match_type == 1 && mam_whole_strands()) ? 0u : kSliceLen, d_cnt, d_wps, d_most);
         STEP(hipGetLastError(), "k_item_counts");
         counted = true;
-        if (ask) {
+        if (slices == 0xFFFFFFFFu) {
             unsigned int most = 0;
             STEP(hipMemcpyAsync(&most, d_most, 4, hipMemcpyDeviceToHost, stream), "memcpy");
             STEP(hipStreamSynchronize(stream), "item count (sync)");
@@ -3692,6 +3703,7 @@ int SearchJob::prep(hipStream_t stream) {
             uint32_t* d_nwork = reinterpret_cast<uint32_t*>(d_total) + 8;  // a word of the zeroed scalar block
             A.seed_left_ids = d_ids;
             A.seed_left_count = d_nwork;
+            A.seed_long_flag = reinterpret_cast<unsigned int*>(d_total) + 3;  // a word of the zeroed scalar block
             const bool long_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLen;
             const dim3 gs(grid_for((uint64_t)num_queries, 4 * (long_reads ? kSeedReadsLong : kSeedReads)));
             // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: six)
@@ -4034,6 +4046,8 @@ int SearchJob::collect() {
     const unsigned long long* scal = h_scal;
     const unsigned long long listed = scal[0];  // records in the atomic list
     total = scal[8];                            // all MEMs
+    saw_long = speculated && (uint32_t)(scal[1] >> 32) != 0u;
+    if (saw_long) return SLAMEM_OK;  // (nothing of this run is used: find_mems_device starts again)
     if ((uint32_t)(scal[4] >> 32) != 0u) {
         // (not SLAMEM_ERR_CAPACITY: callers answer that one by asking again with more room)
         set_error("slamem_find_mems_device: one work item emits 2^28 or more MEMs (a 4096-position slice against a highly "
@@ -4104,12 +4118,10 @@ int SearchJob::collect() {
 }
 #undef STEP
 
-int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
-                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
-                     slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
-                     uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out) {
-    if (!total_out) { set_error("slamem_find_mems_device: null argument"); return SLAMEM_ERR_ARG; }
-    SearchJob job;
+static int run_job(SearchJob& job, const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
+                   uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
+                   slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
+                   uint64_t workspace_bytes, hipStream_t stream) {
     int rc = job.init(idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev,
                       mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes);
     if (rc == SLAMEM_OK) rc = job.tables(stream);
@@ -4120,6 +4132,22 @@ int find_mems_device(const slamem_index* idx, const void* queries_dev, const uin
         if (e != hipSuccess && rc == SLAMEM_OK) rc = hip_fail(e, "MEM search (sync)", __FILE__, __LINE__);
     }
     if (rc == SLAMEM_OK) rc = job.collect();
+    return rc;
+}
+int find_mems_device(const slamem_index* idx, const void* queries_dev, const uint64_t* offsets_dev,
+                     uint32_t num_queries, uint64_t query_bytes, uint32_t min_len, int both_strands, int match_type,
+                     slamem_mem* mems_dev, uint64_t mems_capacity, uint64_t* block_offsets_dev, void* workspace_dev,
+                     uint64_t workspace_bytes, hipStream_t stream, uint64_t* total_out) {
+    if (!total_out) { set_error("slamem_find_mems_device: null argument"); return SLAMEM_ERR_ARG; }
+    SearchJob job;
+    job.speculate = true;
+    int rc = run_job(job, idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev,
+                     mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes, stream);
+    if (rc == SLAMEM_OK && job.saw_long) {  // a record longer than a slice among the reads: once more, with the item tables
+        job.speculate = false;
+        rc = run_job(job, idx, queries_dev, offsets_dev, num_queries, query_bytes, min_len, both_strands, match_type, mems_dev,
+                     mems_capacity, block_offsets_dev, workspace_dev, workspace_bytes, stream);
+    }
     *total_out = job.total;
     return rc;
 }

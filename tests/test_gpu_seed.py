@@ -484,6 +484,22 @@ def test_windows_of_one_offset_array_and_waves_that_do_not_fit_the_staging_buffe
         idx.close()
 
 
+def test_a_record_longer_than_a_slice_among_the_reads(eng):
+    """slamem_find_mems_device takes the seed path without asking the device for the longest record first; K8s notices a record
+    that needs slices (more than 4096 letters) and the call starts again with the item tables: the answer is the oracle's, for the
+    long record (cut into slices, scanned by the index walk) and for the reads beside it."""
+    rng = np.random.default_rng(97)
+    n = 150_000
+    t = rng.choice(ACGT, size=n)
+    qs = reads_from(rng, t, 900, 150, 0.02)
+    qs.insert(400, mutate(rng, t[20_000:29_000], 0.01))
+    qs.insert(700, rc(mutate(rng, t[90_000:94_097], 0.02)))  # 4097 letters: one more than a slice
+    st, om = check(eng, t, qs, 20, True, expect_seed=False)
+    assert len(om) > 1500
+    st, om = check(eng, t, [q for q in qs if len(q) <= 4096], 20, True)  # (without them: the seed path, no second start)
+    assert st["seed_strands_left"] == 0
+
+
 def test_spill_list_runs_full(eng):
     """The spill list holds n/16 + 64 entries: 40 words of 60 letters in 14 copies each ask for more (some 1,900 buckets of 14+
     k-mers, four entries each).  The buckets that still fit are read from the list, the others count as "more than fit" and
