@@ -286,6 +286,9 @@ int slamem_char_at_bwt_pos_batch(const slamem_index *idx, const uint32_t *rows_d
  *   total_out         number of MEMs found (also when SLAMEM_ERR_CAPACITY is returned)
  *   limit             a strand (or a 4096-position slice of a long one) may emit fewer than 2^28 MEMs: beyond that the call
  *                     fails with SLAMEM_ERR_ARG and says so (never wrong output)
+ *   passes            a batch of reads is answered in one pass with one host round trip (the total).  The call does not look
+ *                     at the record lengths first: when the batch turns out to hold a record of more than 4096 letters (it
+ *                     needs slices) the work is done again with the item tables -- two passes, same answer
  *
  * Synchronous with respect to the stream on return (it has to read the total). */
 int slamem_find_mems_workspace_bytes(uint32_t num_queries, int both_strands, uint64_t query_bytes,
