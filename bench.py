@@ -242,11 +242,13 @@ def main():
         reads, offsets, count = batch
         matcher = index.matcher(count, both, mems_capacity=4 * count + 1024, query_bytes=count * L)
         counts_all = torch.zeros(world, dtype=torch.int64, device=cdev)
+        count_bufs = (torch.zeros(1, dtype=torch.int64, device=cdev), torch.zeros(world, dtype=torch.int64, device=cdev))
 
         def step():
             nonlocal counts_all
             total = matcher.run(reads, offsets, a.min_len)
-            counts_all = shard.gather_counts(total, cdev)  # final gather of per-rank MEM counts (tiny; no data-path collective)
+            # the per-rank MEM counts, gathered at every step (tiny; no data-path collective; buffers made once)
+            counts_all = shard.gather_counts(total, cdev, buffers=count_bufs)
         for _ in range(warmup):
             step()
         if world > 1:

@@ -66,13 +66,20 @@ def broadcast_arena(arena: torch.Tensor | None, device, src: int = 0, force: boo
     return arena
 
 
-def gather_counts(count: int, device, force: bool = False) -> torch.Tensor:
-    """All ranks learn every rank's MEM count (int64[world])."""
+def gather_counts(count: int, device, force: bool = False, buffers=None) -> torch.Tensor:
+    """All ranks learn every rank's MEM count (int64[world]).  buffers = (mine int64[1], out int64[world]) on `device`: a caller
+    that gathers at every step hands in its own pair and pays no allocation and no host-to-device copy per call."""
     rank, ws = world()
-    mine = torch.tensor([count], dtype=torch.int64, device=device)
+    if buffers is not None:
+        mine, out = buffers
+        mine.fill_(int(count))
+    else:
+        mine = torch.tensor([count], dtype=torch.int64, device=device)
+        out = None
     if ws == 1 and not (force and dist.is_initialized()):
         return mine
-    out = torch.zeros(ws, dtype=torch.int64, device=device)
+    if out is None:
+        out = torch.zeros(ws, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, mine) if device.type == "cuda" else dist.all_gather(list(out.split(1)), mine)
     return out
 
