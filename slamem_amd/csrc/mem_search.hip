@@ -2446,27 +2446,30 @@ __global__ void __launch_bounds__(256) k_prefilter_list(SearchArgs A, const uint
 // ------------------------------------------------------------------------------------------
 // K8s: seed-and-compare -- the search for READS (k_seed_mems)
 // ------------------------------------------------------------------------------------------
-// Replaces, for strands of up to kSeedMaxLen letters, the scan of GetMatches (slamem.c:105-199) AND the prefilter: the
+// Replaces, for strands of up to kSeedMaxLenLong letters, the scan of GetMatches (slamem.c:105-199) AND the prefilter: the
 // output of the scan is the set of all maximal matches of at least L letters, and every such match contains a
 // k-letter window that starts at a multiple of s = L - k + 1 of its strand.  So, per read:
-//   1. every window of the forward strand at a multiple of s is looked up in the seed table by its canonical form: ONE
-//      64-byte line gives every text position of the window AND of its reverse complement -- the window of the reverse
-//      strand that covers the same letters (strand offset len - k - o; those offsets form a residue class mod s too, so the
-//      reverse strand's MEMs all hold one).  One lane per window, every lookup of a read in flight at once: two dependent
-//      memory phases per read instead of the scan's chain of ~100;
+//   1. windows of the forward strand at multiples of s are looked up in the seed table by their canonical form: ONE
+//      64-byte line (and the spill list behind a bucket of 13 to 28 k-mers) gives every text position of the window AND of
+//      its reverse complement -- the window of the reverse strand that covers the same letters (strand offset len - k - o;
+//      those offsets form a residue class mod s too, so the reverse strand's MEMs all hold one).  One lane per window, in two
+//      rounds when the windows lie close: every m-th window first; a window of the other kind that lies inside a run a
+//      first-round compare measured, and whose k-mer occurs once in the text (a plane of the text units), is not looked up;
 //   2. a hit (strand, text position p, strand offset o) is a diagonal d = p - o; the MEM around the window is the run of
-//      agreeing letters on that diagonal: the strand (bit-planes in LDS) XOR the text (bit-planes, four 16-byte units = the
-//      192 letters from d on), one lane per compare.  A MEM is reported by its window with the smallest forward offset (a
-//      hit whose neighbour window hit the same diagonal is dropped before the compare when s <= k);
+//      agreeing letters on that diagonal: the strand (bit-planes in LDS) XOR the text (four 32-byte units = the 192 letters
+//      from d on), one lane per compare.  A run that holds a first-round window is reported by the first of those, one that
+//      holds none by its first window (a hit whose neighbour window hit the same diagonal is dropped before the compare when
+//      the two windows overlap or touch); a window that is its own reverse complement is compared on both strands;
 //   3. the MEMs of a strand are ranked in the reference's emission order -- start descending, then length descending
-//      (slamem.c:114,139-193: the scan runs right to left, a position reports its deepest interval first) -- with wave-wide
-//      comparisons and go to the strand's inline slots / the overflow list with their text position (K9 skips the
-//      suffix-array read for them).
-// Whatever this cannot decide exactly goes to the index walk (K8), strand by strand (alive[] = 1): a letter that is not
-// A,C,G,T in the read, a read longer than kSeedMaxLen (or with more than 64 windows), a bucket with more k-mers than it
-// holds (a repeat: its rows need the suffix order), a palindromic window that hits,
-// two MEMs of a strand with the same start and length (their order is the order of their BWT rows).  Nothing here is
-// approximate: a strand is either reported completely by this kernel or completely by K8.
+//      (slamem.c:114,139-193: the scan runs right to left, a position reports its deepest interval first), MEMs with the same
+//      start and length as the rows of the suffix array lie around the interval the walk came up from (slamem.c:140,165:
+//      from the text letters behind the match, or TextRec::row) -- and go to the strand's inline slots / the overflow list
+//      with their text position (K9 skips the suffix-array read for them).
+// Whatever this cannot decide exactly goes to the index walk (K8), read by read (alive[] = 1 for both strands; their numbers
+// go straight into K8's work list): a letter that is not A,C,G,T in the read when the text holds such letters too (N equals N
+// in the reference: a MEM may span one), a read longer than the planes hold (or with more than 64 windows), a bucket with more
+// than 28 k-mers (a repeat family), lists that run over.  Nothing here is approximate: a read is either reported completely
+// by this kernel or completely by K8.
 #ifndef SLAMEM_SEED_READS
 #define SLAMEM_SEED_READS 21
 #endif
