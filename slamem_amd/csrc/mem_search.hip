@@ -2637,8 +2637,9 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 const uint32_t nb = nv > 4u * t ? (nv - 4u * t < 4u ? nv - 4u * t : 4u) : 0u;
                 const uint32_t M = nb >= 4u ? 0x01010101u : (0x01010101u & ((1u << (8u * nb)) - 1u));
                 const uint32_t B0 = d, B1 = d >> 1, B2 = d >> 2, B3 = d >> 3, B4 = d >> 4, B6 = d >> 6, B7 = d >> 7;
-                // one of A,C,G,T in either case: 0100 0001, 0100 0011, 0100 0111, 0101 0100 with bit 5 free
-                const uint32_t good = B6 & ~B7 & ~B3 & ((~B4 & B0 & (~B2 | B1)) | (B4 & B2 & ~B1 & ~B0));
+                // one of A,C,G,T in either case: 0100 0001, 0100 0011, 0100 0111, 0101 0100 with bit 5 free -- with t = "bits 2,1
+                // are 1,0" (T's), bit 0 is the opposite of t and bit 4 equals it (of the 16 values of bits 4,2,1,0 exactly those four)
+                const uint32_t tt = B2 & ~B1, good = (B0 ^ tt) & ~((B4 ^ tt) | B3 | B7) & B6;
                 bad |= ~good & M;
                 const uint32_t X = ((B1 ^ B2) & M) | ((B2 & M) << 4);
                 const uint32_t G = (X | (X >> 7) | (X >> 14) | (X >> 21)) & 0xFFu;  // plane 0 of the four letters: bits 0-3, plane 1: bits 4-7
@@ -2655,7 +2656,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                     const uint32_t nb = nv > 4u * t ? (nv - 4u * t < 4u ? nv - 4u * t : 4u) : 0u;
                     const uint32_t M = nb >= 4u ? 0x01010101u : (0x01010101u & ((1u << (8u * nb)) - 1u));
                     const uint32_t B0 = d, B1 = d >> 1, B2 = d >> 2, B3 = d >> 3, B4 = d >> 4, B6 = d >> 6, B7 = d >> 7;
-                    const uint32_t X = ~(B6 & ~B7 & ~B3 & ((~B4 & B0 & (~B2 | B1)) | (B4 & B2 & ~B1 & ~B0))) & M;
+                    const uint32_t tt = B2 & ~B1, X = ~((B0 ^ tt) & ~((B4 ^ tt) | B3 | B7) & B6) & M;
                     const uint32_t G = (X | (X >> 7) | (X >> 14) | (X >> 21)) & 0xFu;
                     if (t < 8u) nlo |= G << (4u * t); else nhi |= G << (4u * (t - 8u));
                 }
