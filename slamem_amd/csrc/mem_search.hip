@@ -2475,9 +2475,10 @@ __global__ void __launch_bounds__(256) k_prefilter_list(SearchArgs A, const uint
 #endif
 // reads of a wave in the instantiation for reads of up to 192 letters: 21 x 3 plane words are 63 lanes of work in the planes
 // step, 21 x 9 first-round windows three full trips (at most 32: a flag word holds a bit per read); the long-read form takes 16
-constexpr uint32_t kSeedReads = SLAMEM_SEED_READS, kSeedReadsLong = 16;
+constexpr uint32_t kSeedReads = SLAMEM_SEED_READS, kSeedReadsMid = 16, kSeedReadsLong = 16;
 constexpr uint32_t kSeedMaxLen = 192;   // letters of a strand the planes hold in the instantiation for reads of up to 192 letters (three words)
-constexpr uint32_t kSeedMaxLenLong = 384;  // ... and in the one for longer reads (six words: 2 x 250 bp runs; a batch takes it when its reads average more than 192)
+constexpr uint32_t kSeedMaxLenMid = 256;   // ... in the one for 2 x 250 bp runs (four words: a batch takes it when its reads average 193 .. 256) ...
+constexpr uint32_t kSeedMaxLenLong = 384;  // ... and in the one for longer reads (six words: a batch takes it when its reads average more than 256)
 #ifndef SLAMEM_SEED_JOBS
 #define SLAMEM_SEED_JOBS 16
 #endif
@@ -2490,7 +2491,7 @@ constexpr uint32_t kSigLetters = 12, kSigMask = (1u << kSigLetters) - 1u, kSigKn
 
 template <uint32_t NW, uint32_t R>
 struct SeedWave {
-    static constexpr uint32_t kJobs = kSeedJobs * R * (NW / 3u), kMems = kSeedMems * R * (NW / 3u);  // (longer strands: more windows, more MEMs)
+    static constexpr uint32_t kJobs = kSeedJobs * R * NW / 3u, kMems = kSeedMems * R * NW / 3u;  // (longer strands: more windows, more MEMs)
     uint64_t pl[R][2][2][NW + 1];       // [read][strand][plane][word]; the last word stays 0 (a window's second word)
     uint32_t len[R];                    // letters (0: the read takes no part)
     uint32_t nwin[R];                   // windows
@@ -3708,12 +3709,15 @@ int SearchJob::prep(hipStream_t stream) {
             A.seed_left_ids = d_ids;
             A.seed_left_count = d_nwork;
             A.seed_long_flag = reinterpret_cast<unsigned int*>(d_total) + 3;  // a word of the zeroed scalar block
-            const bool long_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLen;
-            const dim3 gs(grid_for((uint64_t)num_queries, 4 * (long_reads ? kSeedReadsLong : kSeedReads)));
-            // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: six)
+            const bool mid_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLen, long_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLenMid;
+            const dim3 gs(grid_for((uint64_t)num_queries, 4 * (long_reads ? kSeedReadsLong : mid_reads ? kSeedReadsMid : kSeedReads)));
+            // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: four, or six)
             if (long_reads) {
                 if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 6, kSeedReadsLong>), gs, dim3(256), 0, stream, A, d_alive);
                 else hipLaunchKernelGGL((k_seed_mems<false, 6, kSeedReadsLong>), gs, dim3(256), 0, stream, A, d_alive);
+            } else if (mid_reads) {
+                if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 4, kSeedReadsMid>), gs, dim3(256), 0, stream, A, d_alive);
+                else hipLaunchKernelGGL((k_seed_mems<false, 4, kSeedReadsMid>), gs, dim3(256), 0, stream, A, d_alive);
             } else {
                 if (want_stats) hipLaunchKernelGGL((k_seed_mems<true, 3, kSeedReads>), gs, dim3(256), 0, stream, A, d_alive);
                 else hipLaunchKernelGGL((k_seed_mems<false, 3, kSeedReads>), gs, dim3(256), 0, stream, A, d_alive);

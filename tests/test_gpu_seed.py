@@ -115,22 +115,29 @@ def test_reads_on_random_text(eng, n, count, length, l, both, sub):
 
 
 def test_reads_longer_than_the_planes_go_to_the_index_walk(eng):
-    """Two instantiations: three plane words a strand (reads of up to 192 letters) and six (up to 384: a batch whose reads average
-    more than 192 takes it).  In either, a longer read is left to the index walk strand by strand; a batch that averages more
-    than 384 letters does not take the seed path at all."""
+    """Three instantiations: three plane words a strand (reads of up to 192 letters), four (up to 256: a batch whose reads
+    average 193 .. 256 letters takes it, 2 x 250 bp runs) and six (up to 384: a batch that averages more than 256).  In each, a
+    longer read is left to the index walk strand by strand; a batch that averages more than 384 letters does not take the seed
+    path at all."""
     rng = np.random.default_rng(193)
     t = rng.choice(ACGT, size=100_000)
-    st, _ = check(eng, t, reads_from(rng, t, 300, 193, 0.02), 25, True, max_left_frac=0.05)   # six words: nothing is left for its length
+    st, _ = check(eng, t, reads_from(rng, t, 300, 193, 0.02), 25, True, max_left_frac=0.05)   # four words: nothing is left for its length
     st, _ = check(eng, t, reads_from(rng, t, 300, 250, 0.02), 20, True, max_left_frac=0.05)
+    st, _ = check(eng, t, reads_from(rng, t, 300, 256, 0.02), 22, True, max_left_frac=0.05)
+    st, _ = check(eng, t, reads_from(rng, t, 300, 257, 0.02), 22, True, max_left_frac=0.05)   # six words
     st, _ = check(eng, t, reads_from(rng, t, 200, 384, 0.02), 30, True, max_left_frac=0.05)
-    st, _ = check(eng, t, reads_from(rng, t, 100, 500, 0.02), 25, True, expect_seed=False)    # beyond both
+    st, _ = check(eng, t, reads_from(rng, t, 100, 500, 0.02), 25, True, expect_seed=False)    # beyond all three
     qs = reads_from(rng, t, 300, 193, 0.02) + reads_from(rng, t, 900, 100, 0.02) + reads_from(rng, t, 20, 400, 0.02)
     order = rng.permutation(len(qs))
     st, _ = check(eng, t, [qs[i] for i in order], 25, True, min_left=2 * 320)                 # three words (average 128): 193 and 400 are left
     assert st["seed_strands_left"] <= 2 * 320 + 40
-    qs = reads_from(rng, t, 600, 250, 0.02) + reads_from(rng, t, 300, 150, 0.02) + reads_from(rng, t, 40, 385, 0.02) + reads_from(rng, t, 30, 340, 0.02)
+    qs = reads_from(rng, t, 600, 250, 0.02) + reads_from(rng, t, 300, 150, 0.02) + reads_from(rng, t, 40, 385, 0.02) + reads_from(rng, t, 30, 257, 0.02)
     order = rng.permutation(len(qs))
-    st, _ = check(eng, t, [qs[i] for i in order], 20, True, min_left=2 * 40)                  # six words: the reads of 385 letters are left (340: 33 windows at s = 10, stay)
+    st, _ = check(eng, t, [qs[i] for i in order], 20, True, min_left=2 * 70)                  # four words (average 225): 257 and 385 are left
+    assert st["seed_strands_left"] <= 2 * 70 + 60
+    qs = reads_from(rng, t, 600, 300, 0.02) + reads_from(rng, t, 200, 150, 0.02) + reads_from(rng, t, 40, 385, 0.02) + reads_from(rng, t, 30, 340, 0.02)
+    order = rng.permutation(len(qs))
+    st, _ = check(eng, t, [qs[i] for i in order], 20, True, min_left=2 * 40)                  # six words (average 273): the reads of 385 letters are left (340: 33 windows at s = 10, stay)
     assert st["seed_strands_left"] <= 2 * 40 + 60
 
 
@@ -192,7 +199,7 @@ def test_letters_that_are_not_acgt(eng):
     assert st["seed_letter_masks"] > 0 and st["seed_strands_left"] >= 2 * (len(qs) // 9)
 
 
-@pytest.mark.parametrize("length,l,both", [(150, 20, True), (150, 20, False), (250, 25, True), (36, 18, True)])
+@pytest.mark.parametrize("length,l,both", [(150, 20, True), (150, 20, False), (250, 25, True), (300, 25, True), (36, 18, True)])
 def test_letters_that_are_not_acgt_in_reads_on_a_text_without_them(eng, length, l, both):
     """A text of A,C,G,T only: N (and every other letter the loader turns into N) in a READ agrees with nothing, so no MEM holds
     it -- the seed path keeps the read (windows with such a letter are not looked up, its positions disagree in every compare, on
