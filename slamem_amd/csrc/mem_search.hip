@@ -2755,7 +2755,10 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         uint32_t hits = byte_tops(m0) | (byte_tops(m1) << 4) | (byte_tops(m2) << 8);
         const uint32_t rev = byte_tops(x0 & 0x80808080u) | (byte_tops(x1 & 0x80808080u) << 4) | (byte_tops(x2 & 0x80808080u) << 8);
         hits &= count >= kSeedSlots ? 0xFFFu : (1u << count) - 1u;
-        if (strands == 1u) hits &= ~rev;
+        // (one strand asked for: a hit in the other orientation is no MEM -- but in round A its compare still tells which windows
+        //  of the other kind have their only occurrence there, on the strand that is not reported, and need no lookup: half the
+        //  reads of a run come from that strand)
+        if (strands == 1u && step == 1u) hits &= ~rev;
         if (!act) hits = 0;
         // more than twelve k-mers in the bucket: up to sixteen more in the spill list (looked at behind the twelve)
         const uint32_t xn = act && (count & kSeedSpilled) ? (count >> 24) & 0x1Fu : 0u, xo = (count & 0xFFFFFFu) << 2;
@@ -2815,7 +2818,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                 const uint32_t p = q == 0u ? v0.x : q == 1u ? v0.z : q == 2u ? v1.x : v1.z;
                 const uint32_t d = ((q == 0u ? v0.y : q == 1u ? v0.w : q == 2u ? v1.y : v1.w) ^ want) & 0xFFu;
                 const uint32_t st = d >> 7;
-                const bool hv = on && e0 + q < xn && (d & 0x7Fu) == 0u && !(strands == 1u && st);
+                const bool hv = on && e0 + q < xn && (d & 0x7Fu) == 0u && !(strands == 1u && st && step == 1u);
                 if (__ballot(hv) == 0ull) continue;
                 push(hv, p, st);
                 if (__ballot(hv && both) != 0ull) push(hv && both, p, 1u);
@@ -2947,7 +2950,7 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
                     atomicOr(&S.flags, 1u << jr);
                     if (kStats) atomicAdd(A.stats + SC_SEED_WHY + 4u, 1ull);
                 }
-                else if (owner && b - a >= L) {
+                else if (owner && b - a >= L && (strands == 2u || st == 0u)) {  // (one strand asked for: the other's compares only mark windows)
                     is_mem = true; key = (a << 16) | (b - a); ref = (uint32_t)(d + (int64_t)a);
                     // what the text goes on with behind the match: orders MEMs of one strand with the same start and length
                     // (phase 3) as the rows of the suffix array would

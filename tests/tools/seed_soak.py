@@ -6,7 +6,7 @@ answer with SLAMEM_SEED_SEARCH=0 (the prefilter and the index walk, which the te
 own answer on the smaller cases (checker only); in a third of the cases the reads also go through slamem_stream_submit in
 windows of the one offsets array, batch by batch.  Prints one JSON line per case and a summary; exits 1 on the first difference.
 
-    python tests/tools/seed_soak.py [seconds] [first_seed]
+    python tests/tools/seed_soak.py [seconds] [first_seed]        (SOAK_STRANDS=1|2: every case with one strand / both)
 """
 import json
 import os
@@ -114,6 +114,8 @@ def one(seed):
             r = np.frombuffer(r.tobytes().lower(), dtype=np.uint8)
         qs.append(r)
     both = rng.random() < 0.8
+    if os.environ.get("SOAK_STRANDS") in ("1", "2"):  # (a soak of one setting)
+        both = os.environ["SOAK_STRANDS"] == "2"
     q = np.concatenate(qs)
     off = np.zeros(len(qs) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(x) for x in qs])
