@@ -240,7 +240,8 @@ def main():
     def timed(batch, steps, warmup):
         """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
         reads, offsets, count = batch
-        matcher = index.matcher(count, both, mems_capacity=4 * count + 1024, query_bytes=count * L)
+        # (room for the MEMs: 2.4 a read on the default batch; more letters a read, more MEMs)
+        matcher = index.matcher(count, both, mems_capacity=4 * count * max(1, (L + 149) // 150) + 1024, query_bytes=count * L)
         counts_all = torch.zeros(world, dtype=torch.int64, device=cdev)
         count_bufs = (torch.zeros(1, dtype=torch.int64, device=cdev), torch.zeros(world, dtype=torch.int64, device=cdev))
 
