@@ -275,6 +275,10 @@ struct slamem_index {
     int device;
     int owns_arena;
     slamem::IndexView view;
+    // what the last batches searched against this index said about their reads (mem_search.hip: the seed kernel's form is chosen
+    // by a batch's average read length; a batch with many reads longer than that form holds raises this, so that the next
+    // batch takes the wider form): 0, 4 or 6 plane words.  Relaxed atomic access; decides speed only, never an answer.
+    uint32_t seed_words_hint;
 };
 
 namespace slamem {

@@ -194,6 +194,7 @@ struct SearchArgs {
     uint32_t* seed_left_ids;    // K8s: the strands it leaves to K8 (K8's work list) ...
     unsigned int* seed_left_count;  // ... and their number
     unsigned int* seed_long_flag;   // K8s sets it when a record is longer than a slice (a call that took the seed path without asking starts again)
+    unsigned int* seed_wide;        // K8s, over a sample of the reads (256 to 511 blocks of the grid): [0] reads left to K8 for their length that the four-word form holds, [1] that the six-word form holds, [2] set when a read needed this launch's form (longer than the next narrower one holds), [3] reads in the sample
     uint32_t seed_step;         // K8s: 0, or the stride of the windows of the first round (experiments: SLAMEM_SEED_STEP)
     const uint64_t* item_pk;    // v3: per work item, the word offset of its strand block in pq
     unsigned int* work_cursor;  // v3: next unassigned position of the work list (zeroed per launch)
@@ -2578,6 +2579,28 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
         if (len >= L) nwin = (len - k) / s + 1u;
         if (nwin > 64u) { left = true; nwin = 0; }
     }
+#ifndef SLAMEM_SEED_NO_FORM_HINT
+    const uint32_t lg_grid = 31u - (uint32_t)__clz((int)(gridDim.x | 1u));
+    if ((blockIdx.x & ((1u << (lg_grid > 8u ? lg_grid - 8u : 0u)) - 1u)) == 0u) {
+        // What the next batch against this index should know (the form is chosen by the average length: a batch of mixed
+        // lengths may hold many reads beyond it, and each of those costs a walk of the index).  A sample counts -- 256 to 511
+        // blocks spread evenly over the batch, every block of a small one: every wave of the grid adding to one word is a queue
+        // of its own (5 M reads of 250 letters: 13 ms instead of 5).
+        const uint64_t l64 = lane < nr ? offn - off : 0ull;
+        if (lane == 0u) atomicAdd(A.seed_wide + 3, nr);
+        if (NW < 6u) {
+            const bool w4 = NW < 4u && l64 > kMaxLen && l64 <= kSeedMaxLenMid && l64 >= L;
+            const bool w6 = l64 > (kMaxLen > kSeedMaxLenMid ? kMaxLen : kSeedMaxLenMid) && l64 <= kSeedMaxLenLong && l64 >= L;
+            const uint32_t n4 = (uint32_t)__popcll(__ballot(w4)), n6 = (uint32_t)__popcll(__ballot(w6));
+            if (lane == 0u && n4) atomicAdd(A.seed_wide, n4);
+            if (lane == 0u && n6) atomicAdd(A.seed_wide + 1, n6);
+        }
+        if (NW > 3u) {
+            const bool needed = l64 > (NW == 4u ? kSeedMaxLen : kSeedMaxLenMid) && l64 <= kMaxLen;
+            if (__ballot(needed) != 0ull && lane == 0u) A.seed_wide[2] = 1u;  // (every wave that writes, writes the same)
+        }
+    }
+#endif
     uint32_t wflags = (uint32_t)__ballot(left);  // wave-uniform part of the flags (a bit per read)
     if (lane == 0u) S.flags = 0u;
     const uint32_t plen = nwin ? len : 0u;
@@ -3472,6 +3495,7 @@ struct SearchJob {
     bool speculated = false, saw_long = false;
     bool seed_path = false;  // tables(): this batch takes the seed path
     bool seeded = false;  // this batch's MEMs come from K8s (k_seed_mems); K8 scans only the strands it left
+    uint32_t seed_words = 0, seed_words_avg = 0;  // plane words a strand of this batch's K8s launch, and what the average read length alone asks for
     bool mam_v3 = false;  // -mam on a batch without long records: K8's kMam instantiation (set by tables())
     unsigned long long scal_own[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t k8_wave_cap = 0;  // waves of this batch's K8 (0: as many as the chip holds); a pipeline that keeps two K8 launches in flight gives each a part of the chip
@@ -3712,7 +3736,12 @@ int SearchJob::prep(hipStream_t stream) {
             A.seed_left_ids = d_ids;
             A.seed_left_count = d_nwork;
             A.seed_long_flag = reinterpret_cast<unsigned int*>(d_total) + 3;  // a word of the zeroed scalar block
-            const bool mid_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLen, long_reads = query_bytes > (uint64_t)num_queries * kSeedMaxLenMid;
+            A.seed_wide = reinterpret_cast<unsigned int*>(d_total) + 4;  // four words of the zeroed scalar block
+            // the form: by the batch's average read length -- and not narrower than the last batches against this index asked for
+            seed_words_avg = query_bytes > (uint64_t)num_queries * kSeedMaxLenMid ? 6u : query_bytes > (uint64_t)num_queries * kSeedMaxLen ? 4u : 3u;
+            const uint32_t hint = __atomic_load_n(&idx->seed_words_hint, __ATOMIC_RELAXED);
+            seed_words = seed_words_avg > hint ? seed_words_avg : hint;
+            const bool mid_reads = seed_words == 4u, long_reads = seed_words == 6u;
             const dim3 gs(grid_for((uint64_t)num_queries, 4 * (long_reads ? kSeedReadsLong : mid_reads ? kSeedReadsMid : kSeedReads)));
             // (reads of up to 192 letters: three plane words a strand; a batch whose reads average more: four, or six)
             if (long_reads) {
@@ -4059,6 +4088,19 @@ int SearchJob::collect() {
     total = scal[8];                            // all MEMs
     saw_long = speculated && (uint32_t)(scal[1] >> 32) != 0u;
     if (saw_long) return SLAMEM_OK;  // (nothing of this run is used: find_mems_device starts again)
+    if (seeded) {
+        // more than an eighth of the (sampled) reads were left to the index walk only because the form was too narrow: the next batch
+        // takes the form that holds them; a wider form than the average asks for that no read needed: one step back
+        const uint64_t c4 = (uint32_t)scal[2], c6 = (uint32_t)(scal[2] >> 32), sampled = (uint32_t)(scal[3] >> 32);  // (a sample of the blocks counts)
+        const bool needed = (uint32_t)scal[3] != 0u;
+        uint32_t* hp = const_cast<uint32_t*>(&idx->seed_words_hint);
+        const uint32_t hint = __atomic_load_n(hp, __ATOMIC_RELAXED);
+        uint32_t next = hint;
+        if (c6 * 8u > sampled) next = 6u;
+        else if ((c4 + c6) * 8u > sampled) next = hint > 4u ? hint : 4u;
+        else if (seed_words > seed_words_avg && seed_words == hint && !needed) next = hint == 6u ? 4u : 0u;
+        if (next != hint) __atomic_store_n(hp, next, __ATOMIC_RELAXED);
+    }
     if ((uint32_t)(scal[4] >> 32) != 0u) {
         // (not SLAMEM_ERR_CAPACITY: callers answer that one by asking again with more room)
         set_error("slamem_find_mems_device: one work item emits 2^28 or more MEMs (a 4096-position slice against a highly "

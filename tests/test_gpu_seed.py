@@ -129,8 +129,11 @@ def test_reads_longer_than_the_planes_go_to_the_index_walk(eng):
     st, _ = check(eng, t, reads_from(rng, t, 100, 500, 0.02), 25, True, expect_seed=False)    # beyond all three
     qs = reads_from(rng, t, 300, 193, 0.02) + reads_from(rng, t, 900, 100, 0.02) + reads_from(rng, t, 20, 400, 0.02)
     order = rng.permutation(len(qs))
-    st, _ = check(eng, t, [qs[i] for i in order], 25, True, min_left=2 * 320)                 # three words (average 128): 193 and 400 are left
-    assert st["seed_strands_left"] <= 2 * 320 + 40
+    # (average 128: three words -- the first search leaves the reads of 193 and 400 letters to the index walk and tells the index
+    #  that a quarter of the reads were too long for the form; the search the counters come from is the second: four words, the
+    #  reads of 400 letters are left.  test_the_form_follows_the_reads_of_the_last_batch looks at each step)
+    st, _ = check(eng, t, [qs[i] for i in order], 25, True, min_left=2 * 20)
+    assert st["seed_strands_left"] <= 2 * 20 + 40
     qs = reads_from(rng, t, 600, 250, 0.02) + reads_from(rng, t, 300, 150, 0.02) + reads_from(rng, t, 40, 385, 0.02) + reads_from(rng, t, 30, 257, 0.02)
     order = rng.permutation(len(qs))
     st, _ = check(eng, t, [qs[i] for i in order], 20, True, min_left=2 * 70)                  # four words (average 225): 257 and 385 are left
@@ -139,6 +142,44 @@ def test_reads_longer_than_the_planes_go_to_the_index_walk(eng):
     order = rng.permutation(len(qs))
     st, _ = check(eng, t, [qs[i] for i in order], 20, True, min_left=2 * 40)                  # six words (average 273): the reads of 385 letters are left (340: 33 windows at s = 10, stay)
     assert st["seed_strands_left"] <= 2 * 40 + 60
+
+
+def test_the_form_follows_the_reads_of_the_last_batch(eng):
+    """The seed kernel's form (three, four or six plane words a strand) is chosen by a batch's AVERAGE read length, which a batch
+    of mixed lengths defeats: reads beyond the form are left to the index walk, each at the cost of a walk.  The kernel counts
+    them; when they are more than an eighth of the batch, the next batch against the same index takes the form that holds
+    them, and goes back when a batch comes that did not need it.  Every answer equals the oracle's whatever the form."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(257)
+    t = rng.choice(ACGT, size=120_000)
+    mixed = reads_from(rng, t, 700, 150, 0.02) + reads_from(rng, t, 300, 250, 0.02)      # average 180
+    order = rng.permutation(len(mixed))
+    mixed = [mixed[i] for i in order]
+    longer = reads_from(rng, t, 700, 150, 0.02) + reads_from(rng, t, 300, 380, 0.02)     # average 219
+    short = reads_from(rng, t, 1000, 150, 0.02)
+    o = po.OracleIndex(t.tobytes())
+    g = eng.Index.build(t.tobytes())
+    try:
+        def run(qs):
+            q, off = pack(qs)
+            om, obc = o.match_batch(q, off, 20, True)
+            gm, goff = g.find_mems(q, off, 20, True)
+            assert np.array_equal(np.diff(goff.astype(np.int64)), obc.astype(np.int64))
+            for f in ("ref_pos", "query_pos", "length"):
+                assert np.array_equal(gm[f], om[f]), f
+            return seed_stats(eng, g, q, off, 20, True)["seed_strands_left"]
+        q, off = pack(mixed)
+        assert seed_stats(eng, g, q, off, 20, True)["seed_strands_left"] >= 2 * 300   # three words: the reads of 250 letters are left
+        assert run(mixed) <= 100                                                       # four words from the second batch on
+        assert run(short) <= 100                                                       # (still four; no read needed them: back to three)
+        q, off = pack(mixed)
+        assert seed_stats(eng, g, q, off, 20, True)["seed_strands_left"] >= 2 * 300   # three words again
+        assert run(mixed) <= 100
+        q, off = pack(longer)
+        assert seed_stats(eng, g, q, off, 20, True)["seed_strands_left"] >= 2 * 300   # four words (average and hint): 380 letters are left
+        assert run(longer) <= 100                                                      # six words
+    finally:
+        g.close()
 
 
 def test_every_read_length_in_one_batch(eng):
