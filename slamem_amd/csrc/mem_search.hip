@@ -2569,7 +2569,36 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
 
     // ---- the wave's reads: lengths, windows, bit-planes of both strands -------------------------------------------------
     const uint64_t off = lane <= nr ? A.offsets[r0 + lane] : 0ull;
+    // The reads' bytes are asked for BEFORE the offsets have arrived, on the guess that every read of the batch is as long as
+    // the first (sequencing runs are): where this wave's reads lie then follows from three words every wave reads (scalar
+    // loads, cached).  The guess is checked against the offsets when they are there; a wave it does not hold for asks again.
+    // A wave's life is a chain of dependent round trips (offsets, bytes, lookups, compares -- twice with two rounds) of about
+    // 2 us each, and the chip holds 4,096 waves: one link less is 0.25 ms of the headline's 476,192 waves.
+    constexpr uint32_t kRawChunks = R * NW * 4u + 1u, kSpecIters = (kRawChunks + 63u) / 64u;
+#ifndef SLAMEM_SEED_NO_SPEC
+    constexpr bool kSpec = kSpecIters <= 5u;
+#else
+    constexpr bool kSpec = false;
+#endif
+    uint4 sv[kSpec ? kSpecIters : 1u];
+    uint64_t g0 = 0, len0 = 0;
+    bool spec = false;
+    if (kSpec) {
+        const uint64_t o0 = A.offsets[0], o1 = A.offsets[1], o_end = A.offsets[A.num_queries];
+        len0 = o1 - o0;
+        g0 = o0 + r0 * len0;
+        const uint64_t g1 = g0 + (uint64_t)nr * len0;
+        spec = len0 != 0ull && len0 <= (uint64_t)kMaxLen && g1 <= o_end;  // (at most R * NW * 64 bytes: they fit the buffer; nothing behind the batch is touched)
+        const uint32_t gn = spec ? (uint32_t)(((g1 - 1u) >> 4) - (g0 >> 4) + 1u) : 0u;
+        const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + (g0 >> 4);
+#pragma unroll
+        for (uint32_t j = 0; j < kSpecIters; j++) {
+            const uint32_t c = lane + 64u * j;
+            sv[j] = c < gn ? src[c] : make_uint4(0, 0, 0, 0);
+        }
+    }
     const uint64_t offn = __shfl_down(off, 1);
+    if (kSpec) spec = spec && __ballot(lane <= nr && off != g0 + (uint64_t)lane * len0) == 0ull;
     uint32_t len = 0, nwin = 0;
     bool left = false;  // both strands of the read are left to K8
     if (lane < nr) {
@@ -2612,8 +2641,14 @@ __global__ void __launch_bounds__(256, SLAMEM_SEED_WAVES) k_seed_mems(SearchArgs
     const uint64_t span1 = u64_of((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)nr), (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)nr));
     const uint64_t chunk0 = span0 >> 4;
     const uint32_t nchunks = span1 > span0 ? (uint32_t)(((span1 - 1u) >> 4) - chunk0 + 1u) : 0u;
-    const bool staged = nchunks <= R * NW * 4u + 1u;
-    if (staged) {
+    const bool staged = nchunks <= kRawChunks;
+    if (kSpec && spec) {  // (the guess held: span0 = g0, the chunks asked for are the wave's)
+#pragma unroll
+        for (uint32_t j = 0; j < kSpecIters; j++) {
+            const uint32_t c = lane + 64u * j;
+            if (c < nchunks) S.raw[c] = sv[kSpec ? j : 0u];
+        }
+    } else if (staged) {
         const uint4* src = reinterpret_cast<const uint4*>(A.qwords) + chunk0;
         for (uint32_t c = lane; c < nchunks; c += 64u) S.raw[c] = src[c];
     }
