@@ -2455,7 +2455,8 @@ __global__ void __launch_bounds__(256) k_prefilter_list(SearchArgs A, const uint
 //      its reverse complement -- the window of the reverse strand that covers the same letters (strand offset len - k - o;
 //      those offsets form a residue class mod s too, so the reverse strand's MEMs all hold one).  One lane per window, in two
 //      rounds when the windows lie close: every m-th window first; a window of the other kind that lies inside a run a
-//      first-round compare measured, and whose k-mer occurs once in the text (a plane of the text units), is not looked up;
+//      first-round compare measured, and whose k-mer occurs once in the text (a plane of the text units), is not looked up
+//      (one strand asked for: first-round hits in the other orientation are compared too, for these marks only);
 //   2. a hit (strand, text position p, strand offset o) is a diagonal d = p - o; the MEM around the window is the run of
 //      agreeing letters on that diagonal: the strand (bit-planes in LDS) XOR the text (four 32-byte units = the 192 letters
 //      from d on), one lane per compare.  A run that holds a first-round window is reported by the first of those, one that
@@ -2471,6 +2472,8 @@ __global__ void __launch_bounds__(256) k_prefilter_list(SearchArgs A, const uint
 // in the reference: a MEM may span one), a read longer than the planes hold (or with more than 64 windows), a bucket with more
 // than 28 k-mers (a repeat family), lists that run over.  Nothing here is approximate: a read is either reported completely
 // by this kernel or completely by K8.
+// Three forms (plane words a strand: 3, 4, 6 = reads of up to 192, 256, 384 letters), chosen per batch by the average read
+// length and by what the last batches against the index left for their length (SearchJob::prep / collect, seed_words_hint).
 #ifndef SLAMEM_SEED_READS
 #define SLAMEM_SEED_READS 21
 #endif
