@@ -268,6 +268,22 @@ double* last_search_clock();  // diagnostics: {us until the work list was empty,
 }  // namespace slamem
 
 // The opaque handle of the C ABI.
+namespace slamem {
+// The note a batch leaves in the index handle for the next one (slamem_index::seed_words_hint; mem_search.hip, collect()):
+// `hint` the note as it was (0, 4 or 6 plane words), `words` the form the batch ran, `words_avg` the form its average read
+// length alone asks for; over the sampled reads: c4 / c6 reads left to the index walk only for their length that four / six
+// words would hold, `needed` some read was longer than the next narrower form holds.  More than an eighth of the sample left
+// for their length: the form that holds them; a form wider than the average asks for, taken from the note, that no read
+// needed: one step back.
+inline uint32_t seed_words_next(uint32_t hint, uint32_t words, uint32_t words_avg, uint64_t c4, uint64_t c6, uint64_t sampled,
+                                bool needed) {
+    if (c6 * 8u > sampled) return 6u;
+    if ((c4 + c6) * 8u > sampled) return hint > 4u ? hint : 4u;
+    if (words > words_avg && words == hint && !needed) return hint == 6u ? 4u : 0u;
+    return hint;
+}
+}  // namespace slamem
+
 struct slamem_index {
     slamem::ArenaHeader hdr;   // host copy
     void* arena;               // device

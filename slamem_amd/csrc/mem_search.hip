@@ -4133,10 +4133,7 @@ int SearchJob::collect() {
         const bool needed = (uint32_t)scal[3] != 0u;
         uint32_t* hp = const_cast<uint32_t*>(&idx->seed_words_hint);
         const uint32_t hint = __atomic_load_n(hp, __ATOMIC_RELAXED);
-        uint32_t next = hint;
-        if (c6 * 8u > sampled) next = 6u;
-        else if ((c4 + c6) * 8u > sampled) next = hint > 4u ? hint : 4u;
-        else if (seed_words > seed_words_avg && seed_words == hint && !needed) next = hint == 6u ? 4u : 0u;
+        const uint32_t next = seed_words_next(hint, seed_words, seed_words_avg, c4, c6, sampled, needed);
         if (next != hint) __atomic_store_n(hp, next, __ATOMIC_RELAXED);
     }
     if ((uint32_t)(scal[4] >> 32) != 0u) {
